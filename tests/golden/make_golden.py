@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz by IMPORTING the reference on CPU.
+
+Run in the build container only (needs /root/reference; the GPU box never has it):
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+What is pinned:
+  1. model_<case>.npz : for several (J, F, RF, stage, camera-embedding) configurations, the
+     reference RIEModel / RIETrajectoryModel outputs and intermediate taps for the deterministic
+     synthetic weights/inputs of ray3d_amd.synth (loaded with load_state_dict(strict=True), which
+     also pins our state_dict key grammar and shapes against the reference constructors).
+  2. cameras.npz      : CameraInfoPacket-derived constants and uv -> ray pairs for real camera
+     calibrations taken from the reference's H36M / 3DHP tables (numbers only).
+  3. evalcore.npz     : Trainer.evaluate_core's five metrics (with and without flip TTA) and its
+     return_predictions output on synthetic clips.
+  4. losses.npz       : mpjpe / n_mpjpe / p_mpjpe / mean_velocity_error known answers.
+Only numbers leave this script; no reference source text is stored.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("RAY3D_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+sys.modules.setdefault("cv2", types.ModuleType("cv2"))   # only dereferenced on paths we do not take
+
+from lib.model import Model as RefModel                     # noqa: E402
+from lib.camera.camera import CameraInfoPacket              # noqa: E402
+from lib.dataloader.generators import UnchunkedGenerator    # noqa: E402
+from lib.train_val.trainer import Trainer                   # noqa: E402
+from lib.loss import loss as ref_loss                        # noqa: E402
+from lib.dataset.h36m_dataset import (h36m_cameras_extrinsic_params,      # noqa: E402
+                                      h36m_cameras_intrinsic_params)
+from lib.dataset.mpii_3dhp_dataset import camera_params as dhp_camera_params  # noqa: E402
+
+from ray3d_amd.spec import config_from_dicts, default_model_config   # noqa: E402
+from ray3d_amd import synth                                          # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(4)
+
+CASES = {
+    # name: (model_config overrides, batch, out_scale)
+    "j17_rf27_s3": (dict(ARCHITECTURE="3,3,3"), 3, 1.0),
+    "j17_rf243_s3": (dict(ARCHITECTURE="3,3,3,3,3"), 2, 1.0),
+    "j17_rf9_s1": (dict(ARCHITECTURE="3,3", STAGE=1), 3, 1.0),
+    "j14_rf9_s3": (dict(ARCHITECTURE="3,3", NUM_KPTS=14), 4, 1.0),
+    "j15_rf9_s3": (dict(ARCHITECTURE="3,3", NUM_KPTS=15), 3, 1.0),
+    "j17_f2_rf27_noemb_s3": (dict(ARCHITECTURE="3,3,3", INPUT_DIM=2, CAMERA_EMBDDING=False), 3, 1.0),
+    "j17_rf81_s2_big": (dict(ARCHITECTURE="3,3,3,3", STAGE=2), 2, 8.0),
+}
+
+
+def load_synth(module, cfg, seed, out_scale):
+    state = synth.synth_state(cfg, seed=seed, out_scale=out_scale)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in state.items()}
+    module.load_state_dict(sd, strict=True)
+    module.eval()
+    return state
+
+
+def run_with_taps(module, x, p, tap_names):
+    taps, hooks = {}, []
+    mods = dict(module.named_modules())
+    for name in tap_names:
+        def mk(nm):
+            def hook(_m, _i, o):
+                taps[nm] = o.detach().clone().numpy()
+            return hook
+        hooks.append(mods[name].register_forward_hook(mk(name)))
+    with torch.no_grad():
+        out = module(torch.from_numpy(x), torch.from_numpy(p)).numpy()
+    for h in hooks:
+        h.remove()
+    return out, taps
+
+
+def gen_models():
+    for name, (over, batch, out_scale) in CASES.items():
+        mc = default_model_config(**over)
+        ref = RefModel(mc, {}, is_train=False)
+        pos, trj = ref.get_pos_model(), ref.get_trj_model()
+        cpos, ctrj = config_from_dicts(mc, "pos"), config_from_dicts(mc, "trj")
+        load_synth(pos, cpos, 1, out_scale)
+        load_synth(trj, ctrj, 2, out_scale)
+        x = synth.synth_rays(batch, cpos, seed=3)
+        p = synth.synth_param(batch, seed=4)
+        nlev = len(cpos.filter_widths)
+        pos_taps = (["LocalLayer_%s" % b for b in cpos.branch_names()] + ["GlobalInfo"]
+                    + ["Integration_%s" % b for b in cpos.branch_names()])
+        if cpos.stage != 1:
+            pos_taps += ["FuseBlocks.%d" % i for i in range(5)]
+        if cpos.camera_embedding:
+            pos_taps += ["embedder"]
+        # per-level pre-activation BN outputs, Torso only (clone happens before inplace LeakyReLU)
+        pos_taps += ["LocalLayer_Torso.expand_bn"] + ["LocalLayer_Torso.layers_bn.%d" % i
+                                                     for i in range(2 * (nlev - 1))]
+        trj_taps = ["LocalLayer", "GlobalInfo", "Integration", "LocalLayer.expand_bn"] + \
+                   ["LocalLayer.layers_bn.%d" % i for i in range(2 * (nlev - 1))]
+        if ctrj.camera_embedding:
+            trj_taps += ["embedder"]
+        out_pos, tp = run_with_taps(pos, x, p, pos_taps)
+        out_trj, tt = run_with_taps(trj, x, p, trj_taps)
+        blob = dict(x=x, param=p, out_pos=out_pos, out_trj=out_trj,
+                    n_state_pos=np.int64(len(pos.state_dict())),
+                    n_state_trj=np.int64(len(trj.state_dict())),
+                    receptive_field=np.int64(pos.receptive_field()))
+        for k, v in tp.items():
+            # per-level taps: keep window 0 only to stay small; channels-first (C, T) as in torch
+            blob["pos/" + k] = v[0] if ("_bn" in k) else v
+        for k, v in tt.items():
+            blob["trj/" + k] = v[0] if ("_bn" in k) else v
+        blob["model_config_keys"] = np.array(sorted(mc.keys()))
+        blob["model_config_vals"] = np.array([str(mc[k]) for k in sorted(mc.keys())])
+        np.savez_compressed(os.path.join(HERE, "model_%s.npz" % name), **blob)
+        print("model_%s: out_pos %s |max| %.3f  out_trj |max| %.3f  states %d/%d" % (
+            name, out_pos.shape, np.abs(out_pos).max(), np.abs(out_trj).max(),
+            len(pos.state_dict()), len(trj.state_dict())))
+
+
+def ref_cameras():
+    """(tag, K, R, t) exactly as the reference datasets hand them to CameraInfoPacket
+    (lib/dataset/h36m_dataset.py:351-386, lib/dataset/mpii_3dhp_dataset.py:309-341)."""
+    cams = []
+    for subj, idxs in (("S9", (0, 1, 2, 3)), ("S1", (0,)), ("S11", (2,))):
+        for i in idxs:
+            ext, intr = h36m_cameras_extrinsic_params[subj][i], h36m_cameras_intrinsic_params[i]
+            K = np.eye(3, dtype=np.float64)
+            f32 = lambda v: np.array(v, dtype="float32")
+            fl, ce = f32(intr["focal_length"]), f32(intr["center"])
+            K[0, 0], K[1, 1], K[0, 2], K[1, 2] = fl[0], fl[1], ce[0], ce[1]
+            R = f32(ext["R"])
+            t = np.array(f32(ext["translation"]) / 1000, dtype=np.float64).reshape(3, 1)
+            cams.append(("h36m_%s_%d" % (subj, i), K, R, t))
+    for subj in list(dhp_camera_params.keys())[:2]:
+        for i, cam in enumerate(dhp_camera_params[subj][:3]):
+            if "translation" not in cam:
+                continue
+            f32 = lambda v: np.array(v, dtype="float32")
+            fl, ce = f32(cam["focal_length"]), f32(cam["center"])
+            K = np.eye(3, dtype=np.float64)
+            K[0, 0], K[1, 1], K[0, 2], K[1, 2] = fl[0], fl[1], ce[0], ce[1]
+            R = f32(cam["R"])
+            t = np.array(f32(cam["translation"]), dtype=np.float64).reshape(3, 1)
+            cams.append(("3dhp_%s_%d" % (subj, i), K, R, t))
+    return cams
+
+
+def gen_cameras():
+    blob = {}
+    tags = []
+    for tag, K, R, t in ref_cameras():
+        cam = CameraInfoPacket(P=None, K=K, R=R, t=t, res_w=1000, res_h=1000, azimuth=0,
+                               dist_coeff=None, undistort=False)
+        uv = 1000.0 * synth.hash_uniform("uv." + tag, (5, 17, 2), 7)
+        rays = cam.get_cam_ray_given_uv(uv)
+        X = np.concatenate([synth.hash_uniform("xw." + tag, (4, 17, 2), 7) * 2 - 1,
+                            synth.hash_uniform("zw." + tag, (4, 17, 1), 7) * 1.8], axis=-1)
+        tags.append(tag)
+        blob.update({
+            tag + "/K": K, tag + "/R": R.astype(np.float64), tag + "/t": t,
+            tag + "/height": np.float64((-cam.Rw2c.T @ cam.Tw2c)[2][0]),
+            tag + "/pitch": np.float64(cam.cam_pitch_rad),
+            tag + "/Rc2n": cam.Rc2n, tag + "/Tc2n": cam.Tc2n,
+            tag + "/Rn2w": cam.Rn2w, tag + "/Tn2w": cam.Tn2w,
+            tag + "/Rw2n": cam.Rw2n, tag + "/Tw2n": cam.Tw2n,
+            tag + "/uv": uv, tag + "/rays": rays,
+            tag + "/uv_back": cam.get_uv_given_cam_ray(rays),
+            tag + "/Xw": X, tag + "/Xn": cam.world2normalized(X),
+            tag + "/Xw_back": cam.normalized2world(cam.world2normalized(X)),
+            tag + "/proj": cam.project(np.concatenate([X, np.ones_like(X[..., :1])], -1)),
+        })
+    blob["tags"] = np.array(tags)
+    np.savez_compressed(os.path.join(HERE, "cameras.npz"), **blob)
+    print("cameras:", len(tags))
+
+
+def synth_clip(tag, n, cam, seed):
+    """World joints ~ N(0,0.3^2)+[0,0,1] with temporal smoothness, projected by `cam`."""
+    u = synth.hash_uniform("clip." + tag, (n, 17, 3, 4), seed)
+    g = (u.sum(-1) - 2.0) * np.sqrt(3.0)            # ~N(0,1) (Irwin-Hall, 4 terms)
+    pose = 0.3 * g[:1] + 0.03 * np.cumsum(g, axis=0) / np.sqrt(np.arange(1, n + 1))[:, None, None]
+    Xw = pose + np.array([0.0, 0.0, 1.0])
+    uv = cam.project(np.concatenate([Xw, np.ones_like(Xw[..., :1])], -1))
+    rays = cam.get_cam_ray_given_uv(uv)
+    gt = cam.world2normalized(Xw)
+    return Xw, uv, rays, gt
+
+
+def gen_evalcore():
+    mc = default_model_config(ARCHITECTURE="3,3,3")
+    ref = RefModel(mc, {}, is_train=False)
+    pos, trj = ref.get_pos_model(), ref.get_trj_model()
+    cpos, ctrj = config_from_dicts(mc, "pos"), config_from_dicts(mc, "trj")
+    load_synth(pos, cpos, 1, 1.0)
+    load_synth(trj, ctrj, 2, 1.0)
+    cams_all = ref_cameras()
+    picks = [(cams_all[0], 100), (cams_all[1], 57), (cams_all[6], 31)]
+    cams, p3d, p2d, blob = [], [], [], {}
+    for ci, ((tag, K, R, t), n) in enumerate(picks):
+        cam = CameraInfoPacket(P=None, K=K, R=R, t=t, res_w=1000, res_h=1000, azimuth=0,
+                               dist_coeff=None, undistort=False)
+        Xw, uv, rays, gt = synth_clip(tag, n, cam, 11 + ci)
+        cams.append(cam)
+        p3d.append(gt.astype(np.float32))          # dataset stores normalized-space GT as float32
+        p2d.append(rays.astype(np.float32))
+        blob.update({"clip%d/K" % ci: K, "clip%d/R" % ci: R.astype(np.float64), "clip%d/t" % ci: t,
+                     "clip%d/uv" % ci: uv, "clip%d/rays" % ci: rays.astype(np.float32),
+                     "clip%d/gt_norm" % ci: gt.astype(np.float32), "clip%d/Xw" % ci: Xw})
+    # H36M 17-joint symmetry (lib/dataset/h36m_dataset.py skeleton after joint removal)
+    kps_left, kps_right = [4, 5, 6, 11, 12, 13], [1, 2, 3, 14, 15, 16]
+    data_config = {"RAY_ENCODING": True}
+    tr = Trainer(data_config, mc, {"LEARNING_RATE": 1e-3}, {}, None, None,
+                 {"train_pos": pos, "test_pos": pos, "train_trj": trj, "test_trj": trj},
+                 None, kps_left, kps_right, kps_left, kps_right, None)
+    pad = (cpos.receptive_field - 1) // 2
+    for flip in (False, True):
+        gen = UnchunkedGenerator(cams, p3d, p2d, pad=pad, causal_shift=0, kps_left=kps_left,
+                                 kps_right=kps_right, joints_left=kps_left, joints_right=kps_right)
+        e = tr.evaluate_core(gen, flip_test=flip)
+        blob["metrics_flip%d" % int(flip)] = np.array(e, dtype=np.float64)
+        print("evaluate_core flip=%s ->" % flip, e)
+        for ci in range(len(cams)):
+            g1 = UnchunkedGenerator([cams[ci]], [p3d[ci]], [p2d[ci]], pad=pad, causal_shift=0,
+                                    kps_left=kps_left, kps_right=kps_right,
+                                    joints_left=kps_left, joints_right=kps_right)
+            blob["clip%d/metrics_flip%d" % (ci, int(flip))] = np.array(
+                tr.evaluate_core(g1, flip_test=flip), dtype=np.float64)
+    gen = UnchunkedGenerator([cams[0]], [p3d[0]], [p2d[0]], pad=pad, causal_shift=0)
+    blob["clip0/predictions"] = tr.evaluate_core(gen, return_predictions=True)
+    blob["kps_left"], blob["kps_right"] = np.array(kps_left), np.array(kps_right)
+    np.savez_compressed(os.path.join(HERE, "evalcore.npz"), **blob)
+
+
+def gen_losses():
+    a = (synth.hash_uniform("loss.a", (6, 1, 17, 3), 5) * 2 - 1)
+    b = a + 0.1 * (synth.hash_uniform("loss.b", (6, 1, 17, 3), 5) * 2 - 1)
+    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+    blob = dict(pred=a, target=b,
+                mpjpe=np.float64(ref_loss.mpjpe(ta, tb).item()),
+                n_mpjpe=np.float64(ref_loss.n_mpjpe(ta, tb).item()),
+                p_mpjpe=np.float64(ref_loss.p_mpjpe(a.reshape(-1, 17, 3).copy(), b.reshape(-1, 17, 3).copy())),
+                mpjve=np.float64(ref_loss.mean_velocity_error(a.reshape(-1, 17, 3), b.reshape(-1, 17, 3))))
+    np.savez_compressed(os.path.join(HERE, "losses.npz"), **blob)
+    print("losses:", {k: float(v) for k, v in blob.items() if np.ndim(v) == 0})
+
+
+if __name__ == "__main__":
+    gen_cameras()
+    gen_losses()
+    gen_models()
+    gen_evalcore()
+    tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
+    print("total fixture bytes: %.2f MB" % (tot / 1e6))
