@@ -1,0 +1,134 @@
+/*
+ * ray3d_hip.h - C ABI of libray3d_hip.so: the MI355X (gfx950) implementation of Ray3D's
+ * 2D->3D lifting forward pass.
+ *
+ * The reference (YxZhxn/Ray3D) has no FFI for this path; its seam is the Python nn.Module
+ * contract.  Each entry point below names the reference interface it
+ * replaces; INTEGRATION.md shows the ctypes stub a maintainer would add on the reference side.
+ *
+ * Conventions: plain C, int status codes (0 = ok, <0 = error, text via r3d_last_error()),
+ * no exceptions cross the boundary.  All *_dev pointers are device (HBM) pointers owned by the
+ * caller; the library owns only its packed weights.  A handle is bound to the HIP device that
+ * was current at r3d_finalize(); it is not thread-safe, different handles are independent.
+ * Every call enqueues on the given hipStream_t (passed as void*) and returns without syncing.
+ */
+#ifndef RAY3D_HIP_H
+#define RAY3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define R3D_OK 0
+#define R3D_ERR_ARG (-1)        /* bad argument / unsupported configuration            */
+#define R3D_ERR_KEY (-2)        /* unknown, duplicate or missing state_dict key         */
+#define R3D_ERR_SHAPE (-3)      /* tensor shape does not match the configuration         */
+#define R3D_ERR_STATE (-4)      /* call order violated (e.g. forward before finalize)    */
+#define R3D_ERR_HIP (-5)        /* a HIP runtime call failed                             */
+#define R3D_ERR_WORKSPACE (-6)  /* workspace too small                                   */
+
+#define R3D_KIND_POS 0 /* lib/model/rie.py:172  RIEModel            -> (B,1,J,3) */
+#define R3D_KIND_TRJ 1 /* lib/model/rie.py:437  RIETrajectoryModel  -> (B,1,1,3) */
+
+/* Mirrors the constructor arguments the reference factory passes
+ * (lib/model/__init__.py:23-46 -> lib/model/rie.py:178-181 / :443-446). */
+typedef struct {
+    int32_t kind;          /* R3D_KIND_POS | R3D_KIND_TRJ                               */
+    int32_t num_joints;    /* NUM_KPTS: 14, 15 or 17                                    */
+    int32_t in_features;   /* INPUT_DIM: 3 (rays) or 2                                  */
+    int32_t num_levels;    /* len(ARCHITECTURE); every filter width must be 3           */
+    int32_t channels;      /* CHANNELS (multiple of 32)                                 */
+    int32_t latent;        /* LATENT_FEATURES_DIM (multiple of 32)                      */
+    int32_t stage;         /* STAGE (pos only; 1 = no FuseBlocks)                       */
+    int32_t extrinsic_dim; /* EXTRINSIC_DIM, or 0 when CAMERA_EMBDDING is False         */
+    int32_t embed_dim;     /* EMBEDD_DIM (multiple of 32), or 0 when CAMERA_EMBDDING off */
+} r3d_config;
+
+typedef struct r3d_model r3d_model;
+
+/* ---- construction: replaces RIEModel(...)/RIETrajectoryModel(...) + load_state_dict ---- */
+
+/* lib/model/rie.py:178-253 / :443-494 (module construction). */
+int r3d_create(const r3d_config *cfg, r3d_model **out);
+int r3d_destroy(r3d_model *m);
+
+/* The float tensors of the reference state_dict this configuration expects (SURVEY.md A.4;
+ * int64 num_batches_tracked buffers are not part of the ABI).  Lets a binding enumerate keys. */
+int r3d_num_weights(const r3d_model *m);
+const char *r3d_weight_key(const r3d_model *m, int index);
+int r3d_weight_shape(const r3d_model *m, int index, int64_t shape[4], int *rank);
+
+/* nn.Module.load_state_dict(strict=True) equivalent (lib/train_val/trainer.py:161-164,
+ * lib/utils/utils.py:208-218, but loud: unknown key -> R3D_ERR_KEY, wrong shape ->
+ * R3D_ERR_SHAPE).  `host` is float32 row-major in torch layout (Conv1d (Cout,Cin,k),
+ * Linear (out,in)); it is copied.  A leading "module." (nn.DataParallel checkpoints,
+ * lib/model/__init__.py:52) is stripped.  May be called again after finalize to update. */
+int r3d_set_weight(r3d_model *m, const char *key, const float *host, const int64_t *shape, int rank);
+
+/* model.eval() + device placement: folds eval-mode BatchNorm (eps 1e-5) into the preceding
+ * Conv1d/Linear in float64, repacks every layer into the GEMM layout the kernels read and
+ * uploads to the current HIP device.  R3D_ERR_KEY (message lists the first missing key) if any
+ * tensor was not set. */
+int r3d_finalize(r3d_model *m);
+
+/* ---- forward: replaces pos_model(inputs_2d, inputs_param) [+ trj_model(...)] ---- */
+
+#define R3D_INPUT_RAYS 0 /* x is what the reference feeds the model: ray-encoded keypoints  */
+#define R3D_INPUT_UV 1   /* x is pixel keypoints; rays are computed on the fly from `cam`   */
+
+typedef struct {
+    int32_t mode;          /* R3D_INPUT_RAYS | R3D_INPUT_UV                                  */
+    const float *x_dev;    /* RAYS: float32 (frames, J, F);  UV: float32 (frames, J, 2)      */
+    int64_t window_stride; /* frames between the starts of consecutive windows:
+                              RF for a (B,RF,J,F) batch (lib/train_val/trainer.py:47-58 output),
+                              1 to slide over an edge-padded clip in place (replaces
+                              eval_data_prepare: window i = frames [i, i+RF))                */
+    const float *param_dev;/* float32 [height, pitch] rows (lib/train_val/trainer.py:297);
+                              ignored (may be NULL) when the camera embedding is off         */
+    int64_t param_stride;  /* floats between consecutive windows' rows: extrinsic_dim for a
+                              (B,E) tensor, 0 to broadcast one row to every window           */
+    const double *cam_dev; /* UV mode only: float64 rows {fx, fy, cx, cy, cos(pitch),
+                              sin(pitch), 0, 0} (lib/camera/camera.py:423-471)               */
+    int64_t cam_stride;    /* doubles between consecutive windows' rows: 8, or 0 = broadcast */
+} r3d_input;
+
+/* Bytes of scratch HBM a forward of B windows needs (either model may be NULL). */
+size_t r3d_workspace_bytes(const r3d_model *pos, const r3d_model *trj, int64_t B);
+
+/* One network, exactly the reference module's forward:
+ *   pos: out_dev (B,1,J,3)   lib/model/rie.py:284-434
+ *   trj: out_dev (B,1,1,3)   lib/model/rie.py:518-559 */
+int r3d_forward(r3d_model *m, const r3d_input *in, int64_t B, float *out_dev,
+                void *workspace_dev, size_t workspace_bytes, void *hip_stream);
+
+/* Both networks in one pass over the input: out_dev (B,1,J,3) = pos + trj broadcast over
+ * joints (lib/train_val/trainer.py:337,346,353); out_trj_dev (B,1,1,3) optional (may be NULL). */
+int r3d_forward_pair(r3d_model *pos, r3d_model *trj, const r3d_input *in, int64_t B,
+                     float *out_dev, float *out_trj_dev, void *workspace_dev,
+                     size_t workspace_bytes, void *hip_stream);
+
+/* ---- instrumentation (bench.py / tests) ---- */
+
+/* When enabled, the next forward brackets every kernel launch with hipEvents on the launch
+ * stream; r3d_profile_read then synchronises and returns per-launch records. */
+typedef struct {
+    char kernel[48];  /* kernel family name as rocprofv3 shows it (prefix)                  */
+    int32_t stage;    /* position in the launch sequence                                     */
+    int32_t blocks;   /* workgroups launched                                                 */
+    float ms;         /* elapsed milliseconds between the bracketing events                  */
+    double flops;     /* algorithmic FLOPs (2*M*K*N over the reference's layers) in launch   */
+    double bytes;     /* algorithmic HBM bytes (operands read once + result written once)    */
+} r3d_launch_record;
+int r3d_profile_enable(r3d_model *m, int on);
+int r3d_profile_read(r3d_model *m, r3d_launch_record *records, int capacity);
+
+const char *r3d_last_error(void);
+const char *r3d_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

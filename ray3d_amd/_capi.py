@@ -1,0 +1,160 @@
+"""ctypes binding of libray3d_hip.so (C ABI: include/ray3d_hip.h).
+
+There is deliberately no fallback: if the shared library is missing or a call fails, this module
+raises.  It never imports anything from ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libray3d_hip.so")
+
+R3D_KIND_POS, R3D_KIND_TRJ = 0, 1
+R3D_INPUT_RAYS, R3D_INPUT_UV = 0, 1
+
+# every symbol include/ray3d_hip.h declares (tests check the library exports exactly these)
+EXPORTS = (
+    "r3d_create", "r3d_destroy", "r3d_num_weights", "r3d_weight_key", "r3d_weight_shape",
+    "r3d_set_weight", "r3d_finalize", "r3d_workspace_bytes", "r3d_forward", "r3d_forward_pair",
+    "r3d_profile_enable", "r3d_profile_read", "r3d_last_error", "r3d_version",
+)
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("kind", "num_joints", "in_features", "num_levels",
+                                         "channels", "latent", "stage", "extrinsic_dim",
+                                         "embed_dim")]
+
+
+class Input(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("x_dev", C.c_void_p), ("window_stride", C.c_int64),
+                ("param_dev", C.c_void_p), ("param_stride", C.c_int64),
+                ("cam_dev", C.c_void_p), ("cam_stride", C.c_int64)]
+
+
+class LaunchRecord(C.Structure):
+    _fields_ = [("kernel", C.c_char * 48), ("stage", C.c_int32), ("blocks", C.c_int32),
+                ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+class Ray3DHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libray3d_hip.so; raise (never fall back) when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Ray3DHipError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i64p = C.c_void_p, C.POINTER(C.c_int64)
+    lib.r3d_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.r3d_destroy.argtypes = [vp]
+    lib.r3d_num_weights.argtypes = [vp]
+    lib.r3d_weight_key.argtypes = [vp, C.c_int]
+    lib.r3d_weight_key.restype = C.c_char_p
+    lib.r3d_weight_shape.argtypes = [vp, C.c_int, i64p, C.POINTER(C.c_int)]
+    lib.r3d_set_weight.argtypes = [vp, C.c_char_p, vp, i64p, C.c_int]
+    lib.r3d_finalize.argtypes = [vp]
+    lib.r3d_workspace_bytes.argtypes = [vp, vp, C.c_int64]
+    lib.r3d_workspace_bytes.restype = C.c_size_t
+    lib.r3d_forward.argtypes = [vp, C.POINTER(Input), C.c_int64, vp, vp, C.c_size_t, vp]
+    lib.r3d_forward_pair.argtypes = [vp, vp, C.POINTER(Input), C.c_int64, vp, vp, vp, C.c_size_t, vp]
+    lib.r3d_profile_enable.argtypes = [vp, C.c_int]
+    lib.r3d_profile_read.argtypes = [vp, C.POINTER(LaunchRecord), C.c_int]
+    lib.r3d_last_error.restype = C.c_char_p
+    lib.r3d_version.restype = C.c_char_p
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int or fn.restype is None:
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc < 0:
+        raise Ray3DHipError("%s failed (%d): %s" % (what, rc, load().r3d_last_error().decode()))
+    return rc
+
+
+class Handle:
+    """Owns one r3d_model*."""
+
+    def __init__(self, cfg):
+        lib = load()
+        c = Config(R3D_KIND_POS if cfg.kind == "pos" else R3D_KIND_TRJ, cfg.num_joints,
+                   cfg.in_features, len(cfg.filter_widths), cfg.channels, cfg.latent, cfg.stage,
+                   cfg.extrinsic_dim if cfg.camera_embedding else 0,
+                   cfg.embed_dim if cfg.camera_embedding else 0)
+        self.ptr = C.c_void_p()
+        check(lib.r3d_create(C.byref(c), C.byref(self.ptr)), "r3d_create")
+
+    def keys(self) -> List[str]:
+        lib = load()
+        return [lib.r3d_weight_key(self.ptr, i).decode() for i in range(lib.r3d_num_weights(self.ptr))]
+
+    def shape(self, index: int):
+        shp = (C.c_int64 * 4)()
+        rank = C.c_int()
+        check(load().r3d_weight_shape(self.ptr, index, shp, C.byref(rank)), "r3d_weight_shape")
+        return tuple(int(shp[i]) for i in range(rank.value))
+
+    def set_weight(self, key: str, array):
+        """array: C-contiguous float32 numpy array in torch layout."""
+        shp = (C.c_int64 * 4)(*([int(d) for d in array.shape] + [1] * (4 - array.ndim)))
+        check(load().r3d_set_weight(self.ptr, key.encode(), array.ctypes.data_as(C.c_void_p), shp,
+                                    array.ndim), "r3d_set_weight(%s)" % key)
+
+    def finalize(self):
+        check(load().r3d_finalize(self.ptr), "r3d_finalize")
+
+    def profile_enable(self, on: bool):
+        check(load().r3d_profile_enable(self.ptr, 1 if on else 0), "r3d_profile_enable")
+
+    def profile_read(self):
+        cap = 128
+        recs = (LaunchRecord * cap)()
+        n = check(load().r3d_profile_read(self.ptr, recs, cap), "r3d_profile_read")
+        return [dict(kernel=recs[i].kernel.decode(), stage=recs[i].stage, blocks=recs[i].blocks,
+                     ms=recs[i].ms, flops=recs[i].flops, bytes=recs[i].bytes) for i in range(min(n, cap))]
+
+    def close(self):
+        if getattr(self, "ptr", None) and self.ptr.value and _lib is not None:
+            _lib.r3d_destroy(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def workspace_bytes(pos: Optional[Handle], trj: Optional[Handle], batch: int) -> int:
+    return int(load().r3d_workspace_bytes(pos.ptr if pos else None, trj.ptr if trj else None, batch))
+
+
+def make_input(mode, x_ptr, window_stride, param_ptr, param_stride, cam_ptr=None, cam_stride=0) -> Input:
+    return Input(mode, x_ptr, window_stride, param_ptr, param_stride, cam_ptr, cam_stride)
+
+
+def forward(handle: Handle, inp: Input, batch: int, out_ptr: int, ws_ptr: int, ws_bytes: int, stream: int):
+    check(load().r3d_forward(handle.ptr, C.byref(inp), batch, out_ptr, ws_ptr, ws_bytes, stream),
+          "r3d_forward")
+
+
+def forward_pair(pos: Handle, trj: Handle, inp: Input, batch: int, out_ptr: int,
+                 out_trj_ptr: Optional[int], ws_ptr: int, ws_bytes: int, stream: int):
+    check(load().r3d_forward_pair(pos.ptr, trj.ptr, C.byref(inp), batch, out_ptr, out_trj_ptr,
+                                  ws_ptr, ws_bytes, stream), "r3d_forward_pair")

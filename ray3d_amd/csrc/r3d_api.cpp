@@ -1,0 +1,329 @@
+// extern "C" entry points of libray3d_hip.so (contract: include/ray3d_hip.h).
+#include <cstring>
+
+#include "r3d_internal.hpp"
+
+namespace r3d {
+const char *last_error();
+
+// output joint slot -> (body part, index inside the part), lib/model/rie.py:426-431 (quirk Q2:
+// for J = 14 / 15 this is not the inverse of the input grouping).
+static void output_sources(int J, int *src) {
+    int s = 0;
+    auto put = [&](int part, int idx) {
+        for (int f = 0; f < 3; ++f) src[s * 3 + f] = part * DEC_SLOT + idx * 3 + f;
+        ++s;
+    };
+    enum { T = 0, LA = 1, RA = 2, LL = 3, RL = 4 };
+    if (J == 17) {
+        put(T, 0);
+        for (int i = 0; i < 3; ++i) put(LL, i);
+        for (int i = 0; i < 3; ++i) put(RL, i);
+        for (int i = 1; i < 5; ++i) put(T, i);
+        for (int i = 0; i < 3; ++i) put(RA, i);
+        for (int i = 0; i < 3; ++i) put(LA, i);
+    } else if (J == 15) {
+        put(T, 0); put(T, 1);
+        for (int i = 0; i < 3; ++i) put(LL, i);
+        for (int i = 0; i < 3; ++i) put(RL, i);
+        for (int i = 0; i < 3; ++i) put(RA, i);
+        for (int i = 0; i < 3; ++i) put(LA, i);
+        put(T, 2);
+    } else {
+        put(T, 0);
+        for (int i = 0; i < 3; ++i) put(LL, i);
+        for (int i = 0; i < 3; ++i) put(RL, i);
+        for (int i = 0; i < 3; ++i) put(RA, i);
+        for (int i = 0; i < 3; ++i) put(LA, i);
+        put(T, 1);
+    }
+}
+
+static bool same_input_shape(const Model *a, const Model *b) {
+    return a->cfg.num_joints == b->cfg.num_joints && a->cfg.in_features == b->cfg.in_features &&
+           a->cfg.num_levels == b->cfg.num_levels && a->cfg.extrinsic_dim == b->cfg.extrinsic_dim;
+}
+
+struct Recorder {
+    Model *m;
+    hipStream_t stream;
+    size_t n = 0;
+    bool on() const { return m->profiling; }
+    hipError_t begin(const char *kernel, int stage, int blocks, double flops, double bytes) {
+        if (!on()) return hipSuccess;
+        if (n == m->recs.size()) {
+            Model::Rec r;
+            hipError_t e = hipEventCreate(&r.e0);
+            if (e != hipSuccess) return e;
+            if ((e = hipEventCreate(&r.e1)) != hipSuccess) return e;
+            m->recs.push_back(r);
+        }
+        Model::Rec &r = m->recs[n];
+        memset(&r.r, 0, sizeof r.r);
+        strncpy(r.r.kernel, kernel, sizeof r.r.kernel - 1);
+        r.r.stage = stage;
+        r.r.blocks = blocks;
+        r.r.flops = flops;
+        r.r.bytes = bytes;
+        return hipEventRecord(r.e0, stream);
+    }
+    hipError_t end() {
+        if (!on()) return hipSuccess;
+        return hipEventRecord(m->recs[n++].e1, stream);
+    }
+};
+
+static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *out, float *out_trj, void *ws,
+               size_t ws_bytes, void *stream_v) {
+    Model *a = pos ? pos : trj, *b = pos ? trj : nullptr;
+    if (!a) { set_error("forward: no model given"); return R3D_ERR_ARG; }
+    if (!in || !in->x_dev || !out || B <= 0) { set_error("forward: null input/output or B <= 0"); return R3D_ERR_ARG; }
+    for (Model *m : {a, b})
+        if (m && (!m->finalized || m->dirty)) {
+            set_error("forward called before r3d_finalize (or weights changed since)");
+            return R3D_ERR_STATE;
+        }
+    if (b && !same_input_shape(a, b)) { set_error("pos and trj models disagree on J / F / levels / extrinsic_dim"); return R3D_ERR_ARG; }
+    if (in->mode != R3D_INPUT_RAYS && in->mode != R3D_INPUT_UV) { set_error("bad input mode %d", in->mode); return R3D_ERR_ARG; }
+    if (in->mode == R3D_INPUT_UV && (a->cfg.in_features != 3 || !in->cam_dev)) {
+        set_error("R3D_INPUT_UV needs in_features == 3 and cam_dev");
+        return R3D_ERR_ARG;
+    }
+    const bool needs_param = a->cfg.embed_dim > 0 || (b && b->cfg.embed_dim > 0);
+    if (needs_param && !in->param_dev) { set_error("param_dev is required when the camera embedding is on"); return R3D_ERR_ARG; }
+    if (in->window_stride <= 0) { set_error("window_stride must be positive"); return R3D_ERR_ARG; }
+    if (B * (int64_t)(a->RF / 3) * 512 > 0x7fffffffLL * 4) { set_error("B too large for one call"); return R3D_ERR_ARG; }
+
+    Plan *pl = plan_get(a, b);
+    const size_t need = (size_t)pl->floats_per_window * (size_t)B * sizeof(float);
+    if (!ws || ws_bytes < need) {
+        set_error("workspace too small: need %zu bytes, got %zu", need, ws_bytes);
+        return R3D_ERR_WORKSPACE;
+    }
+    hipStream_t stream = (hipStream_t)stream_v;
+    float *wsf = (float *)ws;
+    auto buf_ptr = [&](int id) -> float * { return wsf + (size_t)pl->buffers[id].offset_per_window * (size_t)B; };
+    Recorder rec{a, stream};
+    hipError_t e;
+    int stage_no = 0;
+
+    // ---- prologue
+    EncodeArgs ea;
+    memset(&ea, 0, sizeof ea);
+    ea.x = in->x_dev;
+    ea.cam = in->cam_dev;
+    ea.param = in->param_dev;
+    ea.window_stride = in->window_stride;
+    ea.param_stride = in->param_stride;
+    ea.cam_stride = in->cam_stride;
+    ea.mode = in->mode;
+    ea.J = a->cfg.num_joints;
+    ea.F = a->cfg.in_features;
+    ea.RF = a->RF;
+    ea.tcur = a->RF / a->cfg.in_features;   // quirk Q1: "current" frame is RF // in_features
+    ea.B = B;
+    ea.nbranch = (int)pl->enc.size();
+    double enc_bytes = (double)B * a->RF * ea.J * (in->mode == R3D_INPUT_UV ? 2 : ea.F) * 4.0;
+    for (int i = 0; i < ea.nbranch; ++i) {
+        const Model *m = pl->m[pl->enc[i].model];
+        const Model::Branch &br = m->branches[pl->enc[i].branch];
+        ea.br[i].a0 = buf_ptr(pl->enc[i].buf);
+        ea.br[i].lut = m->d_iarena + br.lut_off;
+        ea.br[i].k0pad = br.k0pad;
+        enc_bytes += (double)B * (a->RF / 3) * br.k0pad * 4.0;
+    }
+    ea.cur = buf_ptr(pl->cur_buf);
+    ea.E = a->cfg.extrinsic_dim;
+    for (int mi = 0; mi < 2; ++mi) {
+        const Model *m = pl->m[mi];
+        if (!m || m->cfg.embed_dim <= 0) continue;
+        ea.emb_w[ea.nembed] = m->d_arena + m->embed_off;
+        ea.emb_out[ea.nembed] = buf_ptr(pl->emb_buf[mi]);
+        ea.emb_dim[ea.nembed] = m->cfg.embed_dim;
+        ++ea.nembed;
+    }
+    int blocks = 0;
+    if ((e = rec.begin("r3d_encode_f32", stage_no, 0, 0.0, enc_bytes)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+    if ((e = launch_encode(ea, stream, &blocks)) != hipSuccess) return hip_fail(e, "launch r3d_encode_f32");
+    if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
+    ++stage_no;
+
+    // ---- grouped GEMM launches, one per DAG level
+    for (const auto &st : pl->stages) {
+        StageArgs sa;
+        memset(&sa, 0, sizeof sa);
+        sa.nprob = (int)st.size();
+        // tile choice: big tiles only when they still give every CU a few workgroups
+        long long tiles128 = 0;
+        for (int id : st) {
+            const ProbSpec &q = pl->probs[id];
+            const Layer &L = pl->m[q.model]->layers[q.layer];
+            const long long M = B * q.rows_per_window;
+            tiles128 += ((M + 127) / 128) * ((L.N + 127) / 128);
+        }
+        const int tile = tiles128 >= 512 ? 128 : 64;
+        int tb = 0;
+        double flops = 0, bytes = 0;
+        for (int i = 0; i < sa.nprob; ++i) {
+            const ProbSpec &q = pl->probs[st[i]];
+            const Model *m = pl->m[q.model];
+            const Layer &L = m->layers[q.layer];
+            GemmProb &g = sa.p[i];
+            int kend = 0;
+            for (int s = 0; s < MAX_SEG; ++s) {
+                if (s < q.nseg) {
+                    g.a[s] = buf_ptr(q.seg[s].buf) + q.seg[s].col;
+                    g.lda[s] = q.seg[s].ld;
+                    kend += q.seg[s].width;
+                } else {
+                    g.a[s] = g.a[0];
+                    g.lda[s] = g.lda[0];
+                }
+                g.kend[s] = s < q.nseg ? kend : 0x7fffffff;
+            }
+            g.kend[q.nseg - 1] = 0x7fffffff;   // the last real segment absorbs the rest
+            g.w = m->d_arena + L.w_off;
+            g.bias = m->d_arena + L.b_off;
+            g.res = q.res_buf >= 0 ? buf_ptr(q.res_buf) + q.res_col : nullptr;
+            g.ldr = q.res_ld;
+            g.c = buf_ptr(q.c_buf) + q.c_col;
+            g.ldc = q.c_ld;
+            g.M = (int)(B * q.rows_per_window);
+            g.N = L.N;
+            g.K = L.Kpad;
+            g.slope = L.slope;
+            g.tile_begin = tb;
+            g.tiles_n = (L.N + tile - 1) / tile;
+            tb += g.tiles_n * ((g.M + tile - 1) / tile);
+            flops += q.flops_per_window * (double)B;
+            bytes += 4.0 * ((double)g.M * L.K + (double)L.N * L.K + (double)g.M * L.N * (q.res_buf >= 0 ? 2.0 : 1.0));
+        }
+        sa.total_tiles = tb;
+        if ((e = rec.begin(gemm_kernel_name(tile), stage_no, tb, flops, bytes)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        if ((e = launch_gemm_stage(sa, tile, stream)) != hipSuccess) return hip_fail(e, "launch r3d_gemm_f32");
+        if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        ++stage_no;
+    }
+
+    // ---- epilogue
+    AssembleArgs aa;
+    memset(&aa, 0, sizeof aa);
+    aa.B = B;
+    aa.J = a->cfg.num_joints;
+    aa.ldt = 4;
+    if (pl->pos_model >= 0) {
+        aa.dec = buf_ptr(pl->dec_buf);
+        aa.trj = pl->trj_model >= 0 ? buf_ptr(pl->trj_buf) : nullptr;
+        aa.out = out;
+        output_sources(aa.J, aa.src);
+        if ((e = rec.begin("r3d_assemble_f32", stage_no, 0, 0.0, (double)B * aa.J * 3 * 8.0)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        if ((e = launch_assemble(aa, stream, &blocks)) != hipSuccess) return hip_fail(e, "launch r3d_assemble_f32");
+        if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        ++stage_no;
+    }
+    float *trj_dst = pl->pos_model >= 0 ? out_trj : out;
+    if (pl->trj_model >= 0 && trj_dst) {
+        aa.dec = nullptr;
+        aa.trj = buf_ptr(pl->trj_buf);
+        aa.out = trj_dst;
+        if ((e = rec.begin("r3d_assemble_f32", stage_no, 0, 0.0, (double)B * 3 * 8.0)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        if ((e = launch_assemble(aa, stream, &blocks)) != hipSuccess) return hip_fail(e, "launch r3d_assemble_f32");
+        if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
+    }
+    if (rec.on()) a->nrec = (int)rec.n;
+    return R3D_OK;
+}
+
+}  // namespace r3d
+
+using namespace r3d;
+
+extern "C" {
+
+int r3d_create(const r3d_config *cfg, r3d_model **out) {
+    if (!cfg || !out) { set_error("r3d_create: null argument"); return R3D_ERR_ARG; }
+    Model *m = model_create(*cfg);
+    if (!m) return R3D_ERR_ARG;
+    *out = reinterpret_cast<r3d_model *>(m);
+    return R3D_OK;
+}
+
+int r3d_destroy(r3d_model *m) {
+    delete reinterpret_cast<Model *>(m);
+    return R3D_OK;
+}
+
+int r3d_num_weights(const r3d_model *m) {
+    return m ? (int)reinterpret_cast<const Model *>(m)->specs.size() : R3D_ERR_ARG;
+}
+
+const char *r3d_weight_key(const r3d_model *m, int index) {
+    const Model *mm = reinterpret_cast<const Model *>(m);
+    if (!mm || index < 0 || index >= (int)mm->specs.size()) return nullptr;
+    return mm->specs[index].key.c_str();
+}
+
+int r3d_weight_shape(const r3d_model *m, int index, int64_t shape[4], int *rank) {
+    const Model *mm = reinterpret_cast<const Model *>(m);
+    if (!mm || !shape || !rank || index < 0 || index >= (int)mm->specs.size()) { set_error("r3d_weight_shape: bad argument"); return R3D_ERR_ARG; }
+    *rank = mm->specs[index].rank;
+    for (int i = 0; i < 4; ++i) shape[i] = mm->specs[index].shape[i];
+    return R3D_OK;
+}
+
+int r3d_set_weight(r3d_model *m, const char *key, const float *host, const int64_t *shape, int rank) {
+    return model_set_weight(reinterpret_cast<Model *>(m), key, host, shape, rank);
+}
+
+int r3d_finalize(r3d_model *m) { return model_finalize(reinterpret_cast<Model *>(m)); }
+
+size_t r3d_workspace_bytes(const r3d_model *pos, const r3d_model *trj, int64_t B) {
+    Model *p = const_cast<Model *>(reinterpret_cast<const Model *>(pos));
+    Model *t = const_cast<Model *>(reinterpret_cast<const Model *>(trj));
+    Model *a = p ? p : t, *b = p ? t : nullptr;
+    if (!a || B <= 0) return 0;
+    return (size_t)plan_get(a, b)->floats_per_window * (size_t)B * sizeof(float);
+}
+
+int r3d_forward(r3d_model *m, const r3d_input *in, int64_t B, float *out_dev, void *ws, size_t ws_bytes, void *stream) {
+    Model *mm = reinterpret_cast<Model *>(m);
+    if (!mm) { set_error("r3d_forward: null model"); return R3D_ERR_ARG; }
+    return mm->cfg.kind == R3D_KIND_POS ? run(mm, nullptr, in, B, out_dev, nullptr, ws, ws_bytes, stream)
+                                        : run(nullptr, mm, in, B, out_dev, nullptr, ws, ws_bytes, stream);
+}
+
+int r3d_forward_pair(r3d_model *pos, r3d_model *trj, const r3d_input *in, int64_t B, float *out_dev, float *out_trj_dev,
+                     void *ws, size_t ws_bytes, void *stream) {
+    Model *p = reinterpret_cast<Model *>(pos), *t = reinterpret_cast<Model *>(trj);
+    if (!p || !t) { set_error("r3d_forward_pair: both models are required"); return R3D_ERR_ARG; }
+    if (p->cfg.kind != R3D_KIND_POS || t->cfg.kind != R3D_KIND_TRJ) { set_error("r3d_forward_pair: (pos, trj) expected in that order"); return R3D_ERR_ARG; }
+    return run(p, t, in, B, out_dev, out_trj_dev, ws, ws_bytes, stream);
+}
+
+int r3d_profile_enable(r3d_model *m, int on) {
+    Model *mm = reinterpret_cast<Model *>(m);
+    if (!mm) { set_error("r3d_profile_enable: null model"); return R3D_ERR_ARG; }
+    mm->profiling = on != 0;
+    mm->nrec = 0;
+    return R3D_OK;
+}
+
+int r3d_profile_read(r3d_model *m, r3d_launch_record *records, int capacity) {
+    Model *mm = reinterpret_cast<Model *>(m);
+    if (!mm) { set_error("r3d_profile_read: null model"); return R3D_ERR_ARG; }
+    int n = 0;
+    for (int i = 0; i < mm->nrec; ++i) {
+        Model::Rec &r = mm->recs[i];
+        hipError_t e = hipEventSynchronize(r.e1);
+        if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize");
+        if ((e = hipEventElapsedTime(&r.r.ms, r.e0, r.e1)) != hipSuccess) return hip_fail(e, "hipEventElapsedTime");
+        if (records && n < capacity) records[n] = r.r;
+        ++n;
+    }
+    return n;
+}
+
+const char *r3d_last_error(void) { return r3d::last_error(); }
+const char *r3d_version(void) { return "ray3d_hip 0.1 (gfx950)"; }
+
+}  // extern "C"

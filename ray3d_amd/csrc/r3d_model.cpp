@@ -1,0 +1,339 @@
+// Weight ABI of the lifting networks: the reference state_dict grammar, strict loading, and the
+// BatchNorm-folding repack into the GEMM layout the gfx950 kernels read.
+//
+// Reference constructors this mirrors: lib/model/rie.py:13-63 (TemporalBlock), :108-120 (Linear),
+// :138-157 (FCBlock), :178-253 (RIEModel), :443-494 (RIETrajectoryModel),
+// lib/model/embedding.py:4-13 (Embedding).  Eval-mode BatchNorm1d: y = (x-mean)/sqrt(var+1e-5)*g+b.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "r3d_internal.hpp"
+
+namespace r3d {
+
+static thread_local char g_error[1024];
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+}
+const char *last_error() { return g_error; }
+
+int hip_fail(hipError_t e, const char *what) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return R3D_ERR_HIP;
+}
+
+static const char *kBranchNames[5] = {"Torso", "LArm", "RArm", "LLeg", "RLeg"};
+
+// joints per body part (lib/model/rie.py:308-331 for F=3, :334-357 for F=2: same joints)
+static std::vector<int> group_joints(int J, int g) {
+    static const std::vector<int> g17[5] = {{0, 7, 8, 9, 10}, {14, 15, 16}, {11, 12, 13}, {1, 2, 3}, {4, 5, 6}};
+    static const std::vector<int> g15[5] = {{0, 1, 14}, {2, 3, 4}, {5, 6, 7}, {8, 9, 10}, {11, 12, 13}};
+    static const std::vector<int> g14[5] = {{0, 7}, {8, 9, 10}, {11, 12, 13}, {4, 5, 6}, {1, 2, 3}};
+    return J == 17 ? g17[g] : J == 15 ? g15[g] : g14[g];
+}
+
+namespace {
+
+struct Grammar {
+    Model *m;
+    void tensor(const std::string &key, std::initializer_list<int64_t> shape) {
+        TensorSpec t;
+        t.key = key;
+        t.rank = (int)shape.size();
+        int i = 0;
+        for (auto d : shape) t.shape[i++] = d;
+        for (; i < 4; ++i) t.shape[i] = 1;
+        m->spec_index[key] = (int)m->specs.size();
+        m->specs.push_back(t);
+    }
+    void bn(const std::string &p, int c) {
+        tensor(p + ".weight", {c});
+        tensor(p + ".bias", {c});
+        tensor(p + ".running_mean", {c});
+        tensor(p + ".running_var", {c});
+    }
+    int layer(const std::string &prefix, int taps, int cin, int n, bool bias, const std::string &bn_prefix,
+              float slope, bool conv) {
+        Layer L;
+        L.weight_key = prefix + ".weight";
+        L.bias_key = bias ? prefix + ".bias" : "";
+        L.bn_prefix = bn_prefix;
+        L.taps = taps;
+        L.cin = cin;
+        L.N = n;
+        L.K = taps * cin;
+        L.Npad = round_up(n, N_ALIGN);
+        L.Kpad = round_up(L.K, BK);
+        L.slope = slope;
+        L.w_off = L.b_off = 0;
+        if (conv)
+            tensor(L.weight_key, {n, cin, taps});
+        else
+            tensor(L.weight_key, {n, cin});
+        if (bias) tensor(L.bias_key, {n});
+        if (!bn_prefix.empty()) bn(bn_prefix, n);
+        m->layer_index[prefix] = (int)m->layers.size();
+        m->layers.push_back(L);
+        return (int)m->layers.size() - 1;
+    }
+    // TemporalBlock, lib/model/rie.py:13-63
+    void temporal_block(const std::string &p, int cin) {
+        const int C = m->cfg.channels;
+        layer(p + ".expand_conv", 3, cin, C, false, p + ".expand_bn", 0.2f, true);
+        for (int i = 1; i < m->cfg.num_levels; ++i) {
+            const std::string a = std::to_string(2 * (i - 1)), b = std::to_string(2 * (i - 1) + 1);
+            layer(p + ".layers_conv." + a, 3, C, C, false, p + ".layers_bn." + a, 0.2f, true);
+            layer(p + ".layers_conv." + b, 1, C, C, false, p + ".layers_bn." + b, 0.2f, true);
+        }
+        layer(p + ".shrink", 1, C, m->cfg.latent, true, "", 1.0f, true);
+    }
+    // FCBlock, lib/model/rie.py:138-157
+    void fc_block(const std::string &p, int cin, int cout, int nblocks) {
+        layer(p + ".fc_1", 1, cin, MLP_HIDDEN, true, p + ".bn_1", 0.2f, false);
+        for (int n = 0; n < nblocks; ++n) {
+            const std::string q = p + ".layers." + std::to_string(n);
+            layer(q + ".w1", 1, MLP_HIDDEN, MLP_HIDDEN, true, q + ".batch_norm1", 0.2f, false);
+            layer(q + ".w2", 1, MLP_HIDDEN, MLP_HIDDEN, true, q + ".batch_norm2", 0.2f, false);
+        }
+        layer(p + ".fc_2", 1, MLP_HIDDEN, cout, true, "", 1.0f, false);
+    }
+    // Embedding, lib/model/embedding.py:4-13 (not a GEMM layer: evaluated in the prologue kernel)
+    void embedding(const std::string &p, int cin, int cout) {
+        tensor(p + ".w1.weight", {EMBED_MID, cin});
+        tensor(p + ".w1.bias", {EMBED_MID});
+        bn(p + ".b1", EMBED_MID);
+        tensor(p + ".w2.weight", {cout, EMBED_MID});
+        tensor(p + ".w2.bias", {cout});
+        bn(p + ".b2", cout);
+    }
+};
+
+}  // namespace
+
+Model::~Model() {
+    for (auto &kv : plans) delete kv.second;
+    if (d_arena) (void)hipFree(d_arena);
+    if (d_iarena) (void)hipFree(d_iarena);
+    for (auto &r : recs) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+}
+
+Model *model_create(const r3d_config &cfg) {
+    const int J = cfg.num_joints, F = cfg.in_features;
+    if (cfg.kind != R3D_KIND_POS && cfg.kind != R3D_KIND_TRJ) { set_error("kind must be R3D_KIND_POS or R3D_KIND_TRJ"); return nullptr; }
+    if (J != 14 && J != 15 && J != 17) { set_error("num_joints must be 14, 15 or 17 (got %d)", J); return nullptr; }
+    if (F != 2 && F != 3) { set_error("in_features must be 2 or 3 (got %d)", F); return nullptr; }
+    if (cfg.num_levels < 1 || cfg.num_levels > 6) { set_error("num_levels must be in 1..6 (got %d)", cfg.num_levels); return nullptr; }
+    if (cfg.channels <= 0 || cfg.channels % BK || cfg.latent <= 0 || cfg.latent % BK) {
+        set_error("channels and latent must be positive multiples of %d", BK);
+        return nullptr;
+    }
+    const bool emb = cfg.extrinsic_dim > 0 && cfg.embed_dim > 0;
+    if (emb && (cfg.embed_dim % BK || cfg.extrinsic_dim > 16)) {
+        set_error("embed_dim must be a multiple of %d and extrinsic_dim <= 16", BK);
+        return nullptr;
+    }
+    if (cfg.kind == R3D_KIND_POS && cfg.stage < 1) { set_error("stage must be >= 1"); return nullptr; }
+
+    Model *m = new Model();
+    m->cfg = cfg;
+    if (!emb) m->cfg.extrinsic_dim = m->cfg.embed_dim = 0;
+    m->RF = 1;
+    for (int i = 0; i < cfg.num_levels; ++i) m->RF *= 3;
+    Grammar g{m};
+    const int lat = cfg.latent, D = m->cfg.embed_dim;
+    if (cfg.kind == R3D_KIND_POS) {
+        for (int b = 0; b < 5; ++b) {
+            Model::Branch br;
+            br.prefix = std::string("LocalLayer_") + kBranchNames[b];
+            br.joints = group_joints(J, b);
+            br.cin = 3 * (int)br.joints.size() * F;
+            br.k0 = 3 * br.cin;
+            br.k0pad = round_up(br.k0, BK);
+            br.lut_off = 0;
+            m->branches.push_back(br);
+            g.temporal_block(br.prefix, br.cin);
+        }
+        g.fc_block("GlobalInfo", J * F, lat, 2);
+        if (cfg.stage != 1)
+            for (int i = 0; i < 5; ++i) g.fc_block("FuseBlocks." + std::to_string(i), 4 * lat, lat, 1);
+        if (emb) g.embedding("embedder", cfg.extrinsic_dim, D);
+        const int dec_in = (cfg.stage == 1 ? 2 : 3) * lat + D;
+        for (int b = 0; b < 5; ++b)
+            g.fc_block(std::string("Integration_") + kBranchNames[b], dec_in, 3 * (int)m->branches[b].joints.size(), 1);
+    } else {
+        Model::Branch br;
+        br.prefix = "LocalLayer";
+        for (int j = 0; j < J; ++j) br.joints.push_back(j);
+        br.cin = 3 * J * F;
+        br.k0 = 3 * br.cin;
+        br.k0pad = round_up(br.k0, BK);
+        br.lut_off = 0;
+        m->branches.push_back(br);
+        g.temporal_block(br.prefix, br.cin);
+        g.fc_block("GlobalInfo", J * F, lat, 2);
+        if (emb) g.embedding("embedder", cfg.extrinsic_dim, D);
+        g.fc_block("Integration", 2 * lat + D, 3, 1);
+    }
+    // GlobalInfo.fc_1 reads the zero-padded current-frame matrix
+    m->layers[m->layer_index["GlobalInfo.fc_1"]].Kpad = CUR_LD;
+    m->host_weights.resize(m->specs.size());
+    m->have.assign(m->specs.size(), false);
+    return m;
+}
+
+int model_set_weight(Model *m, const char *key_in, const float *host, const int64_t *shape, int rank) {
+    if (!m || !key_in || !host || !shape) { set_error("r3d_set_weight: null argument"); return R3D_ERR_ARG; }
+    std::string key(key_in);
+    if (key.rfind("module.", 0) == 0) key = key.substr(7);   // nn.DataParallel checkpoints
+    auto it = m->spec_index.find(key);
+    if (it == m->spec_index.end()) {
+        set_error("unexpected key '%s' for this configuration", key.c_str());
+        return R3D_ERR_KEY;
+    }
+    const TensorSpec &t = m->specs[it->second];
+    bool ok = (rank == t.rank);
+    for (int i = 0; ok && i < rank; ++i) ok = (shape[i] == t.shape[i]);
+    if (!ok) {
+        std::string got = "[", want = "[";
+        for (int i = 0; i < rank && i < 4; ++i) got += std::to_string((long long)shape[i]) + (i + 1 < rank ? "," : "");
+        for (int i = 0; i < t.rank; ++i) want += std::to_string((long long)t.shape[i]) + (i + 1 < t.rank ? "," : "");
+        set_error("size mismatch for '%s': got %s], expected %s]", key.c_str(), got.c_str(), want.c_str());
+        return R3D_ERR_SHAPE;
+    }
+    auto &dst = m->host_weights[it->second];
+    dst.assign(host, host + t.numel());
+    m->have[it->second] = true;
+    m->dirty = true;
+    return R3D_OK;
+}
+
+namespace {
+
+struct Folder {
+    Model *m;
+    const float *get(const std::string &key) const { return m->host_weights[m->spec_index.at(key)].data(); }
+    // per-output-channel scale/shift of an eval BatchNorm following a layer with optional bias
+    void scale_shift(const Layer &L, std::vector<double> &s, std::vector<double> &t) const {
+        s.assign(L.N, 1.0);
+        t.assign(L.N, 0.0);
+        const float *bias = L.bias_key.empty() ? nullptr : get(L.bias_key);
+        if (L.bn_prefix.empty()) {
+            for (int o = 0; o < L.N; ++o) t[o] = bias ? (double)bias[o] : 0.0;
+            return;
+        }
+        const float *g = get(L.bn_prefix + ".weight"), *b = get(L.bn_prefix + ".bias");
+        const float *mu = get(L.bn_prefix + ".running_mean"), *var = get(L.bn_prefix + ".running_var");
+        for (int o = 0; o < L.N; ++o) {
+            const double sc = (double)g[o] / std::sqrt((double)var[o] + 1e-5);
+            s[o] = sc;
+            t[o] = (double)b[o] - (double)mu[o] * sc + (bias ? (double)bias[o] * sc : 0.0);
+        }
+    }
+};
+
+}  // namespace
+
+int model_finalize(Model *m) {
+    if (!m) { set_error("r3d_finalize: null model"); return R3D_ERR_ARG; }
+    for (size_t i = 0; i < m->specs.size(); ++i)
+        if (!m->have[i]) {
+            int missing = 0;
+            for (size_t j = 0; j < m->specs.size(); ++j) missing += !m->have[j];
+            set_error("Missing key(s) in state_dict: '%s' (and %d more)", m->specs[i].key.c_str(), missing - 1);
+            return R3D_ERR_KEY;
+        }
+    // ---- lay out the arenas
+    size_t off = 0;
+    for (auto &L : m->layers) {
+        L.w_off = off;
+        off += (size_t)L.Npad * L.Kpad;
+        L.b_off = off;
+        off += (size_t)L.Npad;
+    }
+    const int E = m->cfg.extrinsic_dim, D = m->cfg.embed_dim;
+    if (D > 0) {
+        m->embed_off = off;
+        off += (size_t)EMBED_MID * E + EMBED_MID + (size_t)D * EMBED_MID + D;
+        off = (off + 63) / 64 * 64;
+    }
+    m->arena.assign(off, 0.0f);
+    Folder f{m};
+    std::vector<double> s, t;
+    for (auto &L : m->layers) {
+        f.scale_shift(L, s, t);
+        const float *w = f.get(L.weight_key);
+        float *dst = m->arena.data() + L.w_off;
+        // torch layout (N, cin, taps) [Linear: taps == 1]; GEMM column index = tap*cin + c
+        for (int o = 0; o < L.N; ++o)
+            for (int c = 0; c < L.cin; ++c)
+                for (int j = 0; j < L.taps; ++j)
+                    dst[(size_t)o * L.Kpad + j * L.cin + c] = (float)((double)w[((size_t)o * L.cin + c) * L.taps + j] * s[o]);
+        float *bd = m->arena.data() + L.b_off;
+        for (int o = 0; o < L.N; ++o) bd[o] = (float)t[o];
+    }
+    if (D > 0) {
+        // Embedding: Linear(E,32)+BN, Linear(32,D)+BN, both folded (embedding.py:15-18)
+        float *e = m->arena.data() + m->embed_off;
+        Layer l1, l2;
+        l1.N = EMBED_MID; l1.bias_key = "embedder.w1.bias"; l1.bn_prefix = "embedder.b1";
+        l2.N = D; l2.bias_key = "embedder.w2.bias"; l2.bn_prefix = "embedder.b2";
+        f.scale_shift(l1, s, t);
+        const float *w1 = f.get("embedder.w1.weight");
+        for (int o = 0; o < EMBED_MID; ++o) {
+            for (int c = 0; c < E; ++c) e[o * E + c] = (float)((double)w1[o * E + c] * s[o]);
+            e[EMBED_MID * E + o] = (float)t[o];
+        }
+        float *e2 = e + EMBED_MID * E + EMBED_MID;
+        f.scale_shift(l2, s, t);
+        const float *w2 = f.get("embedder.w2.weight");
+        for (int o = 0; o < D; ++o) {
+            for (int c = 0; c < EMBED_MID; ++c) e2[o * EMBED_MID + c] = (float)((double)w2[o * EMBED_MID + c] * s[o]);
+            e2[(size_t)D * EMBED_MID + o] = (float)t[o];
+        }
+    }
+    // ---- prologue LUTs: column of the first-layer GEMM -> (tap, kind, source element)
+    // channel order inside a branch: cat(x_g, diff_g, diff_t_g), lib/model/rie.py:308-315, :540
+    m->iarena.clear();
+    const int F = m->cfg.in_features;
+    for (auto &br : m->branches) {
+        br.lut_off = m->iarena.size();
+        const int n = (int)br.joints.size();
+        for (int col = 0; col < br.k0pad; ++col) {
+            if (col >= br.k0) { m->iarena.push_back(encode_lut_entry(0, 3, 0, 0)); continue; }
+            const int tap = col / br.cin, c = col % br.cin;
+            const int kind = c / (n * F), jj = (c % (n * F)) / F, ff = c % F;
+            m->iarena.push_back(encode_lut_entry(tap, kind, br.joints[jj] * F + ff, ff));
+        }
+    }
+    // ---- upload
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+    if (m->d_arena && m->device != dev) {
+        (void)hipFree(m->d_arena); (void)hipFree(m->d_iarena);
+        m->d_arena = nullptr; m->d_iarena = nullptr;
+        for (auto &kv : m->plans) delete kv.second;
+        m->plans.clear();
+    }
+    m->device = dev;
+    if (!m->d_arena) {
+        if ((e = hipMalloc((void **)&m->d_arena, m->arena.size() * sizeof(float))) != hipSuccess) return hip_fail(e, "hipMalloc(weights)");
+        if ((e = hipMalloc((void **)&m->d_iarena, m->iarena.size() * sizeof(int))) != hipSuccess) return hip_fail(e, "hipMalloc(luts)");
+    }
+    if ((e = hipMemcpy(m->d_arena, m->arena.data(), m->arena.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "hipMemcpy(weights)");
+    if ((e = hipMemcpy(m->d_iarena, m->iarena.data(), m->iarena.size() * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "hipMemcpy(luts)");
+    m->finalized = true;
+    m->dirty = false;
+    return R3D_OK;
+}
+
+}  // namespace r3d

@@ -1,0 +1,197 @@
+// Launch plan of the lifting forward pass: which GEMMs exist, what they read/write, and which
+// of them can share a launch.
+//
+// The reference executes RIEModel.forward / RIETrajectoryModel.forward (lib/model/rie.py:284-434,
+// :518-559) as ~170 small ATen ops per network.  Here both networks are lowered once, per pair of
+// configurations, to a DAG of BN-folded GEMM "problems" over channels-last activations
+// (Conv1d(k=3,stride=3) on (B,T,C) is a plain GEMM on the (B*T/3, 3C) view), and
+// the DAG is levelised: all problems of equal depth - the six temporal branches, the GlobalInfo
+// MLPs, the five FuseBlocks ... - run as ONE grouped launch.  Concatenations (rie.py:371-407) are
+// never materialised: a problem's A operand is a list of column segments of other buffers.
+#include <algorithm>
+#include <cstdio>
+
+#include "r3d_internal.hpp"
+
+namespace r3d {
+
+namespace {
+
+struct Builder {
+    Plan &p;
+    int mi;             // model index inside the plan
+    const Model &m;
+
+    int buffer(const std::string &name, int64_t floats_per_window, int external = 0) {
+        BufferSpec b;
+        b.name = name;
+        b.floats_per_window = (floats_per_window + 15) / 16 * 16;
+        b.external = external;
+        b.offset_per_window = 0;
+        p.buffers.push_back(b);
+        return (int)p.buffers.size() - 1;
+    }
+    struct In { int buf, col, ld, width, dep; };
+    int problem(const std::string &layer_prefix, int rows_pw, const std::vector<In> &ins, int res_buf, int res_col,
+                int res_ld, int c_buf, int c_col, int c_ld, std::vector<int> extra_deps = {}) {
+        ProbSpec q;
+        q.model = mi;
+        q.layer = m.layer_index.at(layer_prefix);
+        q.rows_per_window = rows_pw;
+        q.nseg = (int)ins.size();
+        int k = 0;
+        for (int s = 0; s < q.nseg; ++s) {
+            q.seg[s] = {ins[s].buf, ins[s].col, ins[s].ld, ins[s].width};
+            k += ins[s].width;
+            if (ins[s].dep >= 0) q.deps.push_back(ins[s].dep);
+        }
+        for (int d : extra_deps)
+            if (d >= 0) q.deps.push_back(d);
+        const Layer &L = m.layers[q.layer];
+        if (k != L.Kpad) {
+            fprintf(stderr, "r3d: internal plan error: layer %s expects K=%d, operands give %d\n", layer_prefix.c_str(), L.Kpad, k);
+            abort();
+        }
+        q.res_buf = res_buf; q.res_col = res_col; q.res_ld = res_ld;
+        q.c_buf = c_buf; q.c_col = c_col; q.c_ld = c_ld;
+        q.depth = 0;
+        for (int d : q.deps) q.depth = std::max(q.depth, p.probs[d].depth + 1);
+        q.flops_per_window = 2.0 * rows_pw * (double)L.K * (double)L.N;
+        p.probs.push_back(q);
+        return (int)p.probs.size() - 1;
+    }
+
+    // FCBlock.forward (lib/model/rie.py:159-169): fc_1+bn+lrelu, n residual units, fc_2.
+    int fc_block(const std::string &prefix, const std::vector<In> &ins, int nblocks, int c_buf, int c_col, int c_ld) {
+        const int H = MLP_HIDDEN;
+        const int h = buffer(prefix + ".h", H), y = buffer(prefix + ".y", H);
+        int last = problem(prefix + ".fc_1", 1, ins, -1, 0, 0, h, 0, H);
+        for (int n = 0; n < nblocks; ++n) {
+            const std::string q = prefix + ".layers." + std::to_string(n);
+            const int p1 = problem(q + ".w1", 1, {{h, 0, H, H, last}}, -1, 0, 0, y, 0, H);
+            // out = x + lrelu(bn(w2 y))  (rie.py:122-135): residual = h, written in place
+            last = problem(q + ".w2", 1, {{y, 0, H, H, p1}}, h, 0, H, h, 0, H, {last});
+        }
+        return problem(prefix + ".fc_2", 1, {{h, 0, H, H, last}}, -1, 0, 0, c_buf, c_col, c_ld);
+    }
+
+    // TemporalBlock.forward (rie.py:85-105) for branch `bi`; returns the shrink problem id.
+    int temporal_block(int bi, int c_buf, int c_col, int c_ld) {
+        const Model::Branch &br = m.branches[bi];
+        const int C = m.cfg.channels, L = m.cfg.num_levels;
+        int rows = m.RF / 3;
+        const int a0 = buffer(br.prefix + ".A0", (int64_t)rows * br.k0pad);
+        p.enc.push_back({mi, bi, a0});
+        const int pp[2] = {buffer(br.prefix + ".P0", (int64_t)rows * C),
+                           L > 1 ? buffer(br.prefix + ".P1", (int64_t)(rows / 3) * C) : -1};
+        const int hb = L > 1 ? buffer(br.prefix + ".H", (int64_t)(rows / 3) * C) : -1;
+        int last = problem(br.prefix + ".expand_conv", rows, {{a0, 0, br.k0pad, br.k0pad, -1}}, -1, 0, 0, pp[0], 0, C);
+        for (int i = 1; i < L; ++i) {
+            const int src = pp[(i - 1) & 1], dst = pp[i & 1];
+            rows /= 3;
+            const std::string a = br.prefix + ".layers_conv." + std::to_string(2 * (i - 1));
+            const std::string b = br.prefix + ".layers_conv." + std::to_string(2 * (i - 1) + 1);
+            // three consecutive frames of the previous level form one GEMM row (stride == kernel)
+            const int pa = problem(a, rows, {{src, 0, 3 * C, 3 * C, last}}, -1, 0, 0, hb, 0, C);
+            // res = x[:, :, 1::3] is the centre third of that row (rie.py:94)
+            last = problem(b, rows, {{hb, 0, C, C, pa}}, src, C, 3 * C, dst, 0, C, {last});
+        }
+        const int fin = pp[(L - 1) & 1];
+        return problem(br.prefix + ".shrink", 1, {{fin, 0, C, C, last}}, -1, 0, 0, c_buf, c_col, c_ld);
+    }
+};
+
+}  // namespace
+
+static Plan *build_plan(const Model *a, const Model *b) {
+    Plan *pl = new Plan();
+    pl->m[0] = a;
+    pl->m[1] = b;
+    Builder shared{*pl, 0, *a};
+    pl->cur_buf = shared.buffer("cur", CUR_LD);
+    for (int mi = 0; mi < 2; ++mi) {
+        const Model *m = pl->m[mi];
+        if (!m) continue;
+        Builder B{*pl, mi, *m};
+        const int lat = m->cfg.latent, D = m->cfg.embed_dim;
+        if (D > 0) pl->emb_buf[mi] = B.buffer("emb", D);
+        const int g = B.buffer("global", lat);
+        const int pg = B.fc_block("GlobalInfo", {{pl->cur_buf, 0, CUR_LD, CUR_LD, -1}}, 2, g, 0, lat);
+        if (m->cfg.kind == R3D_KIND_POS) {
+            pl->pos_model = mi;
+            const int tmp5 = B.buffer("tmp5", 5 * lat);
+            int sh[5];
+            for (int bi = 0; bi < 5; ++bi) sh[bi] = B.temporal_block(bi, tmp5, bi * lat, 5 * lat);
+            int mix5 = -1, pf[5] = {-1, -1, -1, -1, -1};
+            if (m->cfg.stage != 1) {
+                mix5 = B.buffer("mix5", 5 * lat);
+                for (int i = 0; i < 5; ++i) {
+                    // cat of the other four local features (rie.py:393-394) = <=2 column ranges of tmp5
+                    std::vector<Builder::In> ins;
+                    if (i > 0) ins.push_back({tmp5, 0, 5 * lat, i * lat, sh[0]});
+                    if (i < 4) ins.push_back({tmp5, (i + 1) * lat, 5 * lat, (4 - i) * lat, sh[4]});
+                    // every shrink must be complete, not only the two named above
+                    const int first = (int)pl->probs.size();
+                    pf[i] = B.fc_block("FuseBlocks." + std::to_string(i), ins, 1, mix5, i * lat, 5 * lat);
+                    for (int k = 0; k < 5; ++k) pl->probs[first].deps.push_back(sh[k]);
+                    // re-derive depths of the block just added (deps were extended)
+                    for (int q = first; q < (int)pl->probs.size(); ++q) {
+                        int d = 0;
+                        for (int dep : pl->probs[q].deps) d = std::max(d, pl->probs[dep].depth + 1);
+                        pl->probs[q].depth = d;
+                    }
+                }
+            }
+            pl->dec_buf = B.buffer("dec", 5 * DEC_SLOT);
+            for (int bi = 0; bi < 5; ++bi) {
+                // cat(local, [mix], global, [embedding])  (rie.py:376-407)
+                std::vector<Builder::In> ins;
+                ins.push_back({tmp5, bi * lat, 5 * lat, lat, sh[bi]});
+                if (mix5 >= 0) ins.push_back({mix5, bi * lat, 5 * lat, lat, pf[bi]});
+                ins.push_back({g, 0, lat, lat, pg});
+                if (D > 0) ins.push_back({pl->emb_buf[mi], 0, D, D, -1});
+                B.fc_block(std::string("Integration_") + (bi == 0 ? "Torso" : bi == 1 ? "LArm" : bi == 2 ? "RArm" : bi == 3 ? "LLeg" : "RLeg"),
+                           ins, 1, pl->dec_buf, bi * DEC_SLOT, 5 * DEC_SLOT);
+            }
+        } else {
+            pl->trj_model = mi;
+            const int local = B.buffer("local", lat);
+            const int sh = B.temporal_block(0, local, 0, lat);
+            pl->trj_buf = B.buffer("trj", 4);
+            std::vector<Builder::In> ins;
+            ins.push_back({local, 0, lat, lat, sh});
+            ins.push_back({g, 0, lat, lat, pg});
+            if (D > 0) ins.push_back({pl->emb_buf[mi], 0, D, D, -1});
+            B.fc_block("Integration", ins, 1, pl->trj_buf, 0, 4);
+        }
+    }
+    // levelise
+    int maxd = 0;
+    for (auto &q : pl->probs) maxd = std::max(maxd, q.depth);
+    pl->stages.assign(maxd + 1, {});
+    for (int i = 0; i < (int)pl->probs.size(); ++i) pl->stages[pl->probs[i].depth].push_back(i);
+    // split launches that exceed the kernarg capacity
+    std::vector<std::vector<int>> split;
+    for (auto &st : pl->stages)
+        for (size_t i = 0; i < st.size(); i += MAX_PROB)
+            split.emplace_back(st.begin() + i, st.begin() + std::min(st.size(), i + MAX_PROB));
+    pl->stages.swap(split);
+    // workspace offsets
+    int64_t off = 0;
+    for (auto &bf : pl->buffers) {
+        bf.offset_per_window = off;
+        off += bf.floats_per_window;
+    }
+    pl->floats_per_window = off;
+    return pl;
+}
+
+Plan *plan_get(Model *a, Model *b) {
+    auto it = a->plans.find(b);
+    if (it != a->plans.end()) return it->second;
+    Plan *p = build_plan(a, b);
+    a->plans[b] = p;
+    return p;
+}
+
+}  // namespace r3d

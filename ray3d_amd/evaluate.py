@@ -1,0 +1,159 @@
+"""Batched evaluation over clips: the caller side of the lifting path.
+
+Reproduces the behaviour of ``Trainer.evaluate_core`` / ``Trainer.evaluate``
+(lib/train_val/trainer.py:283-405, :407-483) around the HIP forward:
+
+* a clip is edge-padded by (RF-1)//2 frames per side (lib/dataloader/generators.py:213-216) and
+  window i covers padded frames [i, i+RF) (trainer.py:47-58) - the windows are gathered inside
+  the prologue kernel (`Ray3DLifter.forward_clip`), not materialised;
+* the camera row [height, pitch] is shared by all windows of the clip (trainer.py:297,324);
+* prediction = pos + trj, optionally averaged with the mirrored pass (trainer.py:299-302,338-353);
+* prediction and ground truth go to world coordinates in float64 (trainer.py:355-364) and the five
+  per-clip errors are accumulated weighted by the number of frames (trainer.py:386-403).
+
+Multi-GPU: whole clips are partitioned over ranks (one process per GPU), each rank evaluates its
+share with resident weights, and ONE all_gather of the fixed-size per-clip partial rows
+(RCCL over xGMI with the nccl backend, gloo on CPU) brings them together.  There is no other
+collective on the path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import metrics as M
+from .camera import Camera
+
+PARTIAL_COLS = 8   # clip_id, action_id, n_frames, sum_mpjpe, sum_pmpjpe, sum_nmpjpe, sum_vel, sum_root
+
+
+@dataclass
+class Clip:
+    camera: Camera
+    rays: np.ndarray          # (N, J, F) float32 ray-encoded keypoints (model input space)
+    gt_norm: np.ndarray       # (N, J, 3) float32 ground truth in the normalised frame
+    action: str = ""
+    clip_id: int = 0
+
+
+def pad_clip(rays: np.ndarray, pad: int) -> np.ndarray:
+    """np.pad(seq, ((pad, pad), (0,0), (0,0)), 'edge') - generators.py:213-216 with causal_shift 0."""
+    return np.concatenate([np.repeat(rays[:1], pad, axis=0), rays, np.repeat(rays[-1:], pad, axis=0)], axis=0)
+
+
+def mirror_input(clip: torch.Tensor, kps_left: Sequence[int], kps_right: Sequence[int]) -> torch.Tensor:
+    """trainer.py:299-302: negate x, swap left/right keypoints."""
+    out = clip.clone()
+    out[..., 0] *= -1
+    out[:, list(kps_left) + list(kps_right)] = out[:, list(kps_right) + list(kps_left)]
+    return out
+
+
+def mirror_output(pred: torch.Tensor, joints_left: Sequence[int], joints_right: Sequence[int]) -> torch.Tensor:
+    """trainer.py:340-342 on (N,1,J,3) predictions."""
+    out = pred.clone()
+    out[..., 0] *= -1
+    out[:, :, list(joints_left) + list(joints_right)] = out[:, :, list(joints_right) + list(joints_left)]
+    return out
+
+
+def predict_clip(lift_clip: Callable, clip: Clip, rf: int, device, flip: bool = False,
+                 kps_left: Sequence[int] = (), kps_right: Sequence[int] = ()) -> torch.Tensor:
+    """(N,1,J,3) absolute poses in the normalised frame for one clip.
+    `lift_clip(padded (N+RF-1,J,F) tensor, param_row (E,) tensor) -> (N,1,J,3)`."""
+    pad = (rf - 1) // 2
+    padded = torch.from_numpy(pad_clip(np.asarray(clip.rays, dtype=np.float32), pad)).to(device)
+    prow = torch.from_numpy(clip.camera.param()).to(device)
+    pred = lift_clip(padded, prow)
+    if flip:
+        pred_m = lift_clip(mirror_input(padded, kps_left, kps_right), prow)
+        pred = 0.5 * (pred + mirror_output(pred_m, kps_left, kps_right))
+    return pred
+
+
+def clip_partials(pred_norm: torch.Tensor, clip: Clip, action_id: int = 0) -> torch.Tensor:
+    """One PARTIAL_COLS row (float64, on pred's device): N-weighted error sums in metres."""
+    dev = pred_norm.device
+    n = pred_norm.shape[0]
+    R = torch.from_numpy(clip.camera.Rn2w.T.copy()).to(dev)
+    T = torch.from_numpy(clip.camera.Tn2w.T.copy()).to(dev)
+    pw = pred_norm.to(torch.float64).reshape(n, 1, -1, 3) @ R + T             # trainer.py:358
+    gw = torch.from_numpy(np.asarray(clip.gt_norm, dtype=np.float32)).to(dev).to(torch.float64)
+    gw = gw.reshape(n, 1, -1, 3) @ R + T                                        # trainer.py:359
+    row = torch.zeros(PARTIAL_COLS, dtype=torch.float64, device=dev)
+    row[0], row[1], row[2] = clip.clip_id, action_id, n
+    row[3] = n * M.mpjpe(pw, gw)                                                # trainer.py:386
+    row[4] = n * M.p_mpjpe(pw.reshape(n, -1, 3), gw.reshape(n, -1, 3))          # :393
+    row[5] = n * M.n_mpjpe(pw, gw)                                              # :388
+    row[6] = n * M.mean_velocity_error(pw.reshape(n, -1, 3), gw.reshape(n, -1, 3))   # :395
+    row[7] = n * M.mpjpe(pw[:, :, 0:1], gw[:, :, 0:1])                          # :387
+    return row
+
+
+def reduce_partials(rows: torch.Tensor) -> Dict[int, tuple]:
+    """{action_id: (e1, e2, e3, ev, er)} in millimetres - trainer.py:399-403 per action."""
+    rows = rows.detach().to("cpu", torch.float64)
+    out = {}
+    for a in sorted(set(int(v) for v in rows[:, 1].tolist())):
+        sel = rows[rows[:, 1] == a]
+        n = sel[:, 2].sum()
+        out[a] = tuple(float(sel[:, c].sum() / n * 1000.0) for c in (3, 4, 5, 6, 7))
+    return out
+
+
+def action_average(per_action: Dict[int, tuple]) -> tuple:
+    """Unweighted mean over actions, rounded to 0.1 mm like trainer.py:473-477."""
+    arr = np.array(list(per_action.values()), dtype=np.float64)
+    return tuple(round(float(v), 1) for v in arr.mean(axis=0))
+
+
+# ------------------------------------------------------------------------------------ sharding
+
+def shard_clips(lengths: Sequence[int], world_size: int) -> List[List[int]]:
+    """Greedy longest-first bin packing of whole clips by frame count; deterministic, so every rank
+    derives the same assignment without communicating."""
+    bins: List[List[int]] = [[] for _ in range(world_size)]
+    load = [0] * world_size
+    for idx in sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i)):
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        bins[r].append(idx)
+        load[r] += int(lengths[idx])
+    return bins
+
+
+def gather_partials(local_rows: torch.Tensor, counts: Sequence[int], group=None) -> torch.Tensor:
+    """The single exchange step: all_gather of per-clip rows, padded to the largest shard."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    kmax = max(max(counts), 1)
+    pad = torch.zeros((kmax, PARTIAL_COLS), dtype=torch.float64, device=local_rows.device)
+    pad[: local_rows.shape[0]] = local_rows
+    bucket = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bucket, pad, group=group)
+    return torch.cat([bucket[r][: counts[r]] for r in range(world)], dim=0)
+
+
+def evaluate_clips(lift_clip: Callable, clips: Sequence[Clip], rf: int, device, flip: bool = False,
+                   kps_left: Sequence[int] = (), kps_right: Sequence[int] = (),
+                   rank: int = 0, world_size: int = 1, group=None):
+    """Evaluate `clips` (sharded over `world_size` ranks when > 1).  Every rank returns
+    (per_action {name: (e1,e2,e3,ev,er) mm}, action-wise average, gathered partial rows)."""
+    actions = sorted(set(c.action for c in clips))
+    aid = {a: i for i, a in enumerate(actions)}
+    shards = shard_clips([c.rays.shape[0] for c in clips], world_size)
+    rows = []
+    for idx in shards[rank]:
+        c = clips[idx]
+        pred = predict_clip(lift_clip, c, rf, device, flip, kps_left, kps_right)
+        rows.append(clip_partials(pred, Clip(c.camera, c.rays, c.gt_norm, c.action, idx), aid[c.action]))
+    local = torch.stack(rows) if rows else torch.zeros((0, PARTIAL_COLS), dtype=torch.float64, device=device)
+    if world_size > 1:
+        allrows = gather_partials(local, [len(s) for s in shards], group)
+    else:
+        allrows = local
+    per = reduce_partials(allrows)
+    named = {actions[a]: v for a, v in per.items()}
+    return named, action_average(per), allrows

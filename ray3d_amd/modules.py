@@ -1,0 +1,332 @@
+"""nn.Module front end that keeps the reference's module contract but runs on libray3d_hip.so.
+
+Drop-in seam:
+
+* ``Model(model_config, data_config, is_train)`` with ``get_pos_model()`` / ``get_trj_model()``
+  - lib/model/__init__.py:5-62
+* ``pos_model(inputs_2d (B,RF,J,F), inputs_param (B,E)) -> (B,1,J,3)``  - lib/model/rie.py:284-434
+* ``trj_model(...) -> (B,1,1,3)``                                        - lib/model/rie.py:518-559
+* ``state_dict`` / ``load_state_dict(strict=True)`` with the reference's key names and shapes
+  (lib/model/rie.py constructors), ``receptive_field()``, ``eval()/train()``.
+
+The modules only *hold* parameters (so checkpoints and optimisers see the usual tensors); the
+arithmetic happens in the HIP library.  Forward is inference-only (eval-mode BatchNorm, dropout
+off) - calling it in training mode, on a CPU tensor or without the built library raises; there
+is no PyTorch or CPU fallback.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _capi
+from .spec import LiftConfig, config_from_dicts, state_entries
+
+
+class _Node(nn.Module):
+    """Anonymous container; the tree of these mirrors the reference's attribute paths."""
+
+
+def _grow_tree(root: nn.Module, cfg: LiftConfig) -> None:
+    for e in state_entries(cfg):
+        *path, leaf = e.key.split(".")
+        node = root
+        for part in path:
+            if part not in node._modules:
+                node.add_module(part, _Node())
+            node = node._modules[part]
+        if e.role == "bn_count":
+            node.register_buffer(leaf, torch.tensor(0, dtype=torch.long))
+        elif e.is_buffer:
+            fill = 1.0 if e.role == "bn_var" else 0.0
+            node.register_buffer(leaf, torch.full(e.shape, fill, dtype=torch.float32))
+        else:
+            t = torch.empty(e.shape, dtype=torch.float32)
+            if e.role in ("conv_w", "lin_w"):        # nn.Conv1d / nn.Linear default init
+                nn.init.kaiming_uniform_(t, a=math.sqrt(5))
+            elif e.role == "bias":
+                b = 1.0 / math.sqrt(max(e.fan_in, 1))
+                nn.init.uniform_(t, -b, b)
+            elif e.role == "bn_weight":
+                t.fill_(1.0)
+            else:
+                t.zero_()
+            node.register_parameter(leaf, nn.Parameter(t))
+
+
+class _Workspace:
+    """Grow-only scratch HBM per device, handed to the C ABI (the caller owns device buffers)."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(int(nbytes * 1.0) + 256, dtype=torch.uint8, device=device)
+        return self.buf
+
+
+class LiftModule(nn.Module):
+    """Common machinery of RIEModel / RIETrajectoryModel."""
+
+    KIND = "pos"
+
+    def __init__(self, cfg: LiftConfig):
+        super().__init__()
+        self.cfg = cfg
+        self.num_joints_in = cfg.num_joints
+        self.num_joints_out = cfg.num_joints
+        self.in_features = cfg.in_features
+        self.latten_features = cfg.latent
+        self.stage = cfg.stage
+        self.camera_embedding = cfg.camera_embedding
+        self.extrinsic_dim = cfg.extrinsic_dim
+        self.embedd_dim = cfg.embed_dim
+        self.pad = (cfg.receptive_field - 1) // 2
+        _grow_tree(self, cfg)
+        self._handle: Optional[_capi.Handle] = None
+        self._synced = False
+        self._ws = _Workspace()
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
+
+    # ---- reference module surface -------------------------------------------------------
+    def receptive_field(self) -> int:
+        """lib/model/rie.py:278-282 / :512-516"""
+        return self.cfg.receptive_field
+
+    def set_bn_momentum(self, momentum):   # rie.py:255-260 (training only; no effect on eval)
+        self._bn_momentum = momentum
+
+    def set_training_status(self, is_train):   # rie.py:262-268
+        self.is_train = is_train
+
+    def set_augment(self, augment):   # rie.py:270-276
+        self.augment = augment
+
+    # ---- weight sync ---------------------------------------------------------------------
+    def _invalidate(self):
+        self._synced = False
+
+    def _apply(self, fn, *args, **kwargs):   # .cuda() / .to() / .float() move the tensors
+        self._invalidate()
+        return super()._apply(fn, *args, **kwargs)
+
+    def refresh_weights(self):
+        """Call after editing parameters in place (optimizer step, manual surgery)."""
+        self._invalidate()
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        # nn.DataParallel checkpoints (lib/model/__init__.py:52) carry a 'module.' prefix
+        if any(k.startswith("module.") for k in state_dict):
+            state_dict = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def handle(self, device: torch.device) -> _capi.Handle:
+        """The finalized C handle for `device`, re-uploading weights when they changed."""
+        if self._handle is None:
+            self._handle = _capi.Handle(self.cfg)
+        if not self._synced or getattr(self, "_device", None) != device:
+            sd = self.state_dict()
+            for key in self._handle.keys():
+                arr = sd[key].detach().to("cpu", torch.float32).contiguous().numpy()
+                self._handle.set_weight(key, np.ascontiguousarray(arr))
+            with torch.cuda.device(device):
+                self._handle.finalize()
+            self._synced, self._device = True, device
+        return self._handle
+
+    # ---- forward ---------------------------------------------------------------------------
+    def _check_inputs(self, x: torch.Tensor, param: Optional[torch.Tensor]):
+        assert len(x.shape) == 4                              # rie.py:285
+        assert x.shape[-2] == self.num_joints_in              # rie.py:286
+        assert x.shape[-1] == self.in_features                # rie.py:287
+        if x.shape[1] != self.cfg.receptive_field:
+            raise RuntimeError("expected %d-frame windows (1 output frame per window, quirk F3), got %d"
+                               % (self.cfg.receptive_field, x.shape[1]))
+        if self.training:
+            raise RuntimeError("ray3d_amd modules are inference-only: call .eval() first "
+                               "(training-mode BatchNorm/Dropout are not implemented)")
+        if not x.is_cuda:
+            raise RuntimeError("ray3d_amd runs on an AMD GPU only (got a %s tensor); there is no "
+                               "CPU fallback" % x.device)
+        if self.camera_embedding:
+            if param is None or param.shape != (x.shape[0], self.extrinsic_dim):
+                raise RuntimeError("inputs_param must have shape (%d, %d)" % (x.shape[0], self.extrinsic_dim))
+
+    def forward(self, x: torch.Tensor, param: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._check_inputs(x, param)
+        dev = x.device
+        x = x.detach().to(torch.float32).contiguous()
+        p = param.detach().to(dev, torch.float32).contiguous() if self.camera_embedding else None
+        B, J = x.shape[0], self.num_joints_in
+        out = torch.empty((B, 1, J if self.KIND == "pos" else 1, 3), dtype=torch.float32, device=dev)
+        h = self.handle(dev)
+        nbytes = _capi.workspace_bytes(h if self.KIND == "pos" else None, h if self.KIND == "trj" else None, B)
+        ws = self._ws.get(nbytes, dev)
+        inp = _capi.make_input(_capi.R3D_INPUT_RAYS, x.data_ptr(), self.cfg.receptive_field,
+                               p.data_ptr() if p is not None else None, self.extrinsic_dim)
+        with torch.cuda.device(dev):
+            _capi.forward(h, inp, B, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                          torch.cuda.current_stream(dev).cuda_stream)
+        return out
+
+
+class RIEModel(LiftModule):
+    """Pose network, lib/model/rie.py:172-434."""
+    KIND = "pos"
+
+
+class RIETrajectoryModel(LiftModule):
+    """Root-trajectory network, lib/model/rie.py:437-559."""
+    KIND = "trj"
+
+
+class _SingleDeviceParallel(nn.Module):
+    """What the reference's ``nn.DataParallel(model).cuda()`` (lib/model/__init__.py:51-53) looks
+    like from the outside - a ``.module`` attribute and 'module.'-prefixed state_dict keys - without
+    the per-call replicate/scatter/gather: multi-GPU here is one process per GPU (ray3d_amd.dist)."""
+
+    def __init__(self, module: LiftModule):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def receptive_field(self):
+        return self.module.receptive_field()
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        if state_dict and not any(k.startswith("module.") for k in state_dict):
+            state_dict = {"module." + k: v for k, v in state_dict.items()}
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+
+class Model(object):
+    """Factory with the reference's surface (lib/model/__init__.py:5-62)."""
+
+    def __init__(self, model_config: dict, data_config: Optional[dict] = None, is_train: bool = True):
+        pos_model = RIEModel(config_from_dicts(model_config, "pos"))
+        trj_model = RIETrajectoryModel(config_from_dicts(model_config, "trj")) \
+            if model_config["TRAJECTORY_MODEL"] else None
+        for m in (pos_model, trj_model):
+            if m is not None:
+                m.is_train = is_train
+                m.train(is_train)
+        if torch.cuda.is_available():
+            pos_model = _SingleDeviceParallel(pos_model).cuda()
+            trj_model = _SingleDeviceParallel(trj_model).cuda() if trj_model is not None else None
+        self.pos_model = pos_model
+        self.trj_model = trj_model
+
+    def get_pos_model(self):
+        return self.pos_model
+
+    def get_trj_model(self):
+        return self.trj_model
+
+
+def _unwrap(m) -> LiftModule:
+    return m.module if isinstance(m, _SingleDeviceParallel) else m
+
+
+class Ray3DLifter(nn.Module):
+    """pos + trj in one pass: ``lifter(x, param) == pos_model(x, param) + trj_model(x, param)``
+    (lib/train_val/trainer.py:337,346,353) with the prologue shared and every level of both
+    networks batched into common launches."""
+
+    def __init__(self, pos_model, trj_model):
+        super().__init__()
+        self.pos = _unwrap(pos_model)
+        self.trj = _unwrap(trj_model)
+        if not isinstance(self.pos, RIEModel) or not isinstance(self.trj, RIETrajectoryModel):
+            raise TypeError("Ray3DLifter(pos_model: RIEModel, trj_model: RIETrajectoryModel)")
+        self._ws = _Workspace()
+
+    def receptive_field(self) -> int:
+        return self.pos.receptive_field()
+
+    def _run(self, mode, x, window_stride, B, param, param_stride, cam=None, cam_stride=0,
+             return_trj=False):
+        dev = x.device
+        if self.pos.training or self.trj.training:
+            raise RuntimeError("ray3d_amd modules are inference-only: call .eval() first")
+        if not x.is_cuda:
+            raise RuntimeError("ray3d_amd runs on an AMD GPU only (got a %s tensor)" % x.device)
+        hp, ht = self.pos.handle(dev), self.trj.handle(dev)
+        out = torch.empty((B, 1, self.pos.num_joints_in, 3), dtype=torch.float32, device=dev)
+        out_trj = torch.empty((B, 1, 1, 3), dtype=torch.float32, device=dev) if return_trj else None
+        ws = self._ws.get(_capi.workspace_bytes(hp, ht, B), dev)
+        inp = _capi.make_input(mode, x.data_ptr(), window_stride,
+                               param.data_ptr() if param is not None else None, param_stride,
+                               cam.data_ptr() if cam is not None else None, cam_stride)
+        with torch.cuda.device(dev):
+            _capi.forward_pair(hp, ht, inp, B, out.data_ptr(),
+                               out_trj.data_ptr() if out_trj is not None else None,
+                               ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
+        return (out, out_trj) if return_trj else out
+
+    def forward(self, x: torch.Tensor, param: Optional[torch.Tensor] = None, return_trj: bool = False):
+        """x (B,RF,J,F) ray-encoded windows, param (B,E) -> (B,1,J,3) absolute poses."""
+        self.pos._check_inputs(x, param)
+        x = x.detach().to(torch.float32).contiguous()
+        p = param.detach().to(x.device, torch.float32).contiguous() if self.pos.camera_embedding else None
+        return self._run(_capi.R3D_INPUT_RAYS, x, self.receptive_field(), x.shape[0], p,
+                         self.pos.extrinsic_dim, return_trj=return_trj)
+
+    def forward_clip(self, clip: torch.Tensor, param_row: Optional[torch.Tensor] = None):
+        """clip (N + RF - 1, J, F): an edge-padded sequence; window i = frames [i, i+RF) is gathered
+        in the prologue kernel instead of materialising lib/train_val/trainer.py:47-58's copy.
+        param_row (E,) is broadcast to every window (trainer.py:324).  Returns (N,1,J,3)."""
+        rf = self.receptive_field()
+        assert clip.dim() == 3 and clip.shape[1] == self.pos.num_joints_in and clip.shape[2] == self.pos.in_features
+        n = clip.shape[0] - rf + 1
+        if n <= 0:
+            raise RuntimeError("clip shorter than the receptive field")
+        clip = clip.detach().to(torch.float32).contiguous()
+        p = param_row.detach().to(clip.device, torch.float32).contiguous().view(-1) \
+            if self.pos.camera_embedding else None
+        return self._run(_capi.R3D_INPUT_RAYS, clip, 1, n, p, 0)
+
+    def forward_uv(self, uv: torch.Tensor, cam_rows: torch.Tensor, param: Optional[torch.Tensor] = None,
+                   window_stride: Optional[int] = None):
+        """Pixel keypoints in, rays computed on the fly (lib/camera/camera.py:423-471, float64).
+        uv (B,RF,J,2) float32 [or a padded clip (N+RF-1,J,2) with window_stride=1];
+        cam_rows (B,8) or (8,) float64 {fx,fy,cx,cy,cos(pitch),sin(pitch),0,0};
+        param (B,E) or (E,) float32 [height, pitch]."""
+        rf = self.receptive_field()
+        uv = uv.detach().to(torch.float32).contiguous()
+        if uv.dim() == 4:
+            B, ws_ = uv.shape[0], rf
+        else:
+            B, ws_ = uv.shape[0] - rf + 1, 1
+        if window_stride is not None:
+            ws_ = window_stride
+        cam = cam_rows.detach().to(uv.device, torch.float64).contiguous()
+        p = param.detach().to(uv.device, torch.float32).contiguous() if self.pos.camera_embedding else None
+        return self._run(_capi.R3D_INPUT_UV, uv, ws_, B, p,
+                         0 if (p is None or p.dim() == 1) else self.pos.extrinsic_dim,
+                         cam, 0 if cam.dim() == 1 else 8)
+
+    def profile(self, x, param):
+        """One forward with per-launch HIP events; returns the launch records."""
+        h = self.pos.handle(x.device)
+        h.profile_enable(True)
+        try:
+            self.forward(x, param)
+            return h.profile_read()
+        finally:
+            h.profile_enable(False)
+
+
+def load_weight(model, pretrained: Dict[str, torch.Tensor]):
+    """Loud replacement for lib/utils/utils.py:208-218 (which silently skips mismatching keys:
+    a DataParallel checkpoint loaded into a bare model changes 0 tensors without an error).
+    Accepts keys with or without the 'module.' prefix; missing/unexpected keys raise."""
+    target = _unwrap(model)
+    target.load_state_dict(pretrained, strict=True)
+    return model
