@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 output of profiles/prof_recipe.sh (per-dispatch PMC table of one forward).
+usage: python profiles/summarize_pmc.py gpurun_out/prof1 > profiles/<round>/pmc_table.txt"""
+import collections
+import csv
+import glob
+import sys
+
+
+def load(d):
+    f = glob.glob(d + '/runc/*_counter_collection.csv')[0]
+    per = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        k = int(r['Dispatch_Id'])
+        per.setdefault(k, {'name': r['Kernel_Name'], 'grid': r['Grid_Size'], 't0': int(r['Start_Timestamp']),
+                           't1': int(r['End_Timestamp'])})
+        per[k][r['Counter_Name']] = float(r['Counter_Value'])
+    return per
+
+
+def one_forward(per):
+    ids = sorted(per)
+    first = [i for i in ids if per[i]['name'].startswith('r3d_')]
+    starts = [i for i in first if per[i]['name'] == per[first[0]]['name']]
+    s, e = starts[-2], starts[-1]
+    return [per[i] for i in ids if s <= i < e and per[i]['name'].startswith('r3d')]
+
+
+root = sys.argv[1]
+f1, f2, f3, f4 = (one_forward(load('%s/pmc%d' % (root, i))) for i in (1, 2, 3, 4))
+print('# one forward (B=256, RF 243, pos+trj); cycles in millions (SQ_* quad-cycle counters x4); FETCH_SIZE x2 per '
+      'MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); clk = GRBM_GUI_ACTIVE / 8 XCDs / duration')
+print('%-20s %9s %8s %8s %8s %8s %8s %8s | %7s %6s | %8s %8s %5s' % (
+    'kernel', 'grid', 'dur_us', 'waveMcy', 'mfmaMcy', 'waitAny', 'waitInst', 'active', 'ldsIdxM', 'clkGHz', 'fetchMB',
+    'writeMB', 'L2hit'))
+for a, b, c, d in zip(f1, f2, f3, f4):
+    dur = (a['t1'] - a['t0']) / 1e3
+    print('%-20s %9s %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f | %7.2f %6.2f | %8.1f %8.1f %5.1f' % (
+        a['name'][:20], a['grid'], dur, a['SQ_WAVE_CYCLES'] * 4 / 1e6, a['SQ_VALU_MFMA_BUSY_CYCLES'] / 1e6,
+        a['SQ_WAIT_ANY'] * 4 / 1e6, a['SQ_WAIT_INST_ANY'] * 4 / 1e6, a['SQ_ACTIVE_INST_ANY'] * 4 / 1e6,
+        b['SQ_LDS_IDX_ACTIVE'] / 1e6, b['GRBM_GUI_ACTIVE'] / 8 / (b['t1'] - b['t0']), c['FETCH_SIZE'] * 2 / 1e3,
+        d['WRITE_SIZE'] / 1e3, 100 * d['TCC_HIT_sum'] / max(1, d['TCC_HIT_sum'] + d['TCC_MISS_sum'])))
