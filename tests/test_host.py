@@ -1,0 +1,264 @@
+"""CPU suite, part 2: host logic of the product (no GPU, no compute calls into the HIP library):
+C-ABI surface, weight grammar, module shim contract, camera constants, metrics, clip evaluation
+logic, clip sharding and the world_size-2 gather over gloo."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, MODEL_CASES, ROOT, load_model_fixture, synth_states
+
+import ray3d_amd
+from ray3d_amd import _capi, evaluate, metrics, synth
+from ray3d_amd.spec import config_from_dicts, default_model_config, state_entries
+
+
+# ------------------------------------------------------------------ C ABI surface
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ray3d_hip.h")).read()
+    declared = set(re.findall(r"\b(r3d_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_capi.EXPORTS), declared ^ set(_capi.EXPORTS)
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in _capi.load().r3d_version()
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_c_grammar_equals_python_spec(name):
+    _, mc = load_model_fixture(name)
+    for kind in ("pos", "trj"):
+        cfg = config_from_dicts(mc, kind)
+        h = _capi.Handle(cfg)
+        want = {e.key: tuple(e.shape) for e in state_entries(cfg) if e.role != "bn_count"}
+        keys = h.keys()
+        assert set(keys) == set(want)
+        for i, k in enumerate(keys):
+            assert h.shape(i) == want[k], k
+        h.close()
+
+
+def test_set_weight_is_strict_and_loud():
+    cfg = config_from_dicts(default_model_config(), "trj")
+    h = _capi.Handle(cfg)
+    w = np.zeros((256, 153, 3), np.float32)
+    h.set_weight("LocalLayer.expand_conv.weight", w)
+    h.set_weight("module.LocalLayer.expand_conv.weight", w)            # DataParallel prefix accepted
+    with pytest.raises(_capi.Ray3DHipError, match="unexpected key"):
+        h.set_weight("LocalLayer.nonexistent.weight", w)
+    with pytest.raises(_capi.Ray3DHipError, match="size mismatch"):
+        h.set_weight("LocalLayer.expand_conv.weight", np.zeros((256, 153, 1), np.float32))
+    with pytest.raises(_capi.Ray3DHipError, match="Missing key"):
+        h.finalize()                                                    # most tensors were never set
+    h.close()
+
+
+def test_create_rejects_unsupported_configs():
+    for over in (dict(NUM_KPTS=16), dict(INPUT_DIM=4), dict(CHANNELS=250)):
+        with pytest.raises((ValueError, _capi.Ray3DHipError)):
+            _capi.Handle(config_from_dicts(default_model_config(**over), "pos"))
+    for over in (dict(CAUSAL=True), dict(DENSE=True), dict(DISABLE_OPTIMIZATIONS=True), dict(ARCHITECTURE="3,5")):
+        with pytest.raises(NotImplementedError):
+            config_from_dicts(default_model_config(**over), "pos")
+
+
+def test_forward_before_finalize_fails():
+    cfg = config_from_dicts(default_model_config(), "trj")
+    h = _capi.Handle(cfg)
+    inp = _capi.make_input(_capi.R3D_INPUT_RAYS, 1 << 20, 9, 1 << 20, 2)
+    with pytest.raises(_capi.Ray3DHipError, match="finalize"):
+        _capi.forward(h, inp, 4, 1 << 20, 1 << 20, 1 << 30, 0)
+    h.close()
+
+
+# ------------------------------------------------------------------ nn.Module shim
+
+def test_module_state_dict_contract():
+    mc = default_model_config(ARCHITECTURE="3,3,3")
+    fac = ray3d_amd.Model(mc, {}, is_train=False)
+    pos, trj = fac.get_pos_model(), fac.get_trj_model()
+    assert pos.receptive_field() == 27 and trj.receptive_field() == 27
+    (cp, sp), (ct, st) = synth_states(mc)
+    assert set(pos.state_dict().keys()) == set(sp.keys())
+    assert set(trj.state_dict().keys()) == set(st.keys())
+    for k, v in pos.state_dict().items():
+        assert tuple(v.shape) == tuple(np.asarray(sp[k]).shape), k
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sp.items()}
+    pos.load_state_dict(sd, strict=True)
+    pos.load_state_dict({"module." + k: v for k, v in sd.items()}, strict=True)   # DataParallel checkpoint
+    bad = dict(sd)
+    bad.pop("GlobalInfo.fc_1.weight")
+    with pytest.raises(RuntimeError, match="Missing key"):
+        ray3d_amd.load_weight(pos, bad)
+    assert sum(p.numel() for p in pos.parameters()) > 39e6          # 39.5 M parameters at RF 27
+    assert len(list(pos.named_parameters())) > 100
+    assert fac.get_trj_model() is trj
+    fac2 = ray3d_amd.Model(default_model_config(TRAJECTORY_MODEL=False), {}, is_train=True)
+    assert fac2.get_trj_model() is None
+
+
+def test_module_forward_guards():
+    mc = default_model_config()
+    pos = ray3d_amd.RIEModel(config_from_dicts(mc, "pos"))
+    x = torch.zeros(2, 9, 17, 3)
+    p = torch.zeros(2, 2)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        pos.train()(x, p)
+    with pytest.raises(RuntimeError, match="no.*CPU fallback|AMD GPU"):
+        pos.eval()(x, p)
+    with pytest.raises(AssertionError):
+        pos(torch.zeros(2, 9, 16, 3), p)
+    with pytest.raises(RuntimeError, match="9-frame"):
+        pos(torch.zeros(2, 27, 17, 3), p)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "ray3d_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
+                assert "ray3d_oracle" not in text or f == "spec.py", f
+
+
+# ------------------------------------------------------------------ synthetic generator pin
+
+def test_synth_generator_is_pinned():
+    u = synth.hash_uniform("pin", (4,), seed=7)
+    assert np.allclose(u, synth.hash_uniform("pin", (4,), seed=7))
+    assert not np.allclose(u, synth.hash_uniform("pin", (4,), seed=8))
+    z, mc = load_model_fixture("j17_rf27_s3")
+    cfg = config_from_dicts(mc, "pos")
+    assert np.array_equal(synth.synth_rays(3, cfg, seed=3), z["x"])          # inputs regenerate bit-exactly
+    assert np.array_equal(synth.synth_param(3, seed=4), z["param"])
+
+
+# ------------------------------------------------------------------ camera + metrics
+
+def test_camera_matches_reference():
+    z = np.load(os.path.join(GOLDEN, "cameras.npz"))
+    for tag in z["tags"]:
+        cam = ray3d_amd.Camera(z[tag + "/K"], z[tag + "/R"], z[tag + "/t"])
+        assert abs(cam.height - float(z[tag + "/height"])) < 1e-12
+        assert abs(cam.pitch - float(z[tag + "/pitch"])) < 1e-12
+        for n in ("Rc2n", "Tc2n", "Rn2w", "Tn2w", "Rw2n", "Tw2n"):
+            assert np.abs(getattr(cam, n) - z[tag + "/" + n]).max() < 1e-12, (tag, n)
+        assert np.abs(cam.rays_from_uv(z[tag + "/uv"]) - z[tag + "/rays"]).max() < 1e-12
+        assert np.abs(cam.uv_from_rays(z[tag + "/rays"]) - z[tag + "/uv"]).max() < 1e-9
+        assert np.abs(cam.world2normalized(z[tag + "/Xw"]) - z[tag + "/Xn"]).max() < 1e-12
+        assert np.abs(cam.normalized2world(z[tag + "/Xn"]) - z[tag + "/Xw_back"]).max() < 1e-12
+        assert np.abs(cam.project(z[tag + "/Xw"]) - z[tag + "/proj"]).max() < 1e-8
+        assert cam.param().dtype == np.float32 and cam.cam_row().shape == (8,)
+    s9 = ray3d_amd.Camera(z["h36m_S9_0/K"], z["h36m_S9_0/R"], z["h36m_S9_0/t"])
+    assert np.allclose(s9.param(), [1.4812, 0.18404], atol=2e-4)    # the constants BASELINE.md quotes
+    with pytest.raises(NotImplementedError):
+        ray3d_amd.Camera(z["h36m_S9_0/K"], z["h36m_S9_0/R"], z["h36m_S9_0/t"], undistort=True)
+
+
+def test_metrics_match_reference():
+    z = np.load(os.path.join(GOLDEN, "losses.npz"))
+    a, b = torch.from_numpy(z["pred"]), torch.from_numpy(z["target"])
+    assert abs(float(metrics.mpjpe(a, b)) - float(z["mpjpe"])) < 1e-12
+    assert abs(float(metrics.n_mpjpe(a, b)) - float(z["n_mpjpe"])) < 1e-12
+    assert abs(float(metrics.p_mpjpe(a.reshape(-1, 17, 3), b.reshape(-1, 17, 3))) - float(z["p_mpjpe"])) < 1e-10
+    assert abs(float(metrics.mean_velocity_error(a.reshape(-1, 17, 3), b.reshape(-1, 17, 3))) - float(z["mpjve"])) < 1e-12
+
+
+# ------------------------------------------------------------------ evaluation loop (oracle as the lifter)
+
+def _evalcore_clips():
+    z = np.load(os.path.join(GOLDEN, "evalcore.npz"))
+    clips = []
+    for ci in range(3):
+        cam = ray3d_amd.Camera(z["clip%d/K" % ci], z["clip%d/R" % ci], z["clip%d/t" % ci])
+        clips.append(evaluate.Clip(cam, z["clip%d/rays" % ci], z["clip%d/gt_norm" % ci], action="A", clip_id=ci))
+    return z, clips
+
+
+def _oracle_lift_clip():
+    """CPU stand-in for Ray3DLifter.forward_clip built on the oracle (checker role only)."""
+    from oracle import oracle
+    mc = default_model_config(ARCHITECTURE="3,3,3")
+    (cp, sp), (ct, st) = synth_states(mc)
+
+    def lift(padded, prow):
+        pad = padded.numpy()
+        n = pad.shape[0] - 27 + 1
+        win = np.stack([pad[i:i + 27] for i in range(n)])
+        par = np.tile(prow.numpy(), (n, 1))
+        return torch.from_numpy(oracle.forward(cp, sp, win, par) + oracle.forward(ct, st, win, par))
+    return lift
+
+
+@pytest.mark.parametrize("flip", [False, True])
+def test_evaluate_reproduces_reference_evaluate_core(flip):
+    z, clips = _evalcore_clips()
+    lift = _oracle_lift_clip()
+    named, avg, rows = evaluate.evaluate_clips(lift, clips, 27, "cpu", flip=flip,
+                                               kps_left=list(z["kps_left"]), kps_right=list(z["kps_right"]))
+    ref = z["metrics_flip%d" % int(flip)]
+    got = np.array(named["A"])
+    assert np.abs(got - ref).max() < 2e-2, (got, ref)     # millimetres; reference works in fp32
+    per_clip = evaluate.reduce_partials(torch.cat([rows[:, :1] * 0 + 0, rows[:, 0:1], rows[:, 2:]], dim=1))
+    for ci in range(3):
+        assert np.abs(np.array(per_clip[ci]) - z["clip%d/metrics_flip%d" % (ci, int(flip))]).max() < 2e-2
+    if not flip:
+        pred0 = evaluate.predict_clip(lift, clips[0], 27, "cpu").numpy()
+        assert np.abs(pred0 - z["clip0/predictions"]).max() < 5e-5
+
+
+def test_pad_clip_is_edge_padding():
+    a = np.arange(24, dtype=np.float32).reshape(4, 2, 3)
+    assert np.array_equal(evaluate.pad_clip(a, 3), np.pad(a, ((3, 3), (0, 0), (0, 0)), "edge"))
+
+
+def test_shard_clips_partitions_and_balances():
+    rng = np.random.default_rng(0)
+    lengths = rng.integers(1000, 6000, size=236).tolist()
+    for world in (1, 2, 4, 8):
+        shards = evaluate.shard_clips(lengths, world)
+        flat = sorted(i for s in shards for i in s)
+        assert flat == list(range(236))
+        loads = [sum(lengths[i] for i in s) for s in shards]
+        assert max(loads) - min(loads) <= max(lengths)
+    assert evaluate.shard_clips([5, 5], 4) == [[0], [1], [], []]
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _, clips = _evalcore_clips()
+        clips[1].action = "B"
+        named, avg, rows = evaluate.evaluate_clips(_oracle_lift_clip(), clips, 27, "cpu", rank=rank, world_size=world)
+        q.put((rank, named, avg, rows.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gather_matches_single_process():
+    import torch.multiprocessing as mp
+    _, clips = _evalcore_clips()
+    clips[1].action = "B"
+    named1, avg1, rows1 = evaluate.evaluate_clips(_oracle_lift_clip(), clips, 27, "cpu")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, named, avg, rows in res:
+        assert avg == avg1
+        for a in named1:
+            assert np.allclose(named[a], named1[a], rtol=0, atol=1e-9)
+        assert sorted(rows[:, 0].tolist()) == [0.0, 1.0, 2.0]
