@@ -148,27 +148,22 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
     if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
     ++stage_no;
 
-    // ---- grouped GEMM launches, one per DAG level
-    for (const auto &st : pl->stages) {
-        StageArgs sa;
-        memset(&sa, 0, sizeof sa);
-        sa.nprob = (int)st.size();
-        // tile choice: big tiles only when they still give every CU a few workgroups
-        long long tiles128 = 0;
-        for (int id : st) {
-            const ProbSpec &q = pl->probs[id];
-            const Layer &L = pl->m[q.model]->layers[q.layer];
-            const long long M = B * q.rows_per_window;
-            tiles128 += ((M + 127) / 128) * ((L.N + 127) / 128);
-        }
-        const int tile = tiles128 >= 512 ? 128 : 64;
-        int tb = 0;
-        double flops = 0, bytes = 0;
-        for (int i = 0; i < sa.nprob; ++i) {
+    // ---- persistent GEMM launches, one per DAG level
+    Schedule *sched = schedule_get(pl, B, device_cu_count());
+    if (!sched) return R3D_ERR_HIP;
+    for (size_t si = 0; si < pl->stages.size(); ++si) {
+        const auto &st = pl->stages[si];
+        const StageSchedule &ss = sched->stages[si];
+        LaunchArgs la;
+        memset(&la, 0, sizeof la);
+        la.tiles = sched->d_tiles + ss.tiles_off;
+        la.wg_off = sched->d_wgoff + ss.wgoff_off;
+        la.nprob = (int)st.size();
+        for (int i = 0; i < la.nprob; ++i) {
             const ProbSpec &q = pl->probs[st[i]];
             const Model *m = pl->m[q.model];
             const Layer &L = m->layers[q.layer];
-            GemmProb &g = sa.p[i];
+            GemmProb &g = la.p[i];
             int kend = 0;
             for (int s = 0; s < MAX_SEG; ++s) {
                 if (s < q.nseg) {
@@ -192,15 +187,9 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             g.N = L.N;
             g.K = L.Kpad;
             g.slope = L.slope;
-            g.tile_begin = tb;
-            g.tiles_n = (L.N + tile - 1) / tile;
-            tb += g.tiles_n * ((g.M + tile - 1) / tile);
-            flops += q.flops_per_window * (double)B;
-            bytes += 4.0 * ((double)g.M * L.K + (double)L.N * L.K + (double)g.M * L.N * (q.res_buf >= 0 ? 2.0 : 1.0));
         }
-        sa.total_tiles = tb;
-        if ((e = rec.begin(gemm_kernel_name(tile), stage_no, tb, flops, bytes)) != hipSuccess) return hip_fail(e, "hipEventRecord");
-        if ((e = launch_gemm_stage(sa, tile, stream)) != hipSuccess) return hip_fail(e, "launch r3d_gemm_f32");
+        if ((e = rec.begin("r3d_gemm_f32", stage_no, ss.nwg, ss.flops, ss.bytes)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        if ((e = launch_gemm_stage(la, ss.nwg, stream)) != hipSuccess) return hip_fail(e, "launch r3d_gemm_f32");
         if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
         ++stage_no;
     }

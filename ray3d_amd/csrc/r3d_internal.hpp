@@ -15,7 +15,7 @@ namespace r3d {
 constexpr int BK = 32;        // K tile of the GEMM kernels; every packed K is a multiple of it
 constexpr int MAX_SEG = 4;    // K segments of an A operand (concatenations are never materialised)
 constexpr int MAX_PROB = 12;  // GEMM problems grouped in one launch
-constexpr int N_ALIGN = 128;  // packed weight rows are padded to this (largest N tile)
+constexpr int N_ALIGN = 256;  // packed weight rows are padded to the GEMM column-block width
 constexpr int MLP_HIDDEN = 1024;
 constexpr int EMBED_MID = 32;
 constexpr int CUR_LD = 64;    // padded row length of the "current frame" matrix (J*F <= 51)
@@ -35,13 +35,16 @@ struct GemmProb {
     int ldr, ldc;
     int M, N, K;
     float slope;              // LeakyReLU slope, 1.0f = linear layer
-    int tile_begin;           // first workgroup of this problem inside the launch
-    int tiles_n;
 };
 
-struct StageArgs {
+// Kernel argument of one persistent GEMM launch.  `tiles`/`wg_off` live in HBM (built once per
+// (plan, batch size) by r3d_schedule.cpp); the problem table travels in the kernarg segment.
+struct LaunchArgs {
+    const int4 *tiles;    // {problem | MI << 8, first row, first column, 0}
+    const int *wg_off;    // [grid + 1]: chunk c executes tiles [wg_off[c], wg_off[c+1])
     int nprob;
-    int total_tiles;
+    int pad_;
+    long long *dbg;       // optional phase timestamps (R3D_TIMING builds only)
     GemmProb p[MAX_PROB];
 };
 
@@ -161,6 +164,24 @@ struct ProbSpec {
     double flops_per_window;     // 2 * rows * K_true * N_true
 };
 
+// Per-(plan, batch) work distribution of the persistent GEMM launches.
+struct StageSchedule {
+    int nwg;               // grid size
+    int ntiles;
+    size_t tiles_off;      // offsets (in int4 / int) into Schedule::d_tiles / d_wgoff
+    size_t wgoff_off;
+    double flops, bytes;   // algorithmic, for the launch records
+    double imbalance;      // max chunk cost / mean chunk cost
+};
+
+struct Schedule {
+    int64_t B = 0;
+    std::vector<StageSchedule> stages;
+    int4 *d_tiles = nullptr;
+    int *d_wgoff = nullptr;
+    ~Schedule();
+};
+
 struct Plan {
     const Model *m[2] = {nullptr, nullptr};   // m[0] may be pos or trj (single), m[1] partner
     std::vector<BufferSpec> buffers;
@@ -176,6 +197,9 @@ struct Plan {
     int dec_buf = -1;            // pos decoder matrix (assemble input), -1 when no pos model
     int trj_buf = -1;            // trj output matrix
     int pos_model = -1, trj_model = -1;
+    std::map<int64_t, Schedule *> schedules;   // by batch size (small LRU, see schedule_get)
+    std::vector<int64_t> schedule_lru;
+    ~Plan();
 };
 
 void set_error(const char *fmt, ...);
@@ -186,12 +210,16 @@ Model *model_create(const r3d_config &cfg);
 int model_set_weight(Model *m, const char *key, const float *host, const int64_t *shape, int rank);
 int model_finalize(Model *m);
 Plan *plan_get(Model *a, Model *b);
+struct SchedProb { int M, N, nk; };
+void schedule_stage(const std::vector<SchedProb> &probs, int nwg, std::vector<int4> &tiles, std::vector<int> &wgoff,
+                    StageSchedule &out);
+Schedule *schedule_get(Plan *pl, int64_t B, int nwg);   // nullptr + set_error on failure
+int device_cu_count();
 
 // kernel launchers (r3d_kernels.hip)
 hipError_t launch_encode(const EncodeArgs &args, hipStream_t stream, int *blocks);
-hipError_t launch_gemm_stage(const StageArgs &args, int tile, hipStream_t stream);
+hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, hipStream_t stream);
 hipError_t launch_assemble(const AssembleArgs &args, hipStream_t stream, int *blocks);
-const char *gemm_kernel_name(int tile);
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 

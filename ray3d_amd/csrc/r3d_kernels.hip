@@ -7,9 +7,9 @@
 //                      or from a sliding clip (lib/train_val/trainer.py:47-58), positional /
 //                      temporal differences and body-part grouping (lib/model/rie.py:290-357),
 //                      camera-embedding MLP (lib/model/embedding.py:15-18).
-//  r3d_gemm_f32_t128   grouped GEMM + fused epilogue  C = res + lrelu(A W^T + b): every Conv1d /
-//  r3d_gemm_f32_t64    Linear of TemporalBlock / FCBlock (rie.py:85-105, :122-135, :159-169) with
-//                      eval BatchNorm folded; 128x128 and 64x64 workgroup tiles.
+//  r3d_gemm_f32        persistent grouped GEMM + fused epilogue  C = res + lrelu(A W^T + b): every
+//                      Conv1d / Linear of TemporalBlock / FCBlock (rie.py:85-105, :122-135, :159-169)
+//                      with eval BatchNorm folded.
 //  r3d_assemble_f32    epilogue: joint reassembly (rie.py:415-432) + trajectory add
 //                      (lib/train_val/trainer.py:353).
 #include <hip/hip_runtime.h>
@@ -22,155 +22,159 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------ GEMM
+//
+// One persistent launch per DAG level: grid = #CUs, one 512-thread workgroup (8 wavefronts, two per
+// SIMD) per CU, owning 144 KiB of LDS.  The host cuts the level's work - all (problem, 256-column
+// block, 32-row unit) triples - into one contiguous, cost-balanced chunk per workgroup
+// (r3d_schedule.cpp); a chunk is executed as a few tiles of BM = 32*MI rows (MI = 1..8) by 256
+// columns.  Wavefront w owns columns [32w, 32w+32) of the tile and all MI row blocks, so any MI is
+// perfectly balanced across the 8 wavefronts and the only waste is the 32-row MFMA granularity.
+//
+// K loop: BK = 32.  A (BM x 32) and W (256 x 32) tiles are staged global -> VGPR -> LDS with a
+// one-tile prefetch (tile t+1 is in flight while tile t feeds the matrix cores) and double-buffered
+// in LDS; rows are padded to 36 floats so the 16 lanes a ds_read_b128 services together hit 16
+// distinct 16-byte slots (no bank conflicts; SQ_LDS_BANK_CONFLICT = 0 in profiles/).
+// MFMA operand mapping (v_mfma_f32_32x32x2_f32): lane l supplies A[i = l&31][k = l>>5] and
+// B[k = l>>5][j = l&31].  Lane (i, h) reads 4 consecutive floats k = 16h + 4q .. +3 of its row per
+// ds_read_b128 and feeds them to 4 MFMAs; since A and W use the same k permutation the sum over
+// k is unchanged.
 
-constexpr int LDS_LD = BK + 4;   // +16 B pad: ds_read_b128 of 16 rows hits 16 distinct 16-B slots
+constexpr int LDS_LD = BK + 4;                       // 36 floats = 144 B per staged row
+constexpr int GEMM_THREADS = 512;
+constexpr int GEMM_BN = 256;
+constexpr int GEMM_MAX_MI = 8;
+constexpr int STAGE_FLOATS = (GEMM_MAX_MI * 32 + GEMM_BN) * LDS_LD;
+constexpr int GEMM_LDS_BYTES = 2 * STAGE_FLOATS * 4; // 147456 B
 
-template <int BM, int BN>
-struct GemmCfg {
-    static constexpr int THREADS = 256;                 // 4 wavefronts, 2 (M) x 2 (N)
-    static constexpr int MI = BM / 64, NI = BN / 64;    // 32x32 MFMA tiles per wavefront
-    static constexpr int A_V4 = BM * BK / 4 / THREADS;  // float4 global loads per thread per K tile
-    static constexpr int B_V4 = BN * BK / 4 / THREADS;
-    static constexpr int STAGE_FLOATS = (BM + BN) * LDS_LD;
-    static constexpr int LDS_BYTES = 2 * STAGE_FLOATS * 4;
-};
+typedef const LaunchArgs __attribute__((address_space(4))) *LaunchArgsPtr;
+typedef const GemmProb __attribute__((address_space(4))) &ProbRef;
 
-// The launch descriptor lives in the kernarg segment; it is read through a constant-address-space
-// pointer so that the (wave-uniform) dynamic problem index turns into scalar loads, not scratch.
-typedef const StageArgs __attribute__((address_space(4))) *StageArgsPtr;
-
-template <int BM, int BN>
-__device__ __forceinline__ void gemm_body(StageArgsPtr argp, float *smem) {
-    const StageArgs __attribute__((address_space(4))) &args = *argp;
-    using Cfg = GemmCfg<BM, BN>;
-    constexpr int MI = Cfg::MI, NI = Cfg::NI, A_V4 = Cfg::A_V4, B_V4 = Cfg::B_V4;
-
+template <int MI>
+__device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int col0, float *smem, long long *dbg) {
+    constexpr int NA = (MI + 1) / 2;        // A staging slots per thread (64 rows per slot)
+    constexpr int NB = 4;                   // W staging slots per thread (256 rows)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
-
-    // XCD-aware order: consecutive logical tiles (which share A rows / weights) stay on one XCD's L2.
-    // Workgroup b runs on XCD b % 8 (observed; affects speed only).
-    int bid = blockIdx.x;
-    {
-        const int n = args.total_tiles, q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < MAX_PROB; ++i)
-        if (i < args.nprob && bid >= args.p[i].tile_begin) pi = i;
-    const GemmProb __attribute__((address_space(4))) &P = args.p[pi];
-    const int t = bid - P.tile_begin;
-    const int tn = t % P.tiles_n, tm = t / P.tiles_n;
-    const int row0 = tm * BM, col0 = tn * BN;
     const int M = P.M, N = P.N, K = P.K;
     const int nk = K / BK;
-
     const int ke0 = P.kend[0], ke1 = P.kend[1], ke2 = P.kend[2];
+    const int srow = tid >> 3, a_kq = (tid & 7) * 4;
 
-    // per-thread staging coordinates (8 float4 per 32-float tile row)
-    int a_row[A_V4], a_lds[A_V4];
+    int a_row[NA];
+    bool a_on[NA];
 #pragma unroll
-    for (int i = 0; i < A_V4; ++i) {
-        const int v = tid + i * Cfg::THREADS, r = v >> 3, kq = v & 7;
-        int gr = row0 + r;
+    for (int i = 0; i < NA; ++i) {
+        const int r = srow + 64 * i;
+        a_on[i] = (MI % 2 == 0) || (i < NA - 1) || (srow < 32);
+        const int gr = row0 + r;
         a_row[i] = gr < M ? gr : M - 1;
-        a_lds[i] = r * LDS_LD + kq * 4;
     }
-    const float *b_ptr[B_V4];
-    int b_lds[B_V4];
-#pragma unroll
-    for (int i = 0; i < B_V4; ++i) {
-        const int v = tid + i * Cfg::THREADS, r = v >> 3, kq = v & 7;
-        b_ptr[i] = P.w + (size_t)(col0 + r) * K + kq * 4;
-        b_lds[i] = BM * LDS_LD + r * LDS_LD + kq * 4;
-    }
-    const int a_kq = (tid & 7) * 4;
+    const float *w_ptr = P.w + (size_t)(col0 + srow) * K + a_kq;
+    const size_t w_step = (size_t)64 * K;
+    const int st_off = srow * LDS_LD + a_kq;           // staging offset inside a 64-row slot
 
-    f32x4 ra[A_V4], rb[B_V4];
+    f32x4 ra[NA], rb[NB];
     auto load_global = [&](int kt) {
         const int kb = kt * BK;
-        // which K segment of the (virtually concatenated) A operand this tile falls in; the
-        // descriptor is in constant memory, so the uniform index becomes three scalar loads
+        // K segment of the (virtually concatenated) A operand this tile falls in (uniform -> scalar loads)
         const int si = (kb >= ke0) + (kb >= ke1) + (kb >= ke2);
         const float *base = P.a[si];
         const int ld = P.lda[si];
         const int k0 = si ? P.kend[si - 1] : 0;
         const int kofs = kb - k0 + a_kq;
 #pragma unroll
-        for (int i = 0; i < A_V4; ++i)
-            ra[i] = *reinterpret_cast<const f32x4 *>(base + (size_t)a_row[i] * ld + kofs);
+        for (int i = 0; i < NA; ++i)
+            if (a_on[i]) ra[i] = *reinterpret_cast<const f32x4 *>(base + (size_t)a_row[i] * ld + kofs);
 #pragma unroll
-        for (int i = 0; i < B_V4; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(b_ptr[i] + kb);
+        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(w_ptr + i * w_step + kb);
     };
     auto store_lds = [&](int buf) {
-        float *s = smem + buf * Cfg::STAGE_FLOATS;
+        float *s = smem + buf * STAGE_FLOATS + st_off;
 #pragma unroll
-        for (int i = 0; i < A_V4; ++i) *reinterpret_cast<f32x4 *>(s + a_lds[i]) = ra[i];
+        for (int i = 0; i < NA; ++i)
+            if (a_on[i]) *reinterpret_cast<f32x4 *>(s + i * 64 * LDS_LD) = ra[i];
 #pragma unroll
-        for (int i = 0; i < B_V4; ++i) *reinterpret_cast<f32x4 *>(s + b_lds[i]) = rb[i];
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4 *>(s + (GEMM_MAX_MI * 32 + i * 64) * LDS_LD) = rb[i];
     };
 
-    f32x16 acc[MI][NI];
+    f32x16 acc[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.0f;
 
-    // fragment read offsets: lane (li, lh) reads row li, K chunk [lh*16 + q*4, +4)
-    const int a_frag = (wm * (BM / 2) + li) * LDS_LD + lh * 16;
-    const int b_frag = BM * LDS_LD + (wn * (BN / 2) + li) * LDS_LD + lh * 16;
+    const int a_frag = li * LDS_LD + lh * 16;
+    const int b_frag = (GEMM_MAX_MI * 32 + wave * 32 + li) * LDS_LD + lh * 16;
 
+#ifdef R3D_TIMING
+#define R3D_STAMP(slot) do { if (dbg && tid == 0 && kt < 32) dbg[kt * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define R3D_STAMP(slot) do { } while (0)
+#endif
     load_global(0);
     store_lds(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
+        R3D_STAMP(0);
         if (more) load_global(kt + 1);
-        const float *s = smem + (kt & 1) * Cfg::STAGE_FLOATS;
+        R3D_STAMP(1);
+        const float *s = smem + (kt & 1) * STAGE_FLOATS;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f32x4 av[MI], bv[NI];
+            f32x4 av[MI];
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(s + b_frag + q * 4);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
                 av[mi] = *reinterpret_cast<const f32x4 *>(s + a_frag + mi * 32 * LDS_LD + q * 4);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                bv[ni] = *reinterpret_cast<const f32x4 *>(s + b_frag + ni * 32 * LDS_LD + q * 4);
-#pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][kk], bv[ni][kk], acc[mi][ni], 0, 0, 0);
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][kk], bv[kk], acc[mi], 0, 0, 0);
         }
+        R3D_STAMP(2);
         if (more) store_lds((kt + 1) & 1);
+        R3D_STAMP(3);
         __syncthreads();
+        R3D_STAMP(4);
     }
+#ifdef R3D_TIMING
+    if (dbg && tid == 0) dbg[255] = __builtin_readcyclecounter();
+#endif
 
     // epilogue: C = res + lrelu(acc + bias).  C/D layout of the 32x32 MFMA: col = lane & 31,
-    // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  A wavefront store instruction writes two
+    // 128-byte row pieces (lanes 0-31 and 32-63).
+    const int col = col0 + wave * 32 + li;
     const float slope = P.slope;
     const float *res = P.res;
     float *c = P.c;
     const int ldc = P.ldc, ldr = P.ldr;
+    const float bias = P.bias[col];
+    const bool full = (row0 + MI * 32 <= M) && (col0 + GEMM_BN <= N);   // wave-uniform
+    if (full) {
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int col = col0 + wn * (BN / 2) + ni * 32 + li;
-        if (col >= N) continue;
-        const float bias = P.bias[col];
+        for (int mi = 0; mi < MI; ++mi) {
+            const size_t rbase = (size_t)(row0 + mi * 32 + 4 * lh);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t row = rbase + (r & 3) + 8 * (r >> 2);
+                float v = acc[mi][r] + bias;
+                v = v > 0.0f ? v : v * slope;
+                if (res) v += res[row * ldr + col];
+                c[row * ldc + col] = v;
+            }
+        }
+    } else if (col < N) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = row0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = row0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row < M) {
-                    float v = acc[mi][ni][r] + bias;
+                    float v = acc[mi][r] + bias;
                     v = v > 0.0f ? v : v * slope;
                     if (res) v += res[(size_t)row * ldr + col];
                     c[(size_t)row * ldc + col] = v;
@@ -180,34 +184,63 @@ __device__ __forceinline__ void gemm_body(StageArgsPtr argp, float *smem) {
     }
 }
 
-extern "C" __global__ __launch_bounds__(256) void r3d_gemm_f32_t128(const StageArgs args) {
+extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_f32(const LaunchArgs args_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    (void)args;
-    gemm_body<128, 128>((StageArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), smem);
+    (void)args_;
+    LaunchArgsPtr args = (LaunchArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    // XCD-aware chunk order: workgroup b runs on XCD b % 8 (observed; speed only), so give each XCD a
+    // contiguous run of chunks - neighbouring chunks share weights (and A rows) through that XCD's L2.
+    int wg = blockIdx.x;
+    {
+        const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = wg & 7, idx = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int t0 = __builtin_amdgcn_readfirstlane(args->wg_off[wg]);
+    const int t1 = __builtin_amdgcn_readfirstlane(args->wg_off[wg + 1]);
+    long long *dbg = nullptr;
+#ifdef R3D_TIMING
+    if (args->dbg && wg < 4) dbg = args->dbg + wg * 256;
+    if (args->dbg && threadIdx.x == 0) {
+        args->dbg[1024 + wg * 4 + 0] = __builtin_readcyclecounter();
+        args->dbg[1024 + wg * 4 + 2] = wall_clock64();
+    }
+#endif
+    for (int t = t0; t < t1; ++t) {
+        const int4 td = args->tiles[t];
+        const int pi = __builtin_amdgcn_readfirstlane(td.x & 0xff);
+        const int mi = __builtin_amdgcn_readfirstlane(td.x >> 8);
+        const int row0 = __builtin_amdgcn_readfirstlane(td.y);
+        const int col0 = __builtin_amdgcn_readfirstlane(td.z);
+        ProbRef P = args->p[pi];
+        switch (mi) {
+            case 1: gemm_tile<1>(P, row0, col0, smem, dbg); break;
+            case 2: gemm_tile<2>(P, row0, col0, smem, dbg); break;
+            case 3: gemm_tile<3>(P, row0, col0, smem, dbg); break;
+            case 4: gemm_tile<4>(P, row0, col0, smem, dbg); break;
+            case 5: gemm_tile<5>(P, row0, col0, smem, dbg); break;
+            case 6: gemm_tile<6>(P, row0, col0, smem, dbg); break;
+            case 7: gemm_tile<7>(P, row0, col0, smem, dbg); break;
+            default: gemm_tile<8>(P, row0, col0, smem, dbg); break;
+        }
+    }
+#ifdef R3D_TIMING
+    if (args->dbg && threadIdx.x == 0) {
+        args->dbg[1024 + wg * 4 + 1] = __builtin_readcyclecounter();
+        args->dbg[1024 + wg * 4 + 3] = wall_clock64();
+    }
+#endif
 }
 
-extern "C" __global__ __launch_bounds__(256) void r3d_gemm_f32_t64(const StageArgs args) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    (void)args;
-    gemm_body<64, 64>((StageArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), smem);
-}
-
-const char *gemm_kernel_name(int tile) { return tile == 128 ? "r3d_gemm_f32_t128" : "r3d_gemm_f32_t64"; }
-
-hipError_t launch_gemm_stage(const StageArgs &args, int tile, hipStream_t stream) {
-    constexpr int kLds128 = GemmCfg<128, 128>::LDS_BYTES, kLds64 = GemmCfg<64, 64>::LDS_BYTES;
+hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        // 72 KiB of dynamic LDS exceeds the 64 KiB default cap
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(r3d_gemm_f32_t128),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLds128);
+        // 144 KiB of dynamic LDS exceeds the 64 KiB default cap
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(r3d_gemm_f32),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    if (tile == 128)
-        r3d_gemm_f32_t128<<<dim3(args.total_tiles), dim3(256), kLds128, stream>>>(args);
-    else
-        r3d_gemm_f32_t64<<<dim3(args.total_tiles), dim3(256), kLds64, stream>>>(args);
+    r3d_gemm_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
     return hipGetLastError();
 }
 

@@ -1,0 +1,8 @@
+#!/bin/bash
+# builds /tmp-free in-tree probe binaries (they travel to the GPU box with the snapshot)
+set -e
+cd "$(dirname "$0")/.."
+F="-O3 -std=c++17 --offload-arch=gfx950 -Iinclude -Iray3d_amd/csrc -Wno-unused-result"
+S="tools/gemm_probe.cpp ray3d_amd/csrc/r3d_kernels.hip ray3d_amd/csrc/r3d_schedule.cpp ray3d_amd/csrc/r3d_model.cpp ray3d_amd/csrc/r3d_plan.cpp"
+/opt/rocm/bin/hipcc $F -x hip $S -o tools/gemm_probe.bin
+/opt/rocm/bin/hipcc $F -DR3D_TIMING -x hip $S -o tools/gemm_probe_timing.bin

@@ -1,0 +1,120 @@
+// Stand-alone probe of the persistent GEMM kernel (development tool, not part of the library):
+// runs one launch shaped like a DAG level of the RF-243 plan on synthetic data and prints its
+// duration, rate and (with -DR3D_TIMING) per-K-tile phase stamps of the first workgroups.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude -Iray3d_amd/csrc [-DR3D_TIMING] \
+//         tools/gemm_probe.cpp ray3d_amd/csrc/r3d_kernels.hip ray3d_amd/csrc/r3d_schedule.cpp \
+//         ray3d_amd/csrc/r3d_model.cpp -o /tmp/gemm_probe
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+#include "r3d_internal.hpp"
+
+using namespace r3d;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+int main(int argc, char **argv) {
+    // usage: gemm_probe nprob M N K [reps]
+    const int nprob = argc > 1 ? atoi(argv[1]) : 6;
+    const int M = argc > 2 ? atoi(argv[2]) : 6912;
+    const int N = argc > 3 ? atoi(argv[3]) : 256;
+    const int K = argc > 4 ? atoi(argv[4]) : 768;
+    const int reps = argc > 5 ? atoi(argv[5]) : 20;
+    const int Npad = round_up(N, 256);
+    std::vector<float> hA((size_t)M * K), hW((size_t)Npad * K, 0.f), hb(Npad, 0.f);
+    for (size_t i = 0; i < hA.size(); ++i) hA[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
+    for (size_t i = 0; i < (size_t)N * K; ++i) hW[i] = (float)((i * 40503u) % 2001) / 1000.f - 1.f;
+    LaunchArgs la;
+    memset(&la, 0, sizeof la);
+    la.nprob = nprob;
+    std::vector<float *> dA(nprob), dW(nprob), dC(nprob);
+    float *dbias;
+    CK(hipMalloc((void **)&dbias, Npad * 4));
+    CK(hipMemcpy(dbias, hb.data(), Npad * 4, hipMemcpyHostToDevice));
+    std::vector<SchedProb> sp;
+    for (int i = 0; i < nprob; ++i) {
+        CK(hipMalloc((void **)&dA[i], hA.size() * 4));
+        CK(hipMalloc((void **)&dW[i], hW.size() * 4));
+        CK(hipMalloc((void **)&dC[i], (size_t)M * N * 4));
+        CK(hipMemcpy(dA[i], hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dW[i], hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
+        GemmProb &g = la.p[i];
+        for (int s = 0; s < MAX_SEG; ++s) { g.a[s] = dA[i]; g.lda[s] = K; g.kend[s] = 0x7fffffff; }
+        g.w = dW[i]; g.bias = dbias; g.res = nullptr; g.c = dC[i]; g.ldr = 0; g.ldc = N;
+        g.M = M; g.N = N; g.K = K; g.slope = 0.2f;
+        sp.push_back({M, N, K / BK});
+    }
+    std::vector<int4> tiles;
+    std::vector<int> wgoff;
+    StageSchedule ss{};
+    const int nwg = device_cu_count();
+    schedule_stage(sp, nwg, tiles, wgoff, ss);
+    int4 *dt; int *dwg; long long *ddbg;
+    CK(hipMalloc((void **)&dt, tiles.size() * sizeof(int4)));
+    CK(hipMalloc((void **)&dwg, wgoff.size() * sizeof(int)));
+    CK(hipMalloc((void **)&ddbg, (1024 + 4 * 1024) * 8));
+    CK(hipMemset(ddbg, 0, (1024 + 4 * 1024) * 8));
+    CK(hipMemcpy(dt, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dwg, wgoff.data(), wgoff.size() * sizeof(int), hipMemcpyHostToDevice));
+    la.tiles = dt; la.wg_off = dwg; la.dbg = ddbg;
+    printf("grid %d tiles %d imbalance %.3f (CUs %d)\n", ss.nwg, ss.ntiles, ss.imbalance, nwg);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) CK(launch_gemm_stage(la, ss.nwg, 0));
+    CK(hipDeviceSynchronize());
+    float best = 1e9, sum = 0;
+    for (int i = 0; i < reps; ++i) {
+        CK(hipEventRecord(e0, 0));
+        CK(launch_gemm_stage(la, ss.nwg, 0));
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best; sum += ms;
+    }
+    const double flops = 2.0 * nprob * (double)M * N * K;
+    printf("nprob %d M %d N %d K %d: best %.1f us avg %.1f us -> %.1f TFLOP/s (best)\n", nprob, M, N, K, best * 1e3,
+           sum / reps * 1e3, flops / (best * 1e-3) / 1e12);
+    // correctness spot check of problem 0, a few entries
+    std::vector<float> hC((size_t)M * N);
+    CK(hipMemcpy(hC.data(), dC[0], hC.size() * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0;
+    for (int t = 0; t < 64; ++t) {
+        const int r = (t * 7919) % M, c = (t * 104729) % N;
+        double acc = 0;
+        for (int k = 0; k < K; ++k) acc += (double)hA[(size_t)r * K + k] * hW[(size_t)c * K + k];
+        acc = acc > 0 ? acc : 0.2 * acc;
+        const double err = fabs(acc - hC[(size_t)r * N + c]) / (1.0 + fabs(acc));
+        maxerr = err > maxerr ? err : maxerr;
+    }
+    printf("spot-check max rel err %.2e\n", maxerr);
+#ifdef R3D_TIMING
+    {
+        std::vector<long long> hw(4 * 1024);
+        CK(hipMemcpy(hw.data(), ddbg + 1024, hw.size() * 8, hipMemcpyDeviceToHost));
+        long long w0 = 1LL << 62, w1 = 0;
+        for (int w = 0; w < ss.nwg; ++w) { w0 = std::min(w0, hw[w * 4 + 2]); w1 = std::max(w1, hw[w * 4 + 3]); }
+        printf("wall span %lld ticks (100 MHz => %.1f us)\n", w1 - w0, (w1 - w0) / 100.0);
+        printf("chunk: tiles units | start_us end_us | cycles | eff GHz\n");
+        for (int w = 0; w < ss.nwg; w += (w < 8 || w > ss.nwg - 9) ? 1 : 13) {
+            int units = 0;
+            for (int t = wgoff[w]; t < wgoff[w + 1]; ++t) units += tiles[t].x >> 8;
+            const double us0 = (hw[w * 4 + 2] - w0) / 100.0, us1 = (hw[w * 4 + 3] - w0) / 100.0;
+            printf("  %3d: %d %2d | %7.1f %7.1f | %7lld | %.2f\n", w, wgoff[w + 1] - wgoff[w], units, us0, us1,
+                   hw[w * 4 + 1] - hw[w * 4 + 0], (hw[w * 4 + 1] - hw[w * 4 + 0]) / (us1 - us0) / 1e3);
+        }
+    }
+    std::vector<long long> hd(4 * 256);
+    CK(hipMemcpy(hd.data(), ddbg, hd.size() * 8, hipMemcpyDeviceToHost));
+    for (int w = 0; w < 2; ++w) {
+        printf("chunk %d (last tile): per K tile cycles  [loads-issue | reads+mfma | lds-write | barrier | total]\n", w);
+        const long long *d = hd.data() + w * 256;
+        for (int kt = 0; kt < 24 && kt < K / BK; ++kt)
+            printf("  kt %2d: %6lld %6lld %6lld %6lld | %6lld\n", kt, d[kt * 8 + 1] - d[kt * 8 + 0], d[kt * 8 + 2] - d[kt * 8 + 1],
+                   d[kt * 8 + 3] - d[kt * 8 + 2], d[kt * 8 + 4] - d[kt * 8 + 3], (kt ? d[kt * 8] - d[(kt - 1) * 8] : 0));
+    }
+#endif
+    return 0;
+}
