@@ -1,4 +1,5 @@
 // extern "C" entry points of libray3d_hip.so (contract: include/ray3d_hip.h).
+#include <algorithm>
 #include <cstring>
 
 #include "r3d_internal.hpp"
@@ -7,11 +8,12 @@ namespace r3d {
 const char *last_error();
 
 // output joint slot -> (body part, index inside the part), lib/model/rie.py:426-431 (quirk Q2:
-// for J = 14 / 15 this is not the inverse of the input grouping).
-static void output_sources(int J, int *src) {
+// for J = 14 / 15 this is not the inverse of the input grouping).  Fills slot[] such that the
+// o-th output of part g (flat index first[g] + o) lands in element slot[first[g] + o] of (J,3).
+static void output_slots(int J, const int *first, int *slot) {
     int s = 0;
     auto put = [&](int part, int idx) {
-        for (int f = 0; f < 3; ++f) src[s * 3 + f] = part * DEC_SLOT + idx * 3 + f;
+        for (int f = 0; f < 3; ++f) slot[first[part] + idx * 3 + f] = s * 3 + f;
         ++s;
     };
     enum { T = 0, LA = 1, RA = 2, LL = 3, RL = 4 };
@@ -42,6 +44,13 @@ static void output_sources(int J, int *src) {
 static bool same_input_shape(const Model *a, const Model *b) {
     return a->cfg.num_joints == b->cfg.num_joints && a->cfg.in_features == b->cfg.in_features &&
            a->cfg.num_levels == b->cfg.num_levels && a->cfg.extrinsic_dim == b->cfg.extrinsic_dim;
+}
+
+static size_t workspace_need(const Plan *pl, int64_t B, int64_t window_stride, int RF, int J) {
+    // activations + (UV mode) rays of every touched frame; sized for the worst case window_stride == RF
+    const size_t act = (size_t)pl->floats_per_window * (size_t)B;
+    const size_t frames = (size_t)((B - 1) * std::min<int64_t>(window_stride, RF) + RF);
+    return (act + frames * J * 3 + 64) * sizeof(float);
 }
 
 struct Recorder {
@@ -92,10 +101,14 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
     const bool needs_param = a->cfg.embed_dim > 0 || (b && b->cfg.embed_dim > 0);
     if (needs_param && !in->param_dev) { set_error("param_dev is required when the camera embedding is on"); return R3D_ERR_ARG; }
     if (in->window_stride <= 0) { set_error("window_stride must be positive"); return R3D_ERR_ARG; }
-    if (B * (int64_t)(a->RF / 3) * 512 > 0x7fffffffLL * 4) { set_error("B too large for one call"); return R3D_ERR_ARG; }
+    if (B * (int64_t)(a->RF / 3) >= 0x7fffffffLL) { set_error("B too large for one call"); return R3D_ERR_ARG; }
 
     Plan *pl = plan_get(a, b);
-    const size_t need = (size_t)pl->floats_per_window * (size_t)B * sizeof(float);
+    // UV mode keeps the encoded rays of every touched frame at the end of the workspace
+    const long long frames = (B - 1) * in->window_stride + a->RF;
+    const size_t act_floats = (size_t)pl->floats_per_window * (size_t)B;
+    const size_t need = workspace_need(pl, B, in->window_stride, a->RF, a->cfg.num_joints);
+    if (in->mode == R3D_INPUT_UV && in->window_stride > a->RF) { set_error("R3D_INPUT_UV needs window_stride <= RF"); return R3D_ERR_ARG; }
     if (!ws || ws_bytes < need) {
         set_error("workspace too small: need %zu bytes, got %zu", need, ws_bytes);
         return R3D_ERR_WORKSPACE;
@@ -107,46 +120,40 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
     hipError_t e;
     int stage_no = 0;
 
-    // ---- prologue
-    EncodeArgs ea;
-    memset(&ea, 0, sizeof ea);
-    ea.x = in->x_dev;
-    ea.cam = in->cam_dev;
-    ea.param = in->param_dev;
-    ea.window_stride = in->window_stride;
-    ea.param_stride = in->param_stride;
-    ea.cam_stride = in->cam_stride;
-    ea.mode = in->mode;
-    ea.J = a->cfg.num_joints;
-    ea.F = a->cfg.in_features;
-    ea.RF = a->RF;
-    ea.tcur = a->RF / a->cfg.in_features;   // quirk Q1: "current" frame is RF // in_features
-    ea.B = B;
-    ea.nbranch = (int)pl->enc.size();
-    double enc_bytes = (double)B * a->RF * ea.J * (in->mode == R3D_INPUT_UV ? 2 : ea.F) * 4.0;
-    for (int i = 0; i < ea.nbranch; ++i) {
-        const Model *m = pl->m[pl->enc[i].model];
-        const Model::Branch &br = m->branches[pl->enc[i].branch];
-        ea.br[i].a0 = buf_ptr(pl->enc[i].buf);
-        ea.br[i].lut = m->d_iarena + br.lut_off;
-        ea.br[i].k0pad = br.k0pad;
-        enc_bytes += (double)B * (a->RF / 3) * br.k0pad * 4.0;
+    // ---- pointwise prologue: uv -> rays (UV mode), camera embeddings
+    const float *x_rays = in->x_dev;
+    PrologueArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.B = B;
+    pa.J = a->cfg.num_joints;
+    pa.RF = a->RF;
+    pa.window_stride = in->window_stride;
+    if (in->mode == R3D_INPUT_UV) {
+        pa.uv = in->x_dev;
+        pa.cam = in->cam_dev;
+        pa.cam_stride = in->cam_stride;
+        pa.rays = wsf + act_floats;
+        pa.frames = frames;
+        x_rays = pa.rays;
     }
-    ea.cur = buf_ptr(pl->cur_buf);
-    ea.E = a->cfg.extrinsic_dim;
+    pa.param = in->param_dev;
+    pa.param_stride = in->param_stride;
+    pa.E = a->cfg.extrinsic_dim;
     for (int mi = 0; mi < 2; ++mi) {
         const Model *m = pl->m[mi];
         if (!m || m->cfg.embed_dim <= 0) continue;
-        ea.emb_w[ea.nembed] = m->d_arena + m->embed_off;
-        ea.emb_out[ea.nembed] = buf_ptr(pl->emb_buf[mi]);
-        ea.emb_dim[ea.nembed] = m->cfg.embed_dim;
-        ++ea.nembed;
+        pa.emb_w[pa.nembed] = m->d_arena + m->embed_off;
+        pa.emb_out[pa.nembed] = buf_ptr(pl->emb_buf[mi]);
+        pa.emb_dim[pa.nembed] = m->cfg.embed_dim;
+        ++pa.nembed;
     }
-    int blocks = 0;
-    if ((e = rec.begin("r3d_encode_f32", stage_no, 0, 0.0, enc_bytes)) != hipSuccess) return hip_fail(e, "hipEventRecord");
-    if ((e = launch_encode(ea, stream, &blocks)) != hipSuccess) return hip_fail(e, "launch r3d_encode_f32");
-    if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
-    ++stage_no;
+    if (pa.uv || pa.nembed) {
+        if ((e = rec.begin("r3d_prologue_f32", stage_no, 0, 0.0, (double)frames * pa.J * (pa.uv ? 20.0 : 0.0))) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        if ((e = launch_prologue(pa, stream)) != hipSuccess) return hip_fail(e, "launch r3d_prologue_f32");
+        if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        ++stage_no;
+    }
+    const int JF = a->cfg.num_joints * a->cfg.in_features;
 
     // ---- persistent GEMM launches, one per DAG level
     Schedule *sched = schedule_get(pl, B, device_cu_count());
@@ -159,6 +166,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         la.tiles = sched->d_tiles + ss.tiles_off;
         la.wg_off = sched->d_wgoff + ss.wgoff_off;
         la.nprob = (int)st.size();
+        int n_enc = 0;
         for (int i = 0; i < la.nprob; ++i) {
             const ProbSpec &q = pl->probs[st[i]];
             const Model *m = pl->m[q.model];
@@ -176,7 +184,16 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
                 }
                 g.kend[s] = s < q.nseg ? kend : 0x7fffffff;
             }
-            g.kend[q.nseg - 1] = 0x7fffffff;   // the last real segment absorbs the rest
+            if (q.nseg > 0) g.kend[q.nseg - 1] = 0x7fffffff;   // the last real segment absorbs the rest
+            if (q.enc_lut >= 0) {
+                ++n_enc;
+                g.lut = m->d_iarena + q.enc_lut;
+                g.x = x_rays;
+                g.enc_ws = in->window_stride * JF;
+                g.enc_rows = q.enc_rows;
+                g.enc_jf = JF;
+                g.enc_cur = (a->RF / a->cfg.in_features) * JF;   // quirk Q1: "current" frame is RF // in_features
+            }
             g.w = m->d_arena + L.w_off;
             g.bias = m->d_arena + L.b_off;
             g.res = q.res_buf >= 0 ? buf_ptr(q.res_buf) + q.res_col : nullptr;
@@ -188,37 +205,46 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             g.K = L.Kpad;
             g.slope = L.slope;
         }
-        if ((e = rec.begin("r3d_gemm_f32", stage_no, ss.nwg, ss.flops, ss.bytes)) != hipSuccess) return hip_fail(e, "hipEventRecord");
-        if ((e = launch_gemm_stage(la, ss.nwg, stream)) != hipSuccess) return hip_fail(e, "launch r3d_gemm_f32");
+        if (n_enc != 0 && n_enc != la.nprob) { set_error("internal: launch mixes encoded and plain operands"); return R3D_ERR_STATE; }
+        if ((e = rec.begin(n_enc ? "r3d_gemm_enc_f32" : "r3d_gemm_f32", stage_no, ss.nwg, ss.flops, ss.bytes)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        if ((e = launch_gemm_stage(la, ss.nwg, n_enc != 0, stream)) != hipSuccess) return hip_fail(e, "launch r3d_gemm_f32");
         if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
         ++stage_no;
     }
 
-    // ---- epilogue
-    AssembleArgs aa;
-    memset(&aa, 0, sizeof aa);
-    aa.B = B;
-    aa.J = a->cfg.num_joints;
-    aa.ldt = 4;
-    if (pl->pos_model >= 0) {
-        aa.dec = buf_ptr(pl->dec_buf);
-        aa.trj = pl->trj_model >= 0 ? buf_ptr(pl->trj_buf) : nullptr;
-        aa.out = out;
-        output_sources(aa.J, aa.src);
-        if ((e = rec.begin("r3d_assemble_f32", stage_no, 0, 0.0, (double)B * aa.J * 3 * 8.0)) != hipSuccess) return hip_fail(e, "hipEventRecord");
-        if ((e = launch_assemble(aa, stream, &blocks)) != hipSuccess) return hip_fail(e, "launch r3d_assemble_f32");
-        if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
-        ++stage_no;
+    // ---- fused decoder tail
+    DecodeArgs da;
+    memset(&da, 0, sizeof da);
+    da.B = B;
+    da.J = a->cfg.num_joints;
+    da.has_pos = pl->pos_model >= 0;
+    da.has_trj = pl->trj_model >= 0;
+    da.out = out;
+    da.out_trj = da.has_pos ? out_trj : nullptr;
+    double dec_flops = 0;
+    int first = 0;
+    // plan.decs lists the pos parts (Torso, LArm, RArm, LLeg, RLeg) then the trajectory decoder
+    std::vector<Plan::Dec> order;
+    for (const auto &d : pl->decs) if (pl->m[d.model]->cfg.kind == R3D_KIND_POS) order.push_back(d);
+    for (const auto &d : pl->decs) if (pl->m[d.model]->cfg.kind == R3D_KIND_TRJ) order.push_back(d);
+    int firsts[MAX_DEC] = {0};
+    for (const auto &d : order) {
+        const Model *m = pl->m[d.model];
+        const Layer &L = m->layers[d.layer];
+        const int sidx = da.nsrc++;
+        da.h[sidx] = buf_ptr(d.hbuf);
+        da.w[sidx] = m->d_arena + L.w_off;
+        da.bias[sidx] = m->d_arena + L.b_off;
+        da.n_out[sidx] = L.N;
+        da.first[sidx] = first;
+        firsts[sidx] = first;
+        if (m->cfg.kind == R3D_KIND_POS) first += L.N;
+        dec_flops += 2.0 * (double)B * L.K * L.N;
     }
-    float *trj_dst = pl->pos_model >= 0 ? out_trj : out;
-    if (pl->trj_model >= 0 && trj_dst) {
-        aa.dec = nullptr;
-        aa.trj = buf_ptr(pl->trj_buf);
-        aa.out = trj_dst;
-        if ((e = rec.begin("r3d_assemble_f32", stage_no, 0, 0.0, (double)B * 3 * 8.0)) != hipSuccess) return hip_fail(e, "hipEventRecord");
-        if ((e = launch_assemble(aa, stream, &blocks)) != hipSuccess) return hip_fail(e, "launch r3d_assemble_f32");
-        if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
-    }
+    if (da.has_pos) output_slots(da.J, firsts, da.slot);
+    if ((e = rec.begin("r3d_decode_f32", stage_no, 0, dec_flops, (double)B * da.nsrc * MLP_HIDDEN * 4.0)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+    if ((e = launch_decode(da, stream)) != hipSuccess) return hip_fail(e, "launch r3d_decode_f32");
+    if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
     if (rec.on()) a->nrec = (int)rec.n;
     return R3D_OK;
 }
@@ -271,7 +297,7 @@ size_t r3d_workspace_bytes(const r3d_model *pos, const r3d_model *trj, int64_t B
     Model *t = const_cast<Model *>(reinterpret_cast<const Model *>(trj));
     Model *a = p ? p : t, *b = p ? t : nullptr;
     if (!a || B <= 0) return 0;
-    return (size_t)plan_get(a, b)->floats_per_window * (size_t)B * sizeof(float);
+    return workspace_need(plan_get(a, b), B, a->RF, a->RF, a->cfg.num_joints);
 }
 
 int r3d_forward(r3d_model *m, const r3d_input *in, int64_t B, float *out_dev, void *ws, size_t ws_bytes, void *stream) {

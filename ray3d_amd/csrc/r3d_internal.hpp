@@ -19,8 +19,6 @@ constexpr int N_ALIGN = 256;  // packed weight rows are padded to the GEMM colum
 constexpr int MLP_HIDDEN = 1024;
 constexpr int EMBED_MID = 32;
 constexpr int CUR_LD = 64;    // padded row length of the "current frame" matrix (J*F <= 51)
-constexpr int DEC_SLOT = 16;  // column slot per body part in the decoder output matrix
-constexpr int MAX_BRANCH = 6; // 5 body parts (pos) + 1 (trj) encoded by one prologue launch
 
 // ------------------------------------------------------------------ device-visible PODs
 
@@ -35,6 +33,16 @@ struct GemmProb {
     int ldr, ldc;
     int M, N, K;
     float slope;              // LeakyReLU slope, 1.0f = linear layer
+    // --- fused feature-encoding prologue (first layers only; lut == nullptr otherwise) ---
+    // A[row][col] is computed on the fly from the raw input instead of being read from memory:
+    // row = window * enc_rows + t3 covers input frames 3*t3 .. 3*t3+2 of that window.
+    const int *lut;           // K entries, see encode_lut_entry()
+    const float *x;           // (frames, J*F) ray-encoded keypoints
+    long long enc_ws;         // window stride in elements (frames * J*F)
+    int enc_rows;             // GEMM rows per window (RF/3 for a temporal branch, 1 for GlobalInfo)
+    int enc_jf;               // J*F
+    int enc_cur;              // element offset of the "current" frame inside a window (tcur * J*F)
+    int pad_;
 };
 
 // Kernel argument of one persistent GEMM launch.  `tiles`/`wg_off` live in HBM (built once per
@@ -48,37 +56,40 @@ struct LaunchArgs {
     GemmProb p[MAX_PROB];
 };
 
-struct EncodeBranch {
-    float *a0;          // (B * RF/3, k0pad)
-    const int *lut;     // k0pad entries, see encode_lut_entry()
-    int k0pad;
-    int pad_;
-};
-
-struct EncodeArgs {
-    const float *x;            // rays or uv
-    const double *cam;
-    const float *param;
-    long long window_stride;   // in frames
-    long long param_stride, cam_stride;
-    int mode, J, F, RF, tcur, nbranch;
+// Pointwise prologue: optional uv -> ray encoding and the camera-embedding MLPs.
+struct PrologueArgs {
+    const float *uv;           // UV mode: (frames, J, 2) pixel keypoints, else nullptr
+    const double *cam;         // rows {fx, fy, cx, cy, cos p, sin p, 0, 0}
+    float *rays;               // UV mode: (frames, J, 3) output
+    long long frames;          // number of input frames touched
+    long long window_stride;   // frames between windows (to find a frame's camera row)
+    long long cam_stride;
     long long B;
-    EncodeBranch br[MAX_BRANCH];
-    float *cur;                // (B, CUR_LD) current-frame matrix, zero padded
-    // camera embedding MLPs (BN folded) of up to two models
+    int J, RF;
+    const float *param;
+    long long param_stride;
     int nembed, E;
-    const float *emb_w[2];     // packed [w1 (32,E) | b1 (32) | w2 (D,32) | b2 (D)]
+    const float *emb_w[2];     // packed [w1 (32,E) | b1 (32) | w2 (D,32) | b2 (D)], BN folded
     float *emb_out[2];         // (B, D)
     int emb_dim[2];
 };
 
-struct AssembleArgs {
-    const float *dec;   // (B, 5*DEC_SLOT) decoder outputs, part g at column g*DEC_SLOT
-    const float *trj;   // optional (B, ldt) root trajectory, broadcast over joints
-    float *out;         // (B, J, 3)
+constexpr int MAX_DEC = 6;     // 5 body-part decoders + the trajectory decoder
+// Fused decoder tail: the last Linear (1024 -> 3*n_g) of every Integration block, the joint
+// reassembly (rie.py:415-432) and the trajectory add (trainer.py:353) in one pass.
+struct DecodeArgs {
+    const float *h[MAX_DEC];   // (B, 1024) hidden activations
+    const float *w[MAX_DEC];   // packed rows [n_out][1024]
+    const float *bias[MAX_DEC];
+    int n_out[MAX_DEC];
+    int first[MAX_DEC];        // index of the source's first output in the flat output list
+    int nsrc;                  // sources; the trajectory source (if any) is the last one
+    int has_pos, has_trj;
+    int J;
     long long B;
-    int J, ldt;
-    int src[17 * 3];    // out[b, e] = dec[b, src[e]] (+ trj[b, e % 3])
+    float *out;                // pos: (B, J, 3);  trj-only: (B, 3)
+    float *out_trj;            // optional (B, 3)
+    int slot[5 * 16];          // flat pos output index -> element of (J,3) it lands in
 };
 
 // ------------------------------------------------------------------ host side
@@ -124,6 +135,7 @@ struct Model {
     };
     std::vector<Branch> branches;
     size_t embed_off = 0;             // packed embedding MLP in the float arena
+    size_t global_lut_off = 0;        // LUT of GlobalInfo.fc_1's input (the current frame)
     std::vector<float> arena;         // packed floats (host mirror)
     std::vector<int> iarena;          // LUTs
     float *d_arena = nullptr;
@@ -159,6 +171,8 @@ struct ProbSpec {
     struct Seg { int buf, col, ld, width; } seg[MAX_SEG];
     int res_buf, res_col, res_ld;
     int c_buf, c_col, c_ld;
+    int enc_lut;                 // >= 0: fused-encode problem, offset of its LUT in the model's int arena
+    int enc_rows;
     std::vector<int> deps;
     int depth;
     double flops_per_window;     // 2 * rows * K_true * N_true
@@ -188,14 +202,11 @@ struct Plan {
     std::vector<ProbSpec> probs;
     std::vector<std::vector<int>> stages;      // problem ids per launch
     int64_t floats_per_window = 0;
-    // prologue
-    struct Enc { int model, branch, buf; };
-    std::vector<Enc> enc;
-    int cur_buf = -1;
     int emb_buf[2] = {-1, -1};
-    // epilogue
-    int dec_buf = -1;            // pos decoder matrix (assemble input), -1 when no pos model
-    int trj_buf = -1;            // trj output matrix
+    int rays_buf = -1;           // UV mode scratch for the encoded rays (sized per call)
+    // fused decoder tail: (model, layer, hidden buffer) per Integration block
+    struct Dec { int model, layer, hbuf; };
+    std::vector<Dec> decs;
     int pos_model = -1, trj_model = -1;
     std::map<int64_t, Schedule *> schedules;   // by batch size (small LRU, see schedule_get)
     std::vector<int64_t> schedule_lru;
@@ -217,16 +228,22 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg);   // nullptr + set_error o
 int device_cu_count();
 
 // kernel launchers (r3d_kernels.hip)
-hipError_t launch_encode(const EncodeArgs &args, hipStream_t stream, int *blocks);
-hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, hipStream_t stream);
-hipError_t launch_assemble(const AssembleArgs &args, hipStream_t stream, int *blocks);
+hipError_t launch_prologue(const PrologueArgs &args, hipStream_t stream);
+hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, bool encode, hipStream_t stream);
+hipError_t launch_decode(const DecodeArgs &args, hipStream_t stream);
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-// LUT entry for the feature-encoding prologue: bits [1:0] tap, [3:2] kind (0 x, 1 x - root,
-// 2 x - current frame, 3 zero padding), [11:4] source element joint*F+f, [13:12] f.
-inline int encode_lut_entry(int tap, int kind, int src, int f) {
-    return (tap & 3) | ((kind & 3) << 2) | ((src & 255) << 4) | ((f & 3) << 12);
+// LUT entry of the fused feature-encoding prologue.  A[row][col] = x[base + off1] - x[base2 + off2]:
+//   bits [9:0]   off1: element offset of the minuend from the row's first frame (tap*J*F + joint*F + f)
+//   bits [19:10] off2: element offset of the subtrahend
+//   bits [21:20] kind: 0 = x (no subtrahend), 1 = x - root joint of the same frame (rie.py:301),
+//                      2 = x - same element of the window's "current" frame (rie.py:304; off2 is
+//                      relative to that frame), 3 = zero padding column
+//   bit  22      minuend is relative to the "current" frame instead of the row's first frame
+//                (GlobalInfo input, rie.py:290-292)
+inline int encode_lut_entry(int off1, int off2, int kind, int cur_rel) {
+    return (off1 & 1023) | ((off2 & 1023) << 10) | ((kind & 3) << 20) | ((cur_rel & 1) << 22);
 }
 
 }  // namespace r3d

@@ -2,16 +2,18 @@
 // the fp32-input matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD, 157 TFLOP/s
 // chip peak) - the path is compute-bound, 1e-4 parity rules out bf16.
 //
-//  r3d_encode_f32      prologue: ray encoding (uv -> [(u-cx)/fx, c*y+s, -s*y+c], float64 like the
-//                      reference's NumPy, lib/camera/camera.py:423-471), window gather from a batch
-//                      or from a sliding clip (lib/train_val/trainer.py:47-58), positional /
-//                      temporal differences and body-part grouping (lib/model/rie.py:290-357),
-//                      camera-embedding MLP (lib/model/embedding.py:15-18).
+//  r3d_prologue_f32    pointwise: ray encoding (uv -> [(u-cx)/fx, c*y+s, -s*y+c], float64 like the
+//                      reference's NumPy, lib/camera/camera.py:423-471) and the camera-embedding MLP
+//                      (lib/model/embedding.py:15-18).
+//  r3d_gemm_enc_f32    first layer of every temporal branch / GlobalInfo with the input encoding
+//                      fused into the operand staging: window gather from a batch or a sliding clip
+//                      (lib/train_val/trainer.py:47-58), positional / temporal differences and
+//                      body-part grouping (lib/model/rie.py:290-357).
 //  r3d_gemm_f32        persistent grouped GEMM + fused epilogue  C = res + lrelu(A W^T + b): every
 //                      Conv1d / Linear of TemporalBlock / FCBlock (rie.py:85-105, :122-135, :159-169)
 //                      with eval BatchNorm folded.
-//  r3d_assemble_f32    epilogue: joint reassembly (rie.py:415-432) + trajectory add
-//                      (lib/train_val/trainer.py:353).
+//  r3d_decode_f32      last Linear of the decoders + joint reassembly (rie.py:409-432) + trajectory
+//                      add (lib/train_val/trainer.py:353).
 #include <hip/hip_runtime.h>
 
 #include "r3d_internal.hpp"
@@ -49,7 +51,7 @@ constexpr int GEMM_LDS_BYTES = 2 * STAGE_FLOATS * 4; // 147456 B
 typedef const LaunchArgs __attribute__((address_space(4))) *LaunchArgsPtr;
 typedef const GemmProb __attribute__((address_space(4))) &ProbRef;
 
-template <int MI>
+template <int MI, bool ENC>
 __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int col0, float *smem, long long *dbg) {
     constexpr int NA = (MI + 1) / 2;        // A staging slots per thread (64 rows per slot)
     constexpr int NB = 4;                   // W staging slots per thread (256 rows)
@@ -63,13 +65,24 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
 
     int a_row[NA];
     bool a_on[NA];
+    // fused prologue (ENC): per staged row, where its first frame and its window's "current" frame
+    // start in the raw input (element offsets)
+    long long e_first[ENC ? NA : 1], e_cur[ENC ? NA : 1];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int r = srow + 64 * i;
         a_on[i] = (MI % 2 == 0) || (i < NA - 1) || (srow < 32);
         const int gr = row0 + r;
         a_row[i] = gr < M ? gr : M - 1;
+        if (ENC) {
+            const int win = a_row[i] / P.enc_rows, t3 = a_row[i] - win * P.enc_rows;
+            const long long wbase = (long long)win * P.enc_ws;
+            e_first[i] = wbase + (long long)t3 * 3 * P.enc_jf;
+            e_cur[i] = wbase + P.enc_cur;
+        }
     }
+    const float *ex = ENC ? P.x : nullptr;
+    const int *elut = ENC ? P.lut + a_kq : nullptr;
     const float *w_ptr = P.w + (size_t)(col0 + srow) * K + a_kq;
     const size_t w_step = (size_t)64 * K;
     const int st_off = srow * LDS_LD + a_kq;           // staging offset inside a 64-row slot
@@ -77,15 +90,35 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
     f32x4 ra[NA], rb[NB];
     auto load_global = [&](int kt) {
         const int kb = kt * BK;
-        // K segment of the (virtually concatenated) A operand this tile falls in (uniform -> scalar loads)
-        const int si = (kb >= ke0) + (kb >= ke1) + (kb >= ke2);
-        const float *base = P.a[si];
-        const int ld = P.lda[si];
-        const int k0 = si ? P.kend[si - 1] : 0;
-        const int kofs = kb - k0 + a_kq;
+        if (ENC) {
+            // A[row][k] = x[first/cur + off1] - x[first/cur + off2]: ray differences and body-part
+            // gather (lib/model/rie.py:290-357) evaluated while staging; nothing is materialised
+            const int4 code = *reinterpret_cast<const int4 *>(elut + kb);
+            const int cd[4] = {code.x, code.y, code.z, code.w};
 #pragma unroll
-        for (int i = 0; i < NA; ++i)
-            if (a_on[i]) ra[i] = *reinterpret_cast<const f32x4 *>(base + (size_t)a_row[i] * ld + kofs);
+            for (int i = 0; i < NA; ++i) {
+                if (!a_on[i]) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = cd[e], kind = (c >> 20) & 3;
+                    const long long b1 = (c >> 22) & 1 ? e_cur[i] : e_first[i];
+                    const long long b2 = kind == 2 ? e_cur[i] : e_first[i];
+                    const float v1 = ex[b1 + (c & 1023)];
+                    const float v2 = ex[b2 + ((c >> 10) & 1023)];
+                    ra[i][e] = kind == 3 ? 0.0f : (kind == 0 ? v1 : v1 - v2);
+                }
+            }
+        } else {
+            // K segment of the (virtually concatenated) A operand this tile falls in (uniform -> scalar loads)
+            const int si = (kb >= ke0) + (kb >= ke1) + (kb >= ke2);
+            const float *base = P.a[si];
+            const int ld = P.lda[si];
+            const int k0 = si ? P.kend[si - 1] : 0;
+            const int kofs = kb - k0 + a_kq;
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                if (a_on[i]) ra[i] = *reinterpret_cast<const f32x4 *>(base + (size_t)a_row[i] * ld + kofs);
+        }
 #pragma unroll
         for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(w_ptr + i * w_step + kb);
     };
@@ -184,9 +217,8 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
     }
 }
 
-extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_f32(const LaunchArgs args_) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    (void)args_;
+template <bool ENC>
+__device__ __forceinline__ void gemm_persistent(float *smem) {
     LaunchArgsPtr args = (LaunchArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     // XCD-aware chunk order: workgroup b runs on XCD b % 8 (observed; speed only), so give each XCD a
     // contiguous run of chunks - neighbouring chunks share weights (and A rows) through that XCD's L2.
@@ -213,14 +245,14 @@ extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_f32(const La
         const int col0 = __builtin_amdgcn_readfirstlane(td.z);
         ProbRef P = args->p[pi];
         switch (mi) {
-            case 1: gemm_tile<1>(P, row0, col0, smem, dbg); break;
-            case 2: gemm_tile<2>(P, row0, col0, smem, dbg); break;
-            case 3: gemm_tile<3>(P, row0, col0, smem, dbg); break;
-            case 4: gemm_tile<4>(P, row0, col0, smem, dbg); break;
-            case 5: gemm_tile<5>(P, row0, col0, smem, dbg); break;
-            case 6: gemm_tile<6>(P, row0, col0, smem, dbg); break;
-            case 7: gemm_tile<7>(P, row0, col0, smem, dbg); break;
-            default: gemm_tile<8>(P, row0, col0, smem, dbg); break;
+            case 1: gemm_tile<1, ENC>(P, row0, col0, smem, dbg); break;
+            case 2: gemm_tile<2, ENC>(P, row0, col0, smem, dbg); break;
+            case 3: gemm_tile<3, ENC>(P, row0, col0, smem, dbg); break;
+            case 4: gemm_tile<4, ENC>(P, row0, col0, smem, dbg); break;
+            case 5: gemm_tile<5, ENC>(P, row0, col0, smem, dbg); break;
+            case 6: gemm_tile<6, ENC>(P, row0, col0, smem, dbg); break;
+            case 7: gemm_tile<7, ENC>(P, row0, col0, smem, dbg); break;
+            default: gemm_tile<8, ENC>(P, row0, col0, smem, dbg); break;
         }
     }
 #ifdef R3D_TIMING
@@ -231,131 +263,138 @@ extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_f32(const La
 #endif
 }
 
-hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, hipStream_t stream) {
+// every layer whose input is an activation matrix in HBM
+extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_f32(const LaunchArgs args_) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    (void)args_;
+    gemm_persistent<false>(smem);
+}
+
+// first layers (expand_conv of every temporal branch, GlobalInfo.fc_1): input encoding fused in
+extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_enc_f32(const LaunchArgs args_) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    (void)args_;
+    gemm_persistent<true>(smem);
+}
+
+hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, bool encode, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
         // 144 KiB of dynamic LDS exceeds the 64 KiB default cap
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(r3d_gemm_f32),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(r3d_gemm_enc_f32),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        if (e != hipSuccess) return e;
         attr_done = true;
     }
-    r3d_gemm_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
+    if (encode)
+        r3d_gemm_enc_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
+    else
+        r3d_gemm_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------ prologue
 
-// One input feature of window b, frame t: element `src` = joint*F + f of the (J,F) frame.
-template <int MODE>
-__device__ __forceinline__ float fetch_feature(const EncodeArgs &a, long long b, int t, int src, int f) {
-    const long long frame = b * a.window_stride + t;
-    if (MODE == R3D_INPUT_RAYS) {
-        return a.x[frame * (a.J * a.F) + src];
-    } else {
-        // lib/camera/camera.py:438-439 then pt_cam @ Rc2n^T (:471) with Rc2n = Rx(pitch) (:333-338)
-        const int joint = src / 3;
-        const float *uv = a.x + (frame * a.J + joint) * 2;
-        const double *cam = a.cam + b * a.cam_stride;
-        if (f == 0) return (float)(((double)uv[0] - cam[2]) / cam[0]);
-        const double y = ((double)uv[1] - cam[3]) / cam[1];
-        return f == 1 ? (float)(cam[4] * y + cam[5]) : (float)(-cam[5] * y + cam[4]);
-    }
-}
-
-template <int MODE>
-__device__ __forceinline__ void encode_body(const EncodeArgs &a) {
-    const int by = blockIdx.y;
+// Pointwise front end.  (1) UV mode: pixel keypoints -> rays, float64 like the reference's NumPy
+// (lib/camera/camera.py:438-439 then pt_cam @ Rc2n^T, :471, Rc2n = Rx(pitch), :333-338):
+// ray = ((u-cx)/fx, c*y + s, -s*y + c) with y = (v-cy)/fy.  (2) camera-embedding MLP
+// (lib/model/embedding.py:15-18; LeakyReLU slope 0.01, BatchNorm folded) for each network.
+extern "C" __global__ __launch_bounds__(256) void r3d_prologue_f32(const PrologueArgs a) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int T3 = a.RF / 3;
-    if (by < a.nbranch) {
-        // first-layer GEMM operand of one temporal branch: row (b, t3) = frames 3*t3 .. 3*t3+2,
-        // column = tap*Cin + channel of cat(x_g, x_g - root, x_g - x_current)
-        const EncodeBranch br = a.br[by];
-        const int v4_per_row = br.k0pad >> 2;
-        const long long total = a.B * T3 * v4_per_row;
-        if (gid >= total) return;
-        const long long row = gid / v4_per_row;
-        const int c4 = (int)(gid - row * v4_per_row) * 4;
-        const long long b = row / T3;
-        const int t3 = (int)(row - b * T3);
-        f32x4 out;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int code = br.lut[c4 + e];
-            const int tap = code & 3, kind = (code >> 2) & 3, src = (code >> 4) & 255, f = (code >> 12) & 3;
-            float v = 0.0f;
-            if (kind != 3) {
-                const int t = 3 * t3 + tap;
-                v = fetch_feature<MODE>(a, b, t, src, f);
-                if (kind == 1) v -= fetch_feature<MODE>(a, b, t, f, f);              // root joint, rie.py:301
-                else if (kind == 2) v -= fetch_feature<MODE>(a, b, a.tcur, src, f);  // frame RF//F, rie.py:304
-            }
-            out[e] = v;
+    if (a.uv) {
+        const long long n = a.frames * a.J;
+        if (gid < n) {
+            const long long frame = gid / a.J;
+            // the camera of the (first) window this frame belongs to
+            long long win = a.window_stride >= a.RF ? frame / a.window_stride : frame - (a.RF - 1);
+            win = win < 0 ? 0 : (win >= a.B ? a.B - 1 : win);
+            const double *cam = a.cam + win * a.cam_stride;
+            const double u = a.uv[gid * 2], v = a.uv[gid * 2 + 1];
+            const double y = (v - cam[3]) / cam[1];
+            a.rays[gid * 3 + 0] = (float)((u - cam[2]) / cam[0]);
+            a.rays[gid * 3 + 1] = (float)(cam[4] * y + cam[5]);
+            a.rays[gid * 3 + 2] = (float)(-cam[5] * y + cam[4]);
         }
-        *reinterpret_cast<f32x4 *>(br.a0 + row * br.k0pad + c4) = out;
-        return;
     }
-    // last slice of the grid: current-frame matrix (rie.py:290-292) and camera embeddings
-    const long long total = a.B * CUR_LD;
-    if (gid >= total) return;
-    const long long b = gid / CUR_LD;
-    const int c = (int)(gid - b * CUR_LD);
-    const int JF = a.J * a.F;
-    a.cur[gid] = c < JF ? fetch_feature<MODE>(a, b, a.tcur, c, c % a.F) : 0.0f;
     for (int m = 0; m < a.nembed; ++m) {
         const int D = a.emb_dim[m], E = a.E;
+        if (gid >= a.B * D) continue;
+        const long long b = gid / D;
+        const int o = (int)(gid - b * D);
         const float *w1 = a.emb_w[m], *b1 = w1 + EMBED_MID * E, *w2 = b1 + EMBED_MID, *b2 = w2 + D * EMBED_MID;
         const float *p = a.param + b * a.param_stride;
-        for (int o = c; o < D; o += CUR_LD) {
-            float acc = b2[o];
-            for (int k = 0; k < EMBED_MID; ++k) {
-                float h = b1[k];
-                for (int e = 0; e < E; ++e) h += w1[k * E + e] * p[e];
-                h = h > 0.0f ? h : 0.01f * h;                 // nn.LeakyReLU() default slope
-                acc += w2[o * EMBED_MID + k] * h;
-            }
-            a.emb_out[m][b * D + o] = acc > 0.0f ? acc : 0.01f * acc;
+        float acc = b2[o];
+        for (int k = 0; k < EMBED_MID; ++k) {
+            float h = b1[k];
+            for (int e = 0; e < E; ++e) h += w1[k * E + e] * p[e];
+            h = h > 0.0f ? h : 0.01f * h;
+            acc += w2[o * EMBED_MID + k] * h;
         }
+        a.emb_out[m][gid] = acc > 0.0f ? acc : 0.01f * acc;
     }
 }
 
-extern "C" __global__ __launch_bounds__(256) void r3d_encode_f32(const EncodeArgs a) {
-    if (a.mode == R3D_INPUT_RAYS) encode_body<R3D_INPUT_RAYS>(a);
-    else encode_body<R3D_INPUT_UV>(a);
-}
-
-hipError_t launch_encode(const EncodeArgs &args, hipStream_t stream, int *blocks) {
-    long long most = args.B * CUR_LD;
-    for (int i = 0; i < args.nbranch; ++i) {
-        const long long t = args.B * (args.RF / 3) * (args.br[i].k0pad >> 2);
-        if (t > most) most = t;
-    }
-    const unsigned gx = (unsigned)((most + 255) / 256);
-    if (blocks) *blocks = (int)(gx * (args.nbranch + 1));
-    hipLaunchKernelGGL(r3d_encode_f32, dim3(gx, args.nbranch + 1), dim3(256), 0, stream, args);
+hipError_t launch_prologue(const PrologueArgs &args, hipStream_t stream) {
+    long long most = args.uv ? args.frames * args.J : 0;
+    for (int m = 0; m < args.nembed; ++m) most = most > args.B * args.emb_dim[m] ? most : args.B * args.emb_dim[m];
+    if (most == 0) return hipSuccess;
+    r3d_prologue_f32<<<dim3((unsigned)((most + 255) / 256)), dim3(256), 0, stream>>>(args);
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------ epilogue
+// ------------------------------------------------------------------------------------ decoder tail
 
-extern "C" __global__ __launch_bounds__(256) void r3d_assemble_f32(const AssembleArgs a) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int per = a.dec ? a.J * 3 : 3;
-    if (gid >= a.B * per) return;
-    const long long b = gid / per;
-    const int e = (int)(gid - b * per);
-    float v = 0.0f;
-    if (a.dec) v = a.dec[b * (5 * DEC_SLOT) + a.src[e]];
-    if (a.trj) v += a.trj[b * a.ldt + e % 3];
-    a.out[gid] = v;
+// One wavefront per window: the final Linear(1024 -> 3 n_g) of each Integration block
+// (lib/model/rie.py:409-413, :557) as 64-lane dot products, written straight into the joint slot
+// the reference's reassembly puts it (rie.py:415-432), plus the trajectory broadcast add
+// (lib/train_val/trainer.py:353).  These layers are 0.05 % of the FLOPs; as GEMMs their N = 3..15
+// would waste a 256-column tile.
+extern "C" __global__ __launch_bounds__(256) void r3d_decode_f32(const DecodeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    float trj0 = 0.0f, trj1 = 0.0f, trj2 = 0.0f;   // scalars: a runtime-indexed array would live in scratch
+    // trajectory source first so that its result can be added to every joint
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int s = 0; s < a.nsrc; ++s) {
+            const bool is_trj = a.has_trj && s == a.nsrc - 1;
+            if ((pass == 0) != is_trj) continue;
+            const float *h = a.h[s] + b * MLP_HIDDEN;
+            f32x4 hv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hv[j] = *reinterpret_cast<const f32x4 *>(h + j * 256 + lane * 4);
+            for (int o = 0; o < a.n_out[s]; ++o) {
+                const float *w = a.w[s] + (size_t)o * MLP_HIDDEN;
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + j * 256 + lane * 4);
+                    acc += hv[j][0] * wv[0] + hv[j][1] * wv[1] + hv[j][2] * wv[2] + hv[j][3] * wv[3];
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+                acc += a.bias[s][o];
+                if (is_trj) {
+                    if (o == 0) trj0 = acc; else if (o == 1) trj1 = acc; else trj2 = acc;
+                    if (lane == 0) {
+                        if (a.out_trj) a.out_trj[b * 3 + o] = acc;
+                        if (!a.has_pos) a.out[b * 3 + o] = acc;
+                    }
+                } else if (lane == 0) {
+                    const int e = a.slot[a.first[s] + o];
+                    const int c3 = e % 3;
+                    a.out[b * (a.J * 3) + e] = acc + (c3 == 0 ? trj0 : c3 == 1 ? trj1 : trj2);
+                }
+            }
+        }
+    }
 }
 
-hipError_t launch_assemble(const AssembleArgs &args, hipStream_t stream, int *blocks) {
-    const long long total = args.B * (args.dec ? args.J * 3 : 3);
-    const unsigned gx = (unsigned)((total + 255) / 256);
-    if (blocks) *blocks = (int)gx;
-    hipLaunchKernelGGL(r3d_assemble_f32, dim3(gx), dim3(256), 0, stream, args);
+hipError_t launch_decode(const DecodeArgs &args, hipStream_t stream) {
+    r3d_decode_f32<<<dim3((unsigned)((args.B + 3) / 4)), dim3(256), 0, stream>>>(args);
     return hipGetLastError();
 }
 

@@ -185,6 +185,27 @@ Model *model_create(const r3d_config &cfg) {
     }
     // GlobalInfo.fc_1 reads the zero-padded current-frame matrix
     m->layers[m->layer_index["GlobalInfo.fc_1"]].Kpad = CUR_LD;
+    // ---- fused-prologue LUTs: column of a first-layer GEMM -> where its value comes from in the
+    // raw input.  Channel order inside a branch: cat(x_g, diff_g, diff_t_g), lib/model/rie.py:308-315, :540
+    m->iarena.clear();
+    const int JF = J * F;
+    for (auto &br : m->branches) {
+        br.lut_off = m->iarena.size();
+        const int n = (int)br.joints.size();
+        for (int col = 0; col < br.k0pad; ++col) {
+            if (col >= br.k0) { m->iarena.push_back(encode_lut_entry(0, 0, 3, 0)); continue; }
+            const int tap = col / br.cin, c = col % br.cin;
+            const int kind = c / (n * F), jj = (c % (n * F)) / F, ff = c % F;
+            const int src = br.joints[jj] * F + ff;
+            const int off1 = tap * JF + src;
+            const int off2 = kind == 1 ? tap * JF + ff : kind == 2 ? src : 0;   // root joint is joint 0 (rie.py:301)
+            m->iarena.push_back(encode_lut_entry(off1, off2, kind, 0));
+        }
+    }
+    // GlobalInfo.fc_1 reads in_current = x[:, RF // F] flattened (rie.py:290-292), zero padded to CUR_LD
+    m->global_lut_off = m->iarena.size();
+    for (int col = 0; col < CUR_LD; ++col)
+        m->iarena.push_back(col < JF ? encode_lut_entry(col, 0, 0, 1) : encode_lut_entry(0, 0, 3, 0));
     m->host_weights.resize(m->specs.size());
     m->have.assign(m->specs.size(), false);
     return m;
@@ -298,20 +319,6 @@ int model_finalize(Model *m) {
         for (int o = 0; o < D; ++o) {
             for (int c = 0; c < EMBED_MID; ++c) e2[o * EMBED_MID + c] = (float)((double)w2[o * EMBED_MID + c] * s[o]);
             e2[(size_t)D * EMBED_MID + o] = (float)t[o];
-        }
-    }
-    // ---- prologue LUTs: column of the first-layer GEMM -> (tap, kind, source element)
-    // channel order inside a branch: cat(x_g, diff_g, diff_t_g), lib/model/rie.py:308-315, :540
-    m->iarena.clear();
-    const int F = m->cfg.in_features;
-    for (auto &br : m->branches) {
-        br.lut_off = m->iarena.size();
-        const int n = (int)br.joints.size();
-        for (int col = 0; col < br.k0pad; ++col) {
-            if (col >= br.k0) { m->iarena.push_back(encode_lut_entry(0, 3, 0, 0)); continue; }
-            const int tap = col / br.cin, c = col % br.cin;
-            const int kind = c / (n * F), jj = (c % (n * F)) / F, ff = c % F;
-            m->iarena.push_back(encode_lut_entry(tap, kind, br.joints[jj] * F + ff, ff));
         }
     }
     // ---- upload

@@ -33,13 +33,15 @@ struct Builder {
     }
     struct In { int buf, col, ld, width, dep; };
     int problem(const std::string &layer_prefix, int rows_pw, const std::vector<In> &ins, int res_buf, int res_col,
-                int res_ld, int c_buf, int c_col, int c_ld, std::vector<int> extra_deps = {}) {
+                int res_ld, int c_buf, int c_col, int c_ld, std::vector<int> extra_deps = {}, int enc_lut = -1) {
         ProbSpec q;
         q.model = mi;
         q.layer = m.layer_index.at(layer_prefix);
         q.rows_per_window = rows_pw;
         q.nseg = (int)ins.size();
-        int k = 0;
+        q.enc_lut = enc_lut;
+        q.enc_rows = rows_pw;
+        int k = enc_lut >= 0 ? m.layers[q.layer].Kpad : 0;
         for (int s = 0; s < q.nseg; ++s) {
             q.seg[s] = {ins[s].buf, ins[s].col, ins[s].ld, ins[s].width};
             k += ins[s].width;
@@ -62,15 +64,21 @@ struct Builder {
     }
 
     // FCBlock.forward (lib/model/rie.py:159-169): fc_1+bn+lrelu, n residual units, fc_2.
-    int fc_block(const std::string &prefix, const std::vector<In> &ins, int nblocks, int c_buf, int c_col, int c_ld) {
+    // c_buf < 0: the last Linear is left to the fused decoder kernel (recorded in plan.decs).
+    int fc_block(const std::string &prefix, const std::vector<In> &ins, int nblocks, int c_buf, int c_col, int c_ld,
+                 int enc_lut = -1) {
         const int H = MLP_HIDDEN;
         const int h = buffer(prefix + ".h", H), y = buffer(prefix + ".y", H);
-        int last = problem(prefix + ".fc_1", 1, ins, -1, 0, 0, h, 0, H);
+        int last = problem(prefix + ".fc_1", 1, ins, -1, 0, 0, h, 0, H, {}, enc_lut);
         for (int n = 0; n < nblocks; ++n) {
             const std::string q = prefix + ".layers." + std::to_string(n);
             const int p1 = problem(q + ".w1", 1, {{h, 0, H, H, last}}, -1, 0, 0, y, 0, H);
             // out = x + lrelu(bn(w2 y))  (rie.py:122-135): residual = h, written in place
             last = problem(q + ".w2", 1, {{y, 0, H, H, p1}}, h, 0, H, h, 0, H, {last});
+        }
+        if (c_buf < 0) {
+            p.decs.push_back({mi, m.layer_index.at(prefix + ".fc_2"), h});
+            return last;
         }
         return problem(prefix + ".fc_2", 1, {{h, 0, H, H, last}}, -1, 0, 0, c_buf, c_col, c_ld);
     }
@@ -80,12 +88,11 @@ struct Builder {
         const Model::Branch &br = m.branches[bi];
         const int C = m.cfg.channels, L = m.cfg.num_levels;
         int rows = m.RF / 3;
-        const int a0 = buffer(br.prefix + ".A0", (int64_t)rows * br.k0pad);
-        p.enc.push_back({mi, bi, a0});
         const int pp[2] = {buffer(br.prefix + ".P0", (int64_t)rows * C),
                            L > 1 ? buffer(br.prefix + ".P1", (int64_t)(rows / 3) * C) : -1};
         const int hb = L > 1 ? buffer(br.prefix + ".H", (int64_t)(rows / 3) * C) : -1;
-        int last = problem(br.prefix + ".expand_conv", rows, {{a0, 0, br.k0pad, br.k0pad, -1}}, -1, 0, 0, pp[0], 0, C);
+        // first layer: the A operand is generated from the raw input inside the kernel (fused prologue)
+        int last = problem(br.prefix + ".expand_conv", rows, {}, -1, 0, 0, pp[0], 0, C, {}, (int)br.lut_off);
         for (int i = 1; i < L; ++i) {
             const int src = pp[(i - 1) & 1], dst = pp[i & 1];
             rows /= 3;
@@ -107,8 +114,6 @@ static Plan *build_plan(const Model *a, const Model *b) {
     Plan *pl = new Plan();
     pl->m[0] = a;
     pl->m[1] = b;
-    Builder shared{*pl, 0, *a};
-    pl->cur_buf = shared.buffer("cur", CUR_LD);
     for (int mi = 0; mi < 2; ++mi) {
         const Model *m = pl->m[mi];
         if (!m) continue;
@@ -116,7 +121,7 @@ static Plan *build_plan(const Model *a, const Model *b) {
         const int lat = m->cfg.latent, D = m->cfg.embed_dim;
         if (D > 0) pl->emb_buf[mi] = B.buffer("emb", D);
         const int g = B.buffer("global", lat);
-        const int pg = B.fc_block("GlobalInfo", {{pl->cur_buf, 0, CUR_LD, CUR_LD, -1}}, 2, g, 0, lat);
+        const int pg = B.fc_block("GlobalInfo", {}, 2, g, 0, lat, (int)m->global_lut_off);
         if (m->cfg.kind == R3D_KIND_POS) {
             pl->pos_model = mi;
             const int tmp5 = B.buffer("tmp5", 5 * lat);
@@ -142,7 +147,6 @@ static Plan *build_plan(const Model *a, const Model *b) {
                     }
                 }
             }
-            pl->dec_buf = B.buffer("dec", 5 * DEC_SLOT);
             for (int bi = 0; bi < 5; ++bi) {
                 // cat(local, [mix], global, [embedding])  (rie.py:376-407)
                 std::vector<Builder::In> ins;
@@ -151,18 +155,17 @@ static Plan *build_plan(const Model *a, const Model *b) {
                 ins.push_back({g, 0, lat, lat, pg});
                 if (D > 0) ins.push_back({pl->emb_buf[mi], 0, D, D, -1});
                 B.fc_block(std::string("Integration_") + (bi == 0 ? "Torso" : bi == 1 ? "LArm" : bi == 2 ? "RArm" : bi == 3 ? "LLeg" : "RLeg"),
-                           ins, 1, pl->dec_buf, bi * DEC_SLOT, 5 * DEC_SLOT);
+                           ins, 1, -1, 0, 0);
             }
         } else {
             pl->trj_model = mi;
             const int local = B.buffer("local", lat);
             const int sh = B.temporal_block(0, local, 0, lat);
-            pl->trj_buf = B.buffer("trj", 4);
             std::vector<Builder::In> ins;
             ins.push_back({local, 0, lat, lat, sh});
             ins.push_back({g, 0, lat, lat, pg});
             if (D > 0) ins.push_back({pl->emb_buf[mi], 0, D, D, -1});
-            B.fc_block("Integration", ins, 1, pl->trj_buf, 0, 4);
+            B.fc_block("Integration", ins, 1, -1, 0, 0);
         }
     }
     // levelise

@@ -56,3 +56,154 @@ def test_lifter_pair_matches_reference_fixture(name):
     ref = z["out_pos"] + z["out_trj"]
     assert np.abs(out.cpu().numpy() - ref).max() <= tol_for(ref)
     assert np.abs(out_trj.cpu().numpy() - z["out_trj"]).max() <= tol_for(z["out_trj"])
+
+
+# ---------------------------------------------------------------- oracle parity beyond the fixtures
+
+@pytest.mark.parametrize("arch,batch", [("3,3", 1), ("3,3", 37), ("3,3,3", 100), ("3,3,3,3", 33), ("3,3,3,3,3", 5)])
+def test_lifter_matches_oracle_ragged_batches(arch, batch):
+    """Batch sizes that are not multiples of any tile (row masking, partial schedules)."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    from oracle import oracle
+    mc = ray3d_amd.default_model_config(ARCHITECTURE=arch)
+    pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    x = synth.synth_rays(batch, cp, seed=21)
+    p = synth.synth_param(batch, seed=22)
+    with torch.no_grad():
+        out = lifter(torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()).cpu().numpy()
+    ref = oracle.forward(cp, sp, x, p) + oracle.forward(ct, st, x, p)
+    assert np.abs(out - ref).max() <= tol_for(ref)
+
+
+def test_forward_clip_equals_materialised_windows():
+    """In-kernel sliding windows (window_stride = 1) == eval_data_prepare's copies (trainer.py:47-58)."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
+    pos, trj, (cp, _), _ = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    n, rf = 150, 27
+    clip = synth.synth_rays(1, ray3d_amd.LiftConfig("pos", 17, 3, (3,) * 3), seed=5)[0]          # (27,17,3)
+    clip = np.concatenate([clip] * 7, axis=0)[: n + rf - 1] + 0.01 * np.arange(n + rf - 1, dtype=np.float32)[:, None, None]
+    windows = np.stack([clip[i:i + rf] for i in range(n)])
+    prow = np.array([1.5, 0.2], np.float32)
+    with torch.no_grad():
+        a = lifter.forward_clip(torch.from_numpy(clip).cuda(), torch.from_numpy(prow).cuda()).cpu().numpy()
+        b = lifter(torch.from_numpy(windows).cuda(), torch.from_numpy(np.tile(prow, (n, 1))).cuda()).cpu().numpy()
+    assert a.shape == (n, 1, 17, 3)
+    assert np.array_equal(a, b)        # same arithmetic, same order: bit-identical
+
+
+def test_forward_uv_matches_host_ray_encoding():
+    """uv + per-window camera rows -> rays on the GPU (float64) == reference-pinned host encoding."""
+    import os
+    import ray3d_amd
+    from conftest import GOLDEN
+    from ray3d_amd import synth
+    z = np.load(os.path.join(GOLDEN, "cameras.npz"))
+    tags = [t for t in z["tags"]]
+    cams = [ray3d_amd.Camera(z[t + "/K"], z[t + "/R"], z[t + "/t"]) for t in tags]
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3")
+    pos, trj, (cp, _), _ = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    B = 24                                           # mixed intrinsics per batch (BASELINE configs[3])
+    uv = (1000.0 * synth.hash_uniform("uvtest", (B, 9, 17, 2), 9)).astype(np.float32)
+    pick = [cams[i % len(cams)] for i in range(B)]
+    rays = np.stack([c.rays_from_uv(uv[i].astype(np.float64)) for i, c in enumerate(pick)]).astype(np.float32)
+    rows = np.stack([c.cam_row() for c in pick])
+    par = np.stack([c.param() for c in pick])
+    with torch.no_grad():
+        a = lifter.forward_uv(torch.from_numpy(uv).cuda(), torch.from_numpy(rows).cuda(), torch.from_numpy(par).cuda())
+        b = lifter(torch.from_numpy(rays).cuda(), torch.from_numpy(par).cuda())
+    assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())   # float64 ray math on both sides -> identical rays
+
+
+@pytest.mark.parametrize("flip", [False, True])
+def test_evaluate_clips_reproduces_reference_metrics(flip):
+    """Whole eval loop on the GPU vs Trainer.evaluate_core's five metrics (tests/golden/evalcore.npz)."""
+    import os
+    import ray3d_amd
+    from conftest import GOLDEN
+    from ray3d_amd import evaluate
+    z = np.load(os.path.join(GOLDEN, "evalcore.npz"))
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
+    pos, trj, _, _ = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    clips = [evaluate.Clip(ray3d_amd.Camera(z["clip%d/K" % i], z["clip%d/R" % i], z["clip%d/t" % i]),
+                           z["clip%d/rays" % i], z["clip%d/gt_norm" % i], "A", i) for i in range(3)]
+    with torch.no_grad():
+        named, avg, rows = evaluate.evaluate_clips(lifter.forward_clip, clips, 27, torch.device("cuda:0"), flip=flip,
+                                                   kps_left=list(z["kps_left"]), kps_right=list(z["kps_right"]))
+    ref = z["metrics_flip%d" % int(flip)]
+    assert np.abs(np.array(named["A"]) - ref).max() < 5e-2, (named["A"], ref)   # mm; MPJPE itself to 0.05 mm
+    assert abs(named["A"][0] - ref[0]) < 2e-2
+
+
+# ---------------------------------------------------------------- full-size properties (BASELINE sizes)
+
+def test_full_size_batch_properties():
+    """B = 256, RF 243 (BASELINE configs[1]): permutation equivariance, split invariance, determinism,
+    and oracle agreement on a sample of windows."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    from oracle import oracle
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3,3,3")
+    pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    B = 256
+    x = synth.synth_rays(B, cp, seed=31)
+    p = synth.synth_param(B, seed=32)
+    xd, pd = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    with torch.no_grad():
+        full = lifter(xd, pd)
+        again = lifter(xd, pd)
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(0)).cuda()
+        permuted = lifter(xd[perm].contiguous(), pd[perm].contiguous())
+        halves = torch.cat([lifter(xd[:100].contiguous(), pd[:100].contiguous()),
+                            lifter(xd[100:].contiguous(), pd[100:].contiguous())])
+    assert torch.equal(full, again)                                   # deterministic (no atomics)
+    assert (full[perm] - permuted).abs().max().item() <= 2e-5         # windows are independent
+    assert (full - halves).abs().max().item() <= 2e-5
+    idx = [0, 77, 255]
+    ref = oracle.forward(cp, sp, x[idx], p[idx]) + oracle.forward(ct, st, x[idx], p[idx])
+    assert np.abs(full[idx].cpu().numpy() - ref).max() <= tol_for(ref)
+    # output buffer is fresh and caller-owned (callers mutate it in place, trainer.py:340-353)
+    full += 1.0
+    assert not torch.equal(full, again)
+
+
+def test_large_batch_1024():
+    """north_star's 1024 x 243 x 17 shape: finite, and equal to four 256-window calls."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3,3,3")
+    pos, trj, (cp, _), _ = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    x = torch.from_numpy(synth.synth_rays(1024, cp, seed=41)).cuda()
+    p = torch.from_numpy(synth.synth_param(1024, seed=42)).cuda()
+    with torch.no_grad():
+        big = lifter(x, p)
+        parts = torch.cat([lifter(x[i:i + 256].contiguous(), p[i:i + 256].contiguous()) for i in range(0, 1024, 256)])
+    assert torch.isfinite(big).all()
+    assert (big - parts).abs().max().item() <= 2e-5
+
+
+def test_weight_update_is_picked_up():
+    import ray3d_amd
+    from ray3d_amd import synth
+    mc = ray3d_amd.default_model_config()
+    pos, trj, (cp, sp), _ = build_modules(mc)
+    x = torch.from_numpy(synth.synth_rays(4, cp, seed=3)).cuda()
+    p = torch.from_numpy(synth.synth_param(4, seed=4)).cuda()
+    with torch.no_grad():
+        a = pos(x, p)
+        sd = {k: v.clone() for k, v in pos.state_dict().items()}
+        key = [k for k in sd if k.endswith("Integration_Torso.fc_2.bias")][0]
+        sd[key] += 1.0
+        pos.load_state_dict(sd)
+        b = pos(x, p)
+    d = (b - a)[:, 0].cpu().numpy()
+    torso_slots = [0, 7, 8, 9, 10]
+    assert np.allclose(d[:, torso_slots], 1.0, atol=1e-5) and np.allclose(np.delete(d, torso_slots, axis=1), 0.0, atol=1e-6)
