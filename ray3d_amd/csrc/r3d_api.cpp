@@ -101,7 +101,10 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
     const bool needs_param = a->cfg.embed_dim > 0 || (b && b->cfg.embed_dim > 0);
     if (needs_param && !in->param_dev) { set_error("param_dev is required when the camera embedding is on"); return R3D_ERR_ARG; }
     if (in->window_stride <= 0) { set_error("window_stride must be positive"); return R3D_ERR_ARG; }
-    if (B * (int64_t)(a->RF / 3) >= 0x7fffffffLL) { set_error("B too large for one call"); return R3D_ERR_ARG; }
+    if (((B - 1) * in->window_stride + a->RF) * (int64_t)(a->cfg.num_joints * 3) * 4 >= 0x7fffffffLL || B * (int64_t)(a->RF / 3) >= 0x7fffffffLL) {
+        set_error("B too large for one call (the raw input must stay below 2 GiB)");
+        return R3D_ERR_ARG;
+    }
 
     Plan *pl = plan_get(a, b);
     // UV mode keeps the encoded rays of every touched frame at the end of the workspace
@@ -193,6 +196,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
                 g.enc_rows = q.enc_rows;
                 g.enc_jf = JF;
                 g.enc_cur = (a->RF / a->cfg.in_features) * JF;   // quirk Q1: "current" frame is RF // in_features
+                g.enc_bytes = (unsigned)((size_t)frames * JF * sizeof(float));
             }
             g.w = m->d_arena + L.w_off;
             g.bias = m->d_arena + L.b_off;

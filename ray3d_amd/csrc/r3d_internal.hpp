@@ -42,7 +42,7 @@ struct GemmProb {
     int enc_rows;             // GEMM rows per window (RF/3 for a temporal branch, 1 for GlobalInfo)
     int enc_jf;               // J*F
     int enc_cur;              // element offset of the "current" frame inside a window (tcur * J*F)
-    int pad_;
+    unsigned enc_bytes;       // size of the raw input in bytes (buffer-descriptor bound)
 };
 
 // Kernel argument of one persistent GEMM launch.  `tiles`/`wg_off` live in HBM (built once per
@@ -114,6 +114,7 @@ struct Layer {
     int cin;                  // input channels per tap
     int N, K, Npad, Kpad;     // K = taps*cin
     float slope;
+    bool frag;                // packed in MFMA fragment order (GEMM layers) or row-major [N][Kpad] (decoder tail)
     size_t w_off, b_off;      // offsets (floats) into the packed arena
 };
 
@@ -222,8 +223,13 @@ int model_set_weight(Model *m, const char *key, const float *host, const int64_t
 int model_finalize(Model *m);
 Plan *plan_get(Model *a, Model *b);
 struct SchedProb { int M, N, nk; };
-void schedule_stage(const std::vector<SchedProb> &probs, int nwg, std::vector<int4> &tiles, std::vector<int> &wgoff,
-                    StageSchedule &out);
+void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units, std::vector<int4> &tiles,
+                    std::vector<int> &wgoff, StageSchedule &out);
+// index of weight element (output channel o, GEMM column k) in the fragment-ordered packing
+inline size_t frag_index(int o, int k, int nk) {
+    const int nb = o >> 5, li = o & 31, kt = k >> 5, kin = k & 31, lh = kin >> 4, q = (kin & 15) >> 2, e = kin & 3;
+    return ((((size_t)nb * nk + kt) * 4 + q) * 64 + (lh * 32 + li)) * 4 + e;
+}
 Schedule *schedule_get(Plan *pl, int64_t B, int nwg);   // nullptr + set_error on failure
 int device_cu_count();
 

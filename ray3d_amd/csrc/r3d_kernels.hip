@@ -23,112 +23,198 @@ namespace r3d {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Explicit global-address-space accesses.  Pointers that reach a kernel through a descriptor table
+// are "generic" to the compiler, which then emits flat_load/flat_store: those tick BOTH vmcnt and
+// lgkmcnt, so every `s_waitcnt lgkmcnt(0)` in front of an MFMA (meant for ds_read) would also wait
+// for the HBM loads in flight.  Casting to address space 1 gives global_load/global_store.
+#define R3D_AS1 __attribute__((address_space(1)))
+__device__ __forceinline__ f32x4 gload4(const float *p) { return *(const R3D_AS1 f32x4 *)p; }
+__device__ __forceinline__ float gload1(const float *p) { return *(const R3D_AS1 float *)p; }
+__device__ __forceinline__ void gstore1(float *p, float v) { *(R3D_AS1 float *)p = v; }
+
 // ------------------------------------------------------------------------------------ GEMM
 //
 // One persistent launch per DAG level: grid = #CUs, one 512-thread workgroup (8 wavefronts, two per
-// SIMD) per CU, owning 144 KiB of LDS.  The host cuts the level's work - all (problem, 256-column
-// block, 32-row unit) triples - into one contiguous, cost-balanced chunk per workgroup
-// (r3d_schedule.cpp); a chunk is executed as a few tiles of BM = 32*MI rows (MI = 1..8) by 256
-// columns.  Wavefront w owns columns [32w, 32w+32) of the tile and all MI row blocks, so any MI is
-// perfectly balanced across the 8 wavefronts and the only waste is the 32-row MFMA granularity.
+// SIMD) per CU.  The host cuts the level's work - all (problem, 256-column block, 32-row unit)
+// triples - into one contiguous, cost-balanced chunk per workgroup (r3d_schedule.cpp); a chunk is
+// executed as a few tiles of BM = 32*MI rows (MI = 1..6) by 256 columns.  Wavefront w owns columns
+// [32w, 32w+32) of the tile and all MI row blocks, so any MI is perfectly balanced across the 8
+// wavefronts and the only waste is the 32-row MFMA granularity.
 //
-// K loop: BK = 32.  A (BM x 32) and W (256 x 32) tiles are staged global -> VGPR -> LDS with a
-// one-tile prefetch (tile t+1 is in flight while tile t feeds the matrix cores) and double-buffered
-// in LDS; rows are padded to 36 floats so the 16 lanes a ds_read_b128 services together hit 16
-// distinct 16-byte slots (no bank conflicts; SQ_LDS_BANK_CONFLICT = 0 in profiles/).
+// Operand paths (BK = 32 per K tile):
+//  * A (activations, BM x 32) is shared by all 8 wavefronts: global -> VGPR -> LDS ring of three
+//    stages.  Tile t+4 is loaded from HBM while tile t feeds the matrix cores, tile t+2 is written
+//    to LDS at the top of iteration t (two iterations after its loads were issued), so neither the HBM latency nor the LDS write sits between a
+//    barrier and the next MFMA.  Rows are padded to 36 floats: the 16 lanes a ds_read_b128 services
+//    together hit 16 distinct 16-byte slots (SQ_LDS_BANK_CONFLICT = 0).
+//  * W (weights) never touches LDS: the host packs every layer in MFMA fragment order
+//    (r3d_model.cpp) so that a wavefront's B fragments of one K tile are four fully coalesced
+//    1 KiB loads straight into VGPRs, issued one K tile ahead.  Each wavefront reads only its own
+//    32 columns - there is nothing to share.
+//  * With MI <= 4 the first A fragments of tile t+1 are read before the end-of-tile barrier, so the
+//    first MFMA after the barrier issues immediately.
 // MFMA operand mapping (v_mfma_f32_32x32x2_f32): lane l supplies A[i = l&31][k = l>>5] and
-// B[k = l>>5][j = l&31].  Lane (i, h) reads 4 consecutive floats k = 16h + 4q .. +3 of its row per
-// ds_read_b128 and feeds them to 4 MFMAs; since A and W use the same k permutation the sum over
-// k is unchanged.
+// B[k = l>>5][j = l&31].  Lane (i, h) holds 4 consecutive floats k = 16h + 4q .. +3 of its row /
+// column per fragment register quad and feeds them to 4 MFMAs; A and W use the same k permutation
+// so the sum over k is unchanged.
 
 constexpr int LDS_LD = BK + 4;                       // 36 floats = 144 B per staged row
 constexpr int GEMM_THREADS = 512;
 constexpr int GEMM_BN = 256;
-constexpr int GEMM_MAX_MI = 8;
-constexpr int STAGE_FLOATS = (GEMM_MAX_MI * 32 + GEMM_BN) * LDS_LD;
-constexpr int GEMM_LDS_BYTES = 2 * STAGE_FLOATS * 4; // 147456 B
+constexpr int GEMM_MAX_MI = 6;
+constexpr int GEMM_STAGES = 3;
+constexpr int STAGE_FLOATS = GEMM_MAX_MI * 32 * LDS_LD;                  // one A tile: 27,648 B
+constexpr int LUT_LDS_INTS = 512;                                        // fused-prologue LUT copy
+constexpr int GEMM_LDS_BYTES = GEMM_STAGES * STAGE_FLOATS * 4 + LUT_LDS_INTS * 4;   // 84,992 B
 
 typedef const LaunchArgs __attribute__((address_space(4))) *LaunchArgsPtr;
 typedef const GemmProb __attribute__((address_space(4))) &ProbRef;
 
 template <int MI, bool ENC>
-__device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int col0, float *smem, long long *dbg) {
+__device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int col0, const bool new_prob, float *smem,
+                                          long long *dbg) {
     constexpr int NA = (MI + 1) / 2;        // A staging slots per thread (64 rows per slot)
-    constexpr int NB = 4;                   // W staging slots per thread (256 rows)
+    constexpr bool PRE = MI <= 3;           // pre-read next tile's first A fragments before the barrier
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int M = P.M, N = P.N, K = P.K;
     const int nk = K / BK;
-    const int ke0 = P.kend[0], ke1 = P.kend[1], ke2 = P.kend[2];
     const int srow = tid >> 3, a_kq = (tid & 7) * 4;
+    int *lut_lds = reinterpret_cast<int *>(smem + GEMM_STAGES * STAGE_FLOATS);
 
+    // ---- A staging state
     int a_row[NA];
-    bool a_on[NA];
-    // fused prologue (ENC): per staged row, where its first frame and its window's "current" frame
-    // start in the raw input (element offsets)
-    long long e_first[ENC ? NA : 1], e_cur[ENC ? NA : 1];
+    int a_voff[ENC ? 1 : NA];               // plain mode: byte offset of the slot's row/column inside the tile's rows
+    unsigned e_first[ENC ? NA : 1], e_cur[ENC ? NA : 1];   // element indices into the raw input
+    const bool multi = !ENC && P.kend[0] < K;   // A is a virtual concatenation of several buffers
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int r = srow + 64 * i;
-        a_on[i] = (MI % 2 == 0) || (i < NA - 1) || (srow < 32);
-        const int gr = row0 + r;
+        const int gr = row0 + srow + 64 * i;
         a_row[i] = gr < M ? gr : M - 1;
         if (ENC) {
+            // where the staged row's first frame and its window's "current" frame start in the raw input
             const int win = a_row[i] / P.enc_rows, t3 = a_row[i] - win * P.enc_rows;
-            const long long wbase = (long long)win * P.enc_ws;
-            e_first[i] = wbase + (long long)t3 * 3 * P.enc_jf;
-            e_cur[i] = wbase + P.enc_cur;
+            const unsigned wbase = (unsigned)win * (unsigned)P.enc_ws;
+            e_first[i] = wbase + (unsigned)(t3 * 3 * P.enc_jf);
+            e_cur[i] = wbase + (unsigned)P.enc_cur;
+        } else {
+            a_voff[i] = ((a_row[i] - row0) * P.lda[0] + a_kq) * 4;
         }
     }
-    const float *ex = ENC ? P.x : nullptr;
-    const int *elut = ENC ? P.lut + a_kq : nullptr;
-    const float *w_ptr = P.w + (size_t)(col0 + srow) * K + a_kq;
-    const size_t w_step = (size_t)64 * K;
-    const int st_off = srow * LDS_LD + a_kq;           // staging offset inside a 64-row slot
+    // Plain operands are read through buffer descriptors whose base (first row of the tile) and K-tile
+    // offset are scalars: a staging load is ONE instruction with no vector address arithmetic.  That
+    // matters because a wavefront's VALU instructions crawl (about one per 64 cycles) while its SIMD
+    // partner streams MFMAs, whereas memory instructions issue freely.
+    __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(ENC ? P.bias : P.a[0] + (size_t)row0 * P.lda[0]), 0, 0x7fffffff, 0x00020000);
+    // concatenated operands: K tiles are issued in increasing order, so the segment state (buffer, leading
+    // dimension, first/last K) only ever advances; the descriptor table is touched at segment
+    // boundaries only (<= 3 times per tile).  No scalar loads in the steady-state loop: an SMEM load in
+    // flight would also degrade every counted `s_waitcnt lgkmcnt(N)` in front of the MFMAs to (0).
+    const float *seg_base = P.a[0] + (size_t)row0 * P.lda[0];
+    int seg_ld = P.lda[0], seg_k0 = 0, seg_end = P.kend[0], seg_i = 0;
+    int a_rel[NA], m_voff[NA];              // 4 * (row inside the tile); byte offset of the slot in the current segment
+    auto prep_seg = [&](int kt) {
+        if (!multi) return;
+        while (kt * BK >= seg_end) {     // uniform
+            ++seg_i;
+            seg_k0 = seg_end;
+            seg_ld = P.lda[seg_i];
+            seg_base = P.a[seg_i] + (size_t)row0 * seg_ld;
+            seg_end = P.kend[seg_i];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) m_voff[i] = a_rel[i] * seg_ld + a_kq * 4;   // per-segment, not per-tile
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        a_rel[i] = (a_row[i] - row0) * 4;
+        m_voff[i] = a_rel[i] * seg_ld + a_kq * 4;
+    }
+    if (ENC && new_prob) {
+        // LUT copy: one ds_read_b128 per K tile instead of a dependent global load
+        for (int i = tid; i < K; i += GEMM_THREADS) lut_lds[i] = *(const R3D_AS1 int *)(P.lut + i);
+        __syncthreads();
+    }
+    // raw input through a buffer descriptor: one 32-bit offset add per gathered element instead of
+    // 64-bit pointer arithmetic, and out-of-range reads return 0 instead of faulting
+    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ENC ? P.x : P.bias), 0, ENC ? P.enc_bytes : 0, 0x00020000);
 
-    f32x4 ra[NA], rb[NB];
-    auto load_global = [&](int kt) {
+    // raw staging registers: plain mode one float4 per slot; ENC mode minuend / subtrahend / codes
+    struct Staged {                         // one A tile on its way from HBM to LDS
+        f32x4 a[NA];                        // plain: the data; ENC: minuends
+        f32x4 s[ENC ? NA : 1];              // ENC: subtrahends
+        int4 code;                          // ENC: LUT entries of this thread's 4 columns
+    };
+    Staged ra, ra2;                         // tiles in flight: even / odd tile index
+    auto issue_a = [&](int kt, Staged &R) {
         const int kb = kt * BK;
         if (ENC) {
             // A[row][k] = x[first/cur + off1] - x[first/cur + off2]: ray differences and body-part
             // gather (lib/model/rie.py:290-357) evaluated while staging; nothing is materialised
-            const int4 code = *reinterpret_cast<const int4 *>(elut + kb);
-            const int cd[4] = {code.x, code.y, code.z, code.w};
+            R.code = *reinterpret_cast<const int4 *>(lut_lds + kb + a_kq);
+            const int cd[4] = {R.code.x, R.code.y, R.code.z, R.code.w};
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                if (!a_on[i]) continue;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int c = cd[e], kind = (c >> 20) & 3;
-                    const long long b1 = (c >> 22) & 1 ? e_cur[i] : e_first[i];
-                    const long long b2 = kind == 2 ? e_cur[i] : e_first[i];
-                    const float v1 = ex[b1 + (c & 1023)];
-                    const float v2 = ex[b2 + ((c >> 10) & 1023)];
-                    ra[i][e] = kind == 3 ? 0.0f : (kind == 0 ? v1 : v1 - v2);
+                    const unsigned b1 = (c >> 22) & 1 ? e_cur[i] : e_first[i];
+                    const unsigned b2 = kind == 2 ? e_cur[i] : e_first[i];
+                    R.a[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (b1 + (c & 1023)) << 2, 0, 0));
+                    R.s[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (b2 + ((c >> 10) & 1023)) << 2, 0, 0));
                 }
             }
         } else {
-            // K segment of the (virtually concatenated) A operand this tile falls in (uniform -> scalar loads)
-            const int si = (kb >= ke0) + (kb >= ke1) + (kb >= ke2);
-            const float *base = P.a[si];
-            const int ld = P.lda[si];
-            const int k0 = si ? P.kend[si - 1] : 0;
-            const int kofs = kb - k0 + a_kq;
+            // every slot loads unconditionally (rows past the tile are clamped and never consumed): a
+            // predicated load would make the compiler wait for ALL outstanding loads at the merge point
+            if (multi) {
+                // concatenated operand: the K segment of this tile was looked up one iteration ago
+                // (prep_seg), so its scalar-load round trip is off the critical path of short K tiles
+                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(seg_base), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-            for (int i = 0; i < NA; ++i)
-                if (a_on[i]) ra[i] = *reinterpret_cast<const f32x4 *>(base + (size_t)a_row[i] * ld + kofs);
+                for (int i = 0; i < NA; ++i)
+                    R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, m_voff[i], (kb - seg_k0) * 4, 0));
+            } else {
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+                    R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff[i], kb * 4, 0));
+            }
         }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(w_ptr + i * w_step + kb);
     };
-    auto store_lds = [&](int buf) {
-        float *s = smem + buf * STAGE_FLOATS + st_off;
+    const int st_off = srow * LDS_LD + a_kq;
+    auto commit_a = [&](int stage, const Staged &R) {
+        // (stage is uniform: three copies of the stores with immediate offsets, no address arithmetic)
+        float *s = stage == 0 ? smem + st_off : stage == 1 ? smem + STAGE_FLOATS + st_off : smem + 2 * STAGE_FLOATS + st_off;
+        if (ENC) {
+            const int cd[4] = {R.code.x, R.code.y, R.code.z, R.code.w};
 #pragma unroll
-        for (int i = 0; i < NA; ++i)
-            if (a_on[i]) *reinterpret_cast<f32x4 *>(s + i * 64 * LDS_LD) = ra[i];
+            for (int i = 0; i < NA; ++i) {
+                f32x4 v;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4 *>(s + (GEMM_MAX_MI * 32 + i * 64) * LDS_LD) = rb[i];
+                for (int e = 0; e < 4; ++e) {
+                    const int kind = (cd[e] >> 20) & 3;
+                    v[e] = kind == 3 ? 0.0f : (kind == 0 ? R.a[i][e] : R.a[i][e] - R.s[i][e]);
+                }
+                *reinterpret_cast<f32x4 *>(s + i * 64 * LDS_LD) = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(s + i * 64 * LDS_LD) = R.a[i];
+        }
+    };
+
+    // ---- W fragments: [(n/32)][k tile][q][lane][4] in HBM, this wavefront's 32 columns
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // make the descriptor provably wave-uniform
+    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.w + ((size_t)((col0 >> 5) + wave_u) * nk) * 1024), 0, nk * 4096, 0x00020000);
+    const int w_voff = lane * 16;
+    f32x4 rb[4], rbn[4];                    // W fragments of the current and the next K tile
+    auto load_w = [&](int kt, f32x4 (&dst)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            dst[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff + q * 1024, kt * 4096, 0));
     };
 
     f32x16 acc[MI];
@@ -138,44 +224,86 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
         for (int r = 0; r < 16; ++r) acc[mi][r] = 0.0f;
 
     const int a_frag = li * LDS_LD + lh * 16;
-    const int b_frag = (GEMM_MAX_MI * 32 + wave * 32 + li) * LDS_LD + lh * 16;
+    f32x4 av0[PRE ? MI : 1];
 
+    // ---- prologue: tiles 0 and 1 into LDS, tile 2 in flight, W(0) in registers
+    // (tile indices past the end are clamped instead of predicated: a redundant reload of the last
+    // tile is free, while a branch around a load makes the compiler's s_waitcnt placement pessimistic)
+    const int last = nk - 1;
+    load_w(0, rb);
+    {
+        Staged r0, r1;                      // four tiles in flight at once: one HBM latency, not four
+        issue_a(0, r0);
+        prep_seg(1 < last ? 1 : last);
+        issue_a(1 < last ? 1 : last, r1);
+        prep_seg(2 < last ? 2 : last);
+        issue_a(2 < last ? 2 : last, ra);
+        prep_seg(3 < last ? 3 : last);
+        issue_a(3 < last ? 3 : last, ra2);
+        prep_seg(4 < last ? 4 : last);
+        commit_a(0, r0);
+        commit_a(1, r1);
+    }
+    __syncthreads();
+    if (PRE) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) av0[mi] = *reinterpret_cast<const f32x4 *>(smem + a_frag + mi * 32 * LDS_LD);
+    }
 #ifdef R3D_TIMING
-#define R3D_STAMP(slot) do { if (dbg && tid == 0 && kt < 32) dbg[kt * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define R3D_STAMP(slot) do { if (dbg && lane == 0 && kt < 4) dbg[wave * 32 + kt * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define R3D_STAMP(slot) do { } while (0)
 #endif
-    load_global(0);
-    store_lds(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
+    (void)wave_u;
+    int st_cur = 0;                              // kt % 3 without a division
+    // One K tile.  `w_use` holds this tile's W fragments, `w_load` receives the next tile's: the two
+    // register sets swap roles every tile (loop unrolled by two) instead of being copied - a copy
+    // would force `s_waitcnt vmcnt(0)` at the end of EVERY tile and with it the HBM latency of the
+    // A loads issued in the same tile.  Staging comes first for every wavefront and is a handful of
+    // memory instructions (no VALU): non-MFMA instructions of one wavefront issue at about one per
+    // MFMA of its SIMD partner, so anything that is not an MFMA belongs in the gap after the barrier
+    // (an asymmetric compute-first/stage-first split between the partners was measured slower).
+    auto k_tile = [&](int kt, f32x4 (&w_use)[4], f32x4 (&w_load)[4], Staged &stg) {
         R3D_STAMP(0);
-        if (more) load_global(kt + 1);
+        const int st_next = st_cur == 2 ? 0 : st_cur + 1, st_next2 = st_next == 2 ? 0 : st_next + 1;
+        // order matters: the LDS write waits for its (old) loads only if no newer load was issued before it
+        commit_a(st_next2, stg);                     // tile kt+2, issued two iterations ago
+        load_w(kt + 1 < last ? kt + 1 : last, w_load);
+        issue_a(kt + 4 < last ? kt + 4 : last, stg);
+        prep_seg(kt + 5 < last ? kt + 5 : last);
         R3D_STAMP(1);
-        const float *s = smem + (kt & 1) * STAGE_FLOATS;
+        const float *s = smem + st_cur * STAGE_FLOATS + a_frag;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 av[MI];
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(s + b_frag + q * 4);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                av[mi] = *reinterpret_cast<const f32x4 *>(s + a_frag + mi * 32 * LDS_LD + q * 4);
+            for (int mi = 0; mi < MI; ++mi) {
+                if (PRE && q == 0) av[mi] = av0[mi];
+                else av[mi] = *reinterpret_cast<const f32x4 *>(s + mi * 32 * LDS_LD + q * 4);
+            }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
-                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][kk], bv[kk], acc[mi], 0, 0, 0);
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][kk], w_use[q][kk], acc[mi], 0, 0, 0);
         }
         R3D_STAMP(2);
-        if (more) store_lds((kt + 1) & 1);
+        if (PRE) {
+            const float *sn = smem + st_next * STAGE_FLOATS + a_frag;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) av0[mi] = *reinterpret_cast<const f32x4 *>(sn + mi * 32 * LDS_LD);
+        }
         R3D_STAMP(3);
         __syncthreads();
         R3D_STAMP(4);
+        st_cur = st_next;
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        k_tile(kt, rb, rbn, ra);
+        k_tile(kt + 1, rbn, rb, ra2);
     }
-#ifdef R3D_TIMING
-    if (dbg && tid == 0) dbg[255] = __builtin_readcyclecounter();
-#endif
+    if (kt < nk) k_tile(kt, rb, rbn, ra);
 
     // epilogue: C = res + lrelu(acc + bias).  C/D layout of the 32x32 MFMA: col = lane & 31,
     // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  A wavefront store instruction writes two
@@ -185,7 +313,7 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
     const float *res = P.res;
     float *c = P.c;
     const int ldc = P.ldc, ldr = P.ldr;
-    const float bias = P.bias[col];
+    const float bias = gload1(P.bias + col);
     const bool full = (row0 + MI * 32 <= M) && (col0 + GEMM_BN <= N);   // wave-uniform
     if (full) {
 #pragma unroll
@@ -196,8 +324,8 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
                 const size_t row = rbase + (r & 3) + 8 * (r >> 2);
                 float v = acc[mi][r] + bias;
                 v = v > 0.0f ? v : v * slope;
-                if (res) v += res[row * ldr + col];
-                c[row * ldc + col] = v;
+                if (res) v += gload1(res + row * ldr + col);
+                gstore1(c + row * ldc + col, v);
             }
         }
     } else if (col < N) {
@@ -209,8 +337,8 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
                 if (row < M) {
                     float v = acc[mi][r] + bias;
                     v = v > 0.0f ? v : v * slope;
-                    if (res) v += res[(size_t)row * ldr + col];
-                    c[(size_t)row * ldc + col] = v;
+                    if (res) v += gload1(res + (size_t)row * ldr + col);
+                    gstore1(c + (size_t)row * ldc + col, v);
                 }
             }
         }
@@ -231,28 +359,29 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
     const int t1 = __builtin_amdgcn_readfirstlane(args->wg_off[wg + 1]);
     long long *dbg = nullptr;
 #ifdef R3D_TIMING
-    if (args->dbg && wg < 4) dbg = args->dbg + wg * 256;
+    if (args->dbg && wg < 4) dbg = args->dbg + wg * 256;   // 8 waves x 4 K tiles x 8 stamps
     if (args->dbg && threadIdx.x == 0) {
         args->dbg[1024 + wg * 4 + 0] = __builtin_readcyclecounter();
         args->dbg[1024 + wg * 4 + 2] = wall_clock64();
     }
 #endif
+    int prev_pi = -1;
     for (int t = t0; t < t1; ++t) {
         const int4 td = args->tiles[t];
         const int pi = __builtin_amdgcn_readfirstlane(td.x & 0xff);
+        const bool new_prob = pi != prev_pi;
+        prev_pi = pi;
         const int mi = __builtin_amdgcn_readfirstlane(td.x >> 8);
         const int row0 = __builtin_amdgcn_readfirstlane(td.y);
         const int col0 = __builtin_amdgcn_readfirstlane(td.z);
         ProbRef P = args->p[pi];
         switch (mi) {
-            case 1: gemm_tile<1, ENC>(P, row0, col0, smem, dbg); break;
-            case 2: gemm_tile<2, ENC>(P, row0, col0, smem, dbg); break;
-            case 3: gemm_tile<3, ENC>(P, row0, col0, smem, dbg); break;
-            case 4: gemm_tile<4, ENC>(P, row0, col0, smem, dbg); break;
-            case 5: gemm_tile<5, ENC>(P, row0, col0, smem, dbg); break;
-            case 6: gemm_tile<6, ENC>(P, row0, col0, smem, dbg); break;
-            case 7: gemm_tile<7, ENC>(P, row0, col0, smem, dbg); break;
-            default: gemm_tile<8, ENC>(P, row0, col0, smem, dbg); break;
+            case 1: gemm_tile<1, ENC>(P, row0, col0, new_prob, smem, dbg); break;
+            case 2: gemm_tile<2, ENC>(P, row0, col0, new_prob, smem, dbg); break;
+            case 3: gemm_tile<3, ENC>(P, row0, col0, new_prob, smem, dbg); break;
+            case 4: gemm_tile<4, ENC>(P, row0, col0, new_prob, smem, dbg); break;
+            case 5: gemm_tile<5, ENC>(P, row0, col0, new_prob, smem, dbg); break;
+            default: gemm_tile<6, ENC>(P, row0, col0, new_prob, smem, dbg); break;
         }
     }
 #ifdef R3D_TIMING
@@ -280,7 +409,7 @@ extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_enc_f32(cons
 hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, bool encode, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        // 144 KiB of dynamic LDS exceeds the 64 KiB default cap
+        // 83 KiB of dynamic LDS exceeds the 64 KiB default cap
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(r3d_gemm_f32),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -347,54 +476,74 @@ hipError_t launch_prologue(const PrologueArgs &args, hipStream_t stream) {
 
 // ------------------------------------------------------------------------------------ decoder tail
 
-// One wavefront per window: the final Linear(1024 -> 3 n_g) of each Integration block
-// (lib/model/rie.py:409-413, :557) as 64-lane dot products, written straight into the joint slot
-// the reference's reassembly puts it (rie.py:415-432), plus the trajectory broadcast add
-// (lib/train_val/trainer.py:353).  These layers are 0.05 % of the FLOPs; as GEMMs their N = 3..15
-// would waste a 256-column tile.
+// One wavefront per (window, decoder): the final Linear(1024 -> 3 n_g) of an Integration block
+// (lib/model/rie.py:409-413, :557) as 64-lane dot products, three outputs (one joint) at a time,
+// written straight into the joint slot the reference's reassembly puts it (rie.py:415-432) plus the
+// trajectory broadcast add (lib/train_val/trainer.py:353).  Every body-part wavefront recomputes the
+// 3-output trajectory head itself - cheaper than a dependency between wavefronts.  These layers are
+// 0.05 % of the FLOPs; as GEMMs their N = 3..15 would waste a 256-column tile.
+__device__ __forceinline__ void decode_dot3(const f32x4 (&hv)[4], const float *w, int lane, float (&o)[3]) {
+    f32x4 wv[3][4];
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wv[n][j] = gload4(w + (size_t)n * MLP_HIDDEN + j * 256 + lane * 4);
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc += hv[j][0] * wv[n][j][0] + hv[j][1] * wv[n][j][1] + hv[j][2] * wv[n][j][2] + hv[j][3] * wv[n][j][3];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        o[n] = acc;
+    }
+}
+
 extern "C" __global__ __launch_bounds__(256) void r3d_decode_f32(const DecodeArgs a) {
     const int lane = threadIdx.x & 63;
-    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // global wavefront index
+    const int npos = a.has_trj ? a.nsrc - 1 : a.nsrc;                        // body-part decoders
+    const int per_win = a.has_pos ? npos : 1;
+    const long long b = gw / per_win;
     if (b >= a.B) return;
-    float trj0 = 0.0f, trj1 = 0.0f, trj2 = 0.0f;   // scalars: a runtime-indexed array would live in scratch
-    // trajectory source first so that its result can be added to every joint
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int s = 0; s < a.nsrc; ++s) {
-            const bool is_trj = a.has_trj && s == a.nsrc - 1;
-            if ((pass == 0) != is_trj) continue;
-            const float *h = a.h[s] + b * MLP_HIDDEN;
-            f32x4 hv[4];
+    const int s = (int)(gw - b * per_win);
+    float trj[3] = {0.0f, 0.0f, 0.0f};
+    if (a.has_trj) {
+        const int ts = a.nsrc - 1;
+        f32x4 hv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) hv[j] = *reinterpret_cast<const f32x4 *>(h + j * 256 + lane * 4);
-            for (int o = 0; o < a.n_out[s]; ++o) {
-                const float *w = a.w[s] + (size_t)o * MLP_HIDDEN;
-                float acc = 0.0f;
+        for (int j = 0; j < 4; ++j) hv[j] = gload4(a.h[ts] + b * MLP_HIDDEN + j * 256 + lane * 4);
+        decode_dot3(hv, a.w[ts], lane, trj);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + j * 256 + lane * 4);
-                    acc += hv[j][0] * wv[0] + hv[j][1] * wv[1] + hv[j][2] * wv[2] + hv[j][3] * wv[3];
-                }
+        for (int n = 0; n < 3; ++n) trj[n] += a.bias[ts][n];
+        if (lane == 0 && s == 0) {
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
-                acc += a.bias[s][o];
-                if (is_trj) {
-                    if (o == 0) trj0 = acc; else if (o == 1) trj1 = acc; else trj2 = acc;
-                    if (lane == 0) {
-                        if (a.out_trj) a.out_trj[b * 3 + o] = acc;
-                        if (!a.has_pos) a.out[b * 3 + o] = acc;
-                    }
-                } else if (lane == 0) {
-                    const int e = a.slot[a.first[s] + o];
-                    const int c3 = e % 3;
-                    a.out[b * (a.J * 3) + e] = acc + (c3 == 0 ? trj0 : c3 == 1 ? trj1 : trj2);
-                }
+            for (int n = 0; n < 3; ++n) {
+                if (a.out_trj) a.out_trj[b * 3 + n] = trj[n];
+                if (!a.has_pos) a.out[b * 3 + n] = trj[n];
             }
+        }
+    }
+    if (!a.has_pos) return;
+    f32x4 hv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) hv[j] = gload4(a.h[s] + b * MLP_HIDDEN + j * 256 + lane * 4);
+    for (int o = 0; o < a.n_out[s]; o += 3) {      // one joint per iteration
+        float v[3];
+        decode_dot3(hv, a.w[s] + (size_t)o * MLP_HIDDEN, lane, v);
+        if (lane == 0) {
+            const int e = a.slot[a.first[s] + o];   // (x, y, z) of a joint are consecutive in the output
+#pragma unroll
+            for (int n = 0; n < 3; ++n) a.out[b * (a.J * 3) + e + n] = v[n] + a.bias[s][o + n] + trj[n];
         }
     }
 }
 
 hipError_t launch_decode(const DecodeArgs &args, hipStream_t stream) {
-    r3d_decode_f32<<<dim3((unsigned)((args.B + 3) / 4)), dim3(256), 0, stream>>>(args);
+    const int npos = args.has_trj ? args.nsrc - 1 : args.nsrc;
+    const long long waves = args.B * (args.has_pos ? npos : 1);
+    r3d_decode_f32<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream>>>(args);
     return hipGetLastError();
 }
 

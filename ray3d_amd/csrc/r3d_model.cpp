@@ -71,6 +71,7 @@ struct Grammar {
         L.Npad = round_up(n, N_ALIGN);
         L.Kpad = round_up(L.K, BK);
         L.slope = slope;
+        L.frag = true;
         L.w_off = L.b_off = 0;
         if (conv)
             tensor(L.weight_key, {n, cin, taps});
@@ -206,6 +207,9 @@ Model *model_create(const r3d_config &cfg) {
     m->global_lut_off = m->iarena.size();
     for (int col = 0; col < CUR_LD; ++col)
         m->iarena.push_back(col < JF ? encode_lut_entry(col, 0, 0, 1) : encode_lut_entry(0, 0, 3, 0));
+    for (auto &kv : m->layer_index)
+        if (kv.first.rfind("Integration", 0) == 0 && kv.first.size() > 5 && kv.first.compare(kv.first.size() - 5, 5, ".fc_2") == 0)
+            m->layers[kv.second].frag = false;   // consumed by r3d_decode_f32
     m->host_weights.resize(m->specs.size());
     m->have.assign(m->specs.size(), false);
     return m;
@@ -293,11 +297,16 @@ int model_finalize(Model *m) {
         f.scale_shift(L, s, t);
         const float *w = f.get(L.weight_key);
         float *dst = m->arena.data() + L.w_off;
-        // torch layout (N, cin, taps) [Linear: taps == 1]; GEMM column index = tap*cin + c
+        // torch layout (N, cin, taps) [Linear: taps == 1]; GEMM column index = tap*cin + c.
+        // GEMM layers are stored in MFMA fragment order (see r3d_kernels.hip), the decoder tail row-major.
+        const int nk = L.Kpad / BK;
         for (int o = 0; o < L.N; ++o)
             for (int c = 0; c < L.cin; ++c)
-                for (int j = 0; j < L.taps; ++j)
-                    dst[(size_t)o * L.Kpad + j * L.cin + c] = (float)((double)w[((size_t)o * L.cin + c) * L.taps + j] * s[o]);
+                for (int j = 0; j < L.taps; ++j) {
+                    const int k = j * L.cin + c;
+                    const float v = (float)((double)w[((size_t)o * L.cin + c) * L.taps + j] * s[o]);
+                    dst[L.frag ? frag_index(o, k, nk) : (size_t)o * L.Kpad + k] = v;
+                }
         float *bd = m->arena.data() + L.b_off;
         for (int o = 0; o < L.N; ++o) bd[o] = (float)t[o];
     }

@@ -5,7 +5,7 @@
 // With one workgroup per CU the only scheduling freedom is how many units each workgroup gets, so
 // the host cuts the unit sequence into `nwg` contiguous chunks of (nearly) equal cost.  Contiguity
 // keeps a workgroup - and, through the XCD-aware chunk order in the kernel, an XCD - on one
-// problem's weights.  A chunk is then emitted as tiles of at most 8 units (BM <= 256 rows).
+// problem's weights.  A chunk is then emitted as tiles of at most 6 units (BM <= 192 rows).
 // This replaces the hardware dispatcher's "first free slot" placement, which left the second
 // round of 128x128 tiles one-third occupied (profiles/r01_v0/pmc_table.txt).
 #include <algorithm>
@@ -51,8 +51,8 @@ double unit_cycles(int nk) { return nk * (2048.0 + 120.0) + 1500.0; }
 
 }  // namespace
 
-void schedule_stage(const std::vector<SchedProb> &probs, int nwg, std::vector<int4> &tiles, std::vector<int> &wgoff,
-                    StageSchedule &out) {
+void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units, std::vector<int4> &tiles,
+                    std::vector<int> &wgoff, StageSchedule &out) {
     std::vector<Segment> segs;
     double total = 0;
     for (int i = 0; i < (int)probs.size(); ++i) {
@@ -89,8 +89,8 @@ void schedule_stage(const std::vector<SchedProb> &probs, int nwg, std::vector<in
             take = std::max(take, chunk_cost == 0 ? 1 : 0);
             take = std::min(take, s.units - u);
             if (take > 0) {
-                // emit `take` units as evenly sized tiles of <= 8 units
-                const int nt = (take + 7) / 8;
+                // emit `take` units as evenly sized tiles of <= max_units units
+                const int nt = (take + max_units - 1) / max_units;
                 int done = 0;
                 for (int k = 0; k < nt; ++k) {
                     const int sz = (take - done + (nt - k) - 1) / (nt - k);
@@ -121,7 +121,7 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
         flops += q.flops_per_window * (double)B;
         bytes += 4.0 * ((double)M * L.K + (double)L.N * L.K + (double)M * L.N * (q.res_buf >= 0 ? 2.0 : 1.0));
     }
-    schedule_stage(probs, nwg, tiles, wgoff, out);
+    schedule_stage(probs, nwg, 6, tiles, wgoff, out);
     out.flops = flops;
     out.bytes = bytes;
 }

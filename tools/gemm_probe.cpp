@@ -23,10 +23,14 @@ int main(int argc, char **argv) {
     const int N = argc > 3 ? atoi(argv[3]) : 256;
     const int K = argc > 4 ? atoi(argv[4]) : 768;
     const int reps = argc > 5 ? atoi(argv[5]) : 20;
+    const int enc = argc > 6 ? atoi(argv[6]) : 0;   // 1: fused-prologue operand (M must be a multiple of 81)
     const int Npad = round_up(N, 256);
     std::vector<float> hA((size_t)M * K), hW((size_t)Npad * K, 0.f), hb(Npad, 0.f);
     for (size_t i = 0; i < hA.size(); ++i) hA[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
-    for (size_t i = 0; i < (size_t)N * K; ++i) hW[i] = (float)((i * 40503u) % 2001) / 1000.f - 1.f;
+    std::vector<float> hWr((size_t)Npad * K, 0.f);   // row-major reference copy; hW is fragment-ordered
+    for (size_t i = 0; i < (size_t)N * K; ++i) hWr[i] = (float)((i * 40503u) % 2001) / 1000.f - 1.f;
+    for (int o = 0; o < N; ++o)
+        for (int k = 0; k < K; ++k) hW[frag_index(o, k, K / BK)] = hWr[(size_t)o * K + k];
     LaunchArgs la;
     memset(&la, 0, sizeof la);
     la.nprob = nprob;
@@ -35,6 +39,22 @@ int main(int argc, char **argv) {
     CK(hipMalloc((void **)&dbias, Npad * 4));
     CK(hipMemcpy(dbias, hb.data(), Npad * 4, hipMemcpyHostToDevice));
     std::vector<SchedProb> sp;
+    // fused-prologue inputs: windows of 243 frames x 51 floats, LUT shaped like a temporal branch's
+    float *dx = nullptr; int *dlut = nullptr;
+    std::vector<float> hx; std::vector<int> hlut(K);
+    if (enc) {
+        const int nwin = M / 81;
+        hx.resize((size_t)nwin * 243 * 51);
+        for (size_t i = 0; i < hx.size(); ++i) hx[i] = (float)((i * 2246822519u) % 2001) / 1000.f - 1.f;
+        for (int k = 0; k < K; ++k) {
+            const int tap = (k * 3) / K, kind = k % 3, src = (k * 7) % 51;
+            hlut[k] = encode_lut_entry(tap * 51 + src, kind == 1 ? tap * 51 + src % 3 : src, kind, 0);
+        }
+        CK(hipMalloc((void **)&dx, hx.size() * 4));
+        CK(hipMalloc((void **)&dlut, K * 4));
+        CK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dlut, hlut.data(), K * 4, hipMemcpyHostToDevice));
+    }
     for (int i = 0; i < nprob; ++i) {
         CK(hipMalloc((void **)&dA[i], hA.size() * 4));
         CK(hipMalloc((void **)&dW[i], hW.size() * 4));
@@ -45,13 +65,14 @@ int main(int argc, char **argv) {
         for (int s = 0; s < MAX_SEG; ++s) { g.a[s] = dA[i]; g.lda[s] = K; g.kend[s] = 0x7fffffff; }
         g.w = dW[i]; g.bias = dbias; g.res = nullptr; g.c = dC[i]; g.ldr = 0; g.ldc = N;
         g.M = M; g.N = N; g.K = K; g.slope = 0.2f;
+        if (enc) { g.lut = dlut; g.x = dx; g.enc_ws = 243 * 51; g.enc_rows = 81; g.enc_jf = 51; g.enc_cur = 81 * 51; g.enc_bytes = (unsigned)(hx.size() * 4); }
         sp.push_back({M, N, K / BK});
     }
     std::vector<int4> tiles;
     std::vector<int> wgoff;
     StageSchedule ss{};
     const int nwg = device_cu_count();
-    schedule_stage(sp, nwg, tiles, wgoff, ss);
+    schedule_stage(sp, nwg, 6, tiles, wgoff, ss);
     int4 *dt; int *dwg; long long *ddbg;
     CK(hipMalloc((void **)&dt, tiles.size() * sizeof(int4)));
     CK(hipMalloc((void **)&dwg, wgoff.size() * sizeof(int)));
@@ -63,12 +84,12 @@ int main(int argc, char **argv) {
     printf("grid %d tiles %d imbalance %.3f (CUs %d)\n", ss.nwg, ss.ntiles, ss.imbalance, nwg);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) CK(launch_gemm_stage(la, ss.nwg, false, 0));
+    for (int i = 0; i < 3; ++i) CK(launch_gemm_stage(la, ss.nwg, enc != 0, 0));
     CK(hipDeviceSynchronize());
     float best = 1e9, sum = 0;
     for (int i = 0; i < reps; ++i) {
         CK(hipEventRecord(e0, 0));
-        CK(launch_gemm_stage(la, ss.nwg, false, 0));
+        CK(launch_gemm_stage(la, ss.nwg, enc != 0, 0));
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -84,7 +105,16 @@ int main(int argc, char **argv) {
     for (int t = 0; t < 64; ++t) {
         const int r = (t * 7919) % M, c = (t * 104729) % N;
         double acc = 0;
-        for (int k = 0; k < K; ++k) acc += (double)hA[(size_t)r * K + k] * hW[(size_t)c * K + k];
+        for (int k = 0; k < K; ++k) {
+            double a = hA[(size_t)r * K + k];
+            if (enc) {
+                const int code = hlut[k], kind = (code >> 20) & 3, win = r / 81, t3 = r % 81;
+                const size_t first = (size_t)win * 243 * 51 + (size_t)t3 * 3 * 51, cur = (size_t)win * 243 * 51 + 81 * 51;
+                const double v1 = hx[first + (code & 1023)], v2 = hx[(kind == 2 ? cur : first) + ((code >> 10) & 1023)];
+                a = kind == 0 ? v1 : v1 - v2;
+            }
+            acc += a * hWr[(size_t)c * K + k];
+        }
         acc = acc > 0 ? acc : 0.2 * acc;
         const double err = fabs(acc - hC[(size_t)r * N + c]) / (1.0 + fabs(acc));
         maxerr = err > maxerr ? err : maxerr;
@@ -108,12 +138,18 @@ int main(int argc, char **argv) {
     }
     std::vector<long long> hd(4 * 256);
     CK(hipMemcpy(hd.data(), ddbg, hd.size() * 8, hipMemcpyDeviceToHost));
-    for (int w = 0; w < 2; ++w) {
-        printf("chunk %d (last tile): per K tile cycles  [loads-issue | reads+mfma | lds-write | barrier | total]\n", w);
-        const long long *d = hd.data() + w * 256;
-        for (int kt = 0; kt < 24 && kt < K / BK; ++kt)
-            printf("  kt %2d: %6lld %6lld %6lld %6lld | %6lld\n", kt, d[kt * 8 + 1] - d[kt * 8 + 0], d[kt * 8 + 2] - d[kt * 8 + 1],
-                   d[kt * 8 + 3] - d[kt * 8 + 2], d[kt * 8 + 4] - d[kt * 8 + 3], (kt ? d[kt * 8] - d[(kt - 1) * 8] : 0));
+    // chunk 1 (chunk 0 also pays for the first-touch of everything): timeline of its 8 wavefronts over the
+    // first 4 K tiles of its last tile, relative to wave 0's first stamp
+    const long long *d = hd.data() + 1 * 256;
+    const long long t0 = d[0];
+    printf("wave: per K tile [top, loads-issued, mfma-done, lds-written, barrier-passed] (cycles since wave0 kt0 top)\n");
+    for (int w = 0; w < 8; ++w) {
+        printf("  w%d:", w);
+        for (int kt = 0; kt < 3; ++kt) {
+            const long long *e = d + w * 32 + kt * 8;
+            printf("  | %6lld %6lld %6lld %6lld %6lld", e[0] - t0, e[1] - t0, e[2] - t0, e[3] - t0, e[4] - t0);
+        }
+        printf("\n");
     }
 #endif
     return 0;
