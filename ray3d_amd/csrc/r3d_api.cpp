@@ -169,6 +169,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         la.tiles = sched->d_tiles + ss.tiles_off;
         la.wg_off = sched->d_wgoff + ss.wgoff_off;
         la.nprob = (int)st.size();
+        la.ks = ss.ks;
         int n_enc = 0;
         for (int i = 0; i < la.nprob; ++i) {
             const ProbSpec &q = pl->probs[st[i]];

@@ -51,7 +51,7 @@ struct LaunchArgs {
     const int4 *tiles;    // {problem | MI << 8, first row, first column, 0}
     const int *wg_off;    // [grid + 1]: chunk c executes tiles [wg_off[c], wg_off[c+1])
     int nprob;
-    int pad_;
+    int ks;               // 1, or 2 = split-K tiles (128 columns, K halves added through LDS)
     long long *dbg;       // optional phase timestamps (R3D_TIMING builds only)
     GemmProb p[MAX_PROB];
 };
@@ -182,6 +182,7 @@ struct ProbSpec {
 // Per-(plan, batch) work distribution of the persistent GEMM launches.
 struct StageSchedule {
     int nwg;               // grid size
+    int ks;                // split-K factor of this launch's tiles (1 or 2)
     int ntiles;
     size_t tiles_off;      // offsets (in int4 / int) into Schedule::d_tiles / d_wgoff
     size_t wgoff_off;
@@ -222,7 +223,7 @@ Model *model_create(const r3d_config &cfg);
 int model_set_weight(Model *m, const char *key, const float *host, const int64_t *shape, int rank);
 int model_finalize(Model *m);
 Plan *plan_get(Model *a, Model *b);
-struct SchedProb { int M, N, nk; };
+struct SchedProb { int M, N, nk; bool plain; };   // plain: single-buffer operand (eligible for split-K tiles)
 void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units, std::vector<int4> &tiles,
                     std::vector<int> &wgoff, StageSchedule &out);
 // index of weight element (output channel o, GEMM column k) in the fragment-ordered packing

@@ -70,16 +70,25 @@ constexpr int GEMM_LDS_BYTES = GEMM_STAGES * STAGE_FLOATS * 4 + LUT_LDS_INTS * 4
 typedef const LaunchArgs __attribute__((address_space(4))) *LaunchArgsPtr;
 typedef const GemmProb __attribute__((address_space(4))) &ProbRef;
 
-template <int MI, bool ENC>
+// KS = 2 ("split-K inside the workgroup") serves levels with too few row units to occupy the chip: the
+// tile is 128 columns wide, wavefronts 0-3 take the even and wavefronts 4-7 the odd 32-wide K tiles
+// of the same 128 columns, and the two partial sums are added through LDS at the end.  Twice as many
+// tiles, each with half as many K-loop iterations.
+template <int MI, bool ENC, int KS>
 __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int col0, const bool new_prob, float *smem,
                                           long long *dbg) {
-    constexpr int NA = (MI + 1) / 2;        // A staging slots per thread (64 rows per slot)
+    static_assert(KS == 1 || (KS == 2 && !ENC && MI <= 2), "split-K tiles are small plain tiles");
+    constexpr int VR = KS * MI * 32;        // staged rows per iteration (KS sub-tiles of MI*32 rows x 32 k)
+    constexpr int NA = (VR + 63) / 64;      // A staging slots per thread (64 staged rows per slot)
     constexpr bool PRE = MI <= 3;           // pre-read next tile's first A fragments before the barrier
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
+    const int wn = KS == 2 ? (wave & 3) : wave;     // 32-column block of the tile this wavefront owns
+    const int wk = KS == 2 ? (wave >> 2) : 0;       // which 32-wide K tile of an iteration it multiplies
     const int M = P.M, N = P.N, K = P.K;
-    const int nk = K / BK;
+    const int nk32 = K / BK;                        // 32-wide K tiles
+    const int nk = (nk32 + KS - 1) / KS;            // K-loop iterations
     const int srow = tid >> 3, a_kq = (tid & 7) * 4;
     int *lut_lds = reinterpret_cast<int *>(smem + GEMM_STAGES * STAGE_FLOATS);
 
@@ -87,10 +96,11 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
     int a_row[NA];
     int a_voff[ENC ? 1 : NA];               // plain mode: byte offset of the slot's row/column inside the tile's rows
     unsigned e_first[ENC ? NA : 1], e_cur[ENC ? NA : 1];   // element indices into the raw input
-    const bool multi = !ENC && P.kend[0] < K;   // A is a virtual concatenation of several buffers
+    const bool multi = !ENC && KS == 1 && P.kend[0] < K;   // A is a virtual concatenation of several buffers
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int gr = row0 + srow + 64 * i;
+        const int vr = srow + 64 * i, sub = vr / (MI * 32);       // staged row -> (sub-tile, row of the tile)
+        const int gr = row0 + vr - sub * (MI * 32);
         a_row[i] = gr < M ? gr : M - 1;
         if (ENC) {
             // where the staged row's first frame and its window's "current" frame start in the raw input
@@ -99,7 +109,7 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
             e_first[i] = wbase + (unsigned)(t3 * 3 * P.enc_jf);
             e_cur[i] = wbase + (unsigned)P.enc_cur;
         } else {
-            a_voff[i] = ((a_row[i] - row0) * P.lda[0] + a_kq) * 4;
+            a_voff[i] = ((a_row[i] - row0) * P.lda[0] + a_kq + sub * BK) * 4;
         }
     }
     // Plain operands are read through buffer descriptors whose base (first row of the tile) and K-tile
@@ -149,7 +159,7 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
     };
     Staged ra, ra2;                         // tiles in flight: even / odd tile index
     auto issue_a = [&](int kt, Staged &R) {
-        const int kb = kt * BK;
+        const int kb = kt * (BK * KS);
         if (ENC) {
             // A[row][k] = x[first/cur + off1] - x[first/cur + off2]: ray differences and body-part
             // gather (lib/model/rie.py:290-357) evaluated while staging; nothing is materialised
@@ -208,13 +218,15 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
     // ---- W fragments: [(n/32)][k tile][q][lane][4] in HBM, this wavefront's 32 columns
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // make the descriptor provably wave-uniform
     __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(P.w + ((size_t)((col0 >> 5) + wave_u) * nk) * 1024), 0, nk * 4096, 0x00020000);
+        const_cast<float *>(P.w + ((size_t)((col0 >> 5) + (KS == 2 ? (wave_u & 3) : wave_u)) * nk32) * 1024), 0, nk32 * 4096,
+        0x00020000);   // (K tiles past the end read as zeros through the descriptor's bound)
     const int w_voff = lane * 16;
     f32x4 rb[4], rbn[4];                    // W fragments of the current and the next K tile
     auto load_w = [&](int kt, f32x4 (&dst)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            dst[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff + q * 1024, kt * 4096, 0));
+            dst[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                wrsrc, w_voff + q * 1024, (kt * KS + (KS == 2 ? (wave_u >> 2) : 0)) * 4096, 0));
     };
 
     f32x16 acc[MI];
@@ -223,7 +235,7 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][r] = 0.0f;
 
-    const int a_frag = li * LDS_LD + lh * 16;
+    const int a_frag = (wk * MI * 32 + li) * LDS_LD + lh * 16;
     f32x4 av0[PRE ? MI : 1];
 
     // ---- prologue: tiles 0 and 1 into LDS, tile 2 in flight, W(0) in registers
@@ -254,7 +266,6 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
 #else
 #define R3D_STAMP(slot) do { } while (0)
 #endif
-    (void)wave_u;
     int st_cur = 0;                              // kt % 3 without a division
     // One K tile.  `w_use` holds this tile's W fragments, `w_load` receives the next tile's: the two
     // register sets swap roles every tile (loop unrolled by two) instead of being copied - a copy
@@ -273,6 +284,7 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
         prep_seg(kt + 5 < last ? kt + 5 : last);
         R3D_STAMP(1);
         const float *s = smem + st_cur * STAGE_FLOATS + a_frag;
+        if (KS == 1 || kt * KS + (wave_u >> 2) < nk32)   // (odd K-tile count: the last iteration has one tile only)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 av[MI];
@@ -308,13 +320,29 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
     // epilogue: C = res + lrelu(acc + bias).  C/D layout of the 32x32 MFMA: col = lane & 31,
     // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  A wavefront store instruction writes two
     // 128-byte row pieces (lanes 0-31 and 32-63).
-    const int col = col0 + wave * 32 + li;
+    if (KS == 2) {
+        // add the odd-K-tile partial sums (wavefronts 4-7) to the even ones through LDS (ring is idle now)
+        float *red = smem + ((wn * MI) * 16) * 64 + lane;
+        if (wk == 1) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(mi * 16 + r) * 64] = acc[mi][r];
+        }
+        __syncthreads();
+        if (wk == 1) return;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][r] += red[(mi * 16 + r) * 64];
+    }
+    const int col = col0 + wn * 32 + li;
     const float slope = P.slope;
     const float *res = P.res;
     float *c = P.c;
     const int ldc = P.ldc, ldr = P.ldr;
     const float bias = gload1(P.bias + col);
-    const bool full = (row0 + MI * 32 <= M) && (col0 + GEMM_BN <= N);   // wave-uniform
+    const bool full = (row0 + MI * 32 <= M) && (col0 + GEMM_BN / KS <= N);   // wave-uniform
     if (full) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
@@ -366,6 +394,7 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
     }
 #endif
     int prev_pi = -1;
+    const int ks = args->ks;
     for (int t = t0; t < t1; ++t) {
         const int4 td = args->tiles[t];
         const int pi = __builtin_amdgcn_readfirstlane(td.x & 0xff);
@@ -375,13 +404,19 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
         const int row0 = __builtin_amdgcn_readfirstlane(td.y);
         const int col0 = __builtin_amdgcn_readfirstlane(td.z);
         ProbRef P = args->p[pi];
+        if (!ENC && ks == 2) {
+            if (mi == 1) gemm_tile<1, false, 2>(P, row0, col0, new_prob, smem, dbg);
+            else gemm_tile<2, false, 2>(P, row0, col0, new_prob, smem, dbg);
+            __syncthreads();   // (half of the wavefronts leave a split-K tile early)
+            continue;
+        }
         switch (mi) {
-            case 1: gemm_tile<1, ENC>(P, row0, col0, new_prob, smem, dbg); break;
-            case 2: gemm_tile<2, ENC>(P, row0, col0, new_prob, smem, dbg); break;
-            case 3: gemm_tile<3, ENC>(P, row0, col0, new_prob, smem, dbg); break;
-            case 4: gemm_tile<4, ENC>(P, row0, col0, new_prob, smem, dbg); break;
-            case 5: gemm_tile<5, ENC>(P, row0, col0, new_prob, smem, dbg); break;
-            default: gemm_tile<6, ENC>(P, row0, col0, new_prob, smem, dbg); break;
+            case 1: gemm_tile<1, ENC, 1>(P, row0, col0, new_prob, smem, dbg); break;
+            case 2: gemm_tile<2, ENC, 1>(P, row0, col0, new_prob, smem, dbg); break;
+            case 3: gemm_tile<3, ENC, 1>(P, row0, col0, new_prob, smem, dbg); break;
+            case 4: gemm_tile<4, ENC, 1>(P, row0, col0, new_prob, smem, dbg); break;
+            case 5: gemm_tile<5, ENC, 1>(P, row0, col0, new_prob, smem, dbg); break;
+            default: gemm_tile<6, ENC, 1>(P, row0, col0, new_prob, smem, dbg); break;
         }
     }
 #ifdef R3D_TIMING

@@ -53,13 +53,26 @@ double unit_cycles(int nk) { return nk * (2048.0 + 120.0) + 1500.0; }
 
 void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units, std::vector<int4> &tiles,
                     std::vector<int> &wgoff, StageSchedule &out) {
+    // Launches that cannot give every CU a unit switch to split-K tiles (128 columns wide, the two K
+    // halves computed by different wavefronts of the workgroup): twice the units, half the K loop.
+    long long units256 = 0;
+    bool all_plain = true;
+    for (const auto &p : probs) {
+        units256 += (long long)((p.M + 31) / 32) * ((p.N + 255) / 256);
+        all_plain = all_plain && p.plain;
+    }
+    const int ks = (all_plain && units256 * 2 <= (long long)nwg) ? 2 : 1;   // only pays when the doubled units still fit one round
+    out.ks = ks;
+    if (ks == 2) max_units = 2;
+    const int bn = 256 / ks;
     std::vector<Segment> segs;
     double total = 0;
     for (int i = 0; i < (int)probs.size(); ++i) {
         const int units = (probs[i].M + 31) / 32;
-        for (int c0 = 0; c0 < probs[i].N; c0 += 256) {
-            segs.push_back({i, c0, units, probs[i].M, unit_cycles(probs[i].nk)});
-            total += units * unit_cycles(probs[i].nk);
+        const double cost = unit_cycles((probs[i].nk + ks - 1) / ks);
+        for (int c0 = 0; c0 < probs[i].N; c0 += bn) {
+            segs.push_back({i, c0, units, probs[i].M, cost});
+            total += units * cost;
         }
     }
     long long total_units = 0;
@@ -117,7 +130,7 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
         const ProbSpec &q = pl->probs[st[i]];
         const Layer &L = pl->m[q.model]->layers[q.layer];
         const int M = (int)(B * q.rows_per_window);
-        probs.push_back({M, L.N, L.Kpad / BK});
+        probs.push_back({M, L.N, L.Kpad / BK, q.enc_lut < 0 && q.nseg == 1});
         flops += q.flops_per_window * (double)B;
         bytes += 4.0 * ((double)M * L.K + (double)L.N * L.K + (double)M * L.N * (q.res_buf >= 0 ? 2.0 : 1.0));
     }

@@ -164,8 +164,10 @@ def test_full_size_batch_properties():
         halves = torch.cat([lifter(xd[:100].contiguous(), pd[:100].contiguous()),
                             lifter(xd[100:].contiguous(), pd[100:].contiguous())])
     assert torch.equal(full, again)                                   # deterministic (no atomics)
-    assert (full[perm] - permuted).abs().max().item() <= 2e-5         # windows are independent
-    assert (full - halves).abs().max().item() <= 2e-5
+    # different batch sizes get different tile schedules (incl. split-K tiles), i.e. different fp32
+    # summation orders: agreement is to rounding noise of the ~14-layer chain, not bit-exact
+    assert (full[perm] - permuted).abs().max().item() <= 6e-5         # windows are independent
+    assert (full - halves).abs().max().item() <= 6e-5
     idx = [0, 77, 255]
     ref = oracle.forward(cp, sp, x[idx], p[idx]) + oracle.forward(ct, st, x[idx], p[idx])
     assert np.abs(full[idx].cpu().numpy() - ref).max() <= tol_for(ref)
@@ -187,7 +189,7 @@ def test_large_batch_1024():
         big = lifter(x, p)
         parts = torch.cat([lifter(x[i:i + 256].contiguous(), p[i:i + 256].contiguous()) for i in range(0, 1024, 256)])
     assert torch.isfinite(big).all()
-    assert (big - parts).abs().max().item() <= 2e-5
+    assert (big - parts).abs().max().item() <= 6e-5
 
 
 def test_weight_update_is_picked_up():

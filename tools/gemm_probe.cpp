@@ -66,7 +66,7 @@ int main(int argc, char **argv) {
         g.w = dW[i]; g.bias = dbias; g.res = nullptr; g.c = dC[i]; g.ldr = 0; g.ldc = N;
         g.M = M; g.N = N; g.K = K; g.slope = 0.2f;
         if (enc) { g.lut = dlut; g.x = dx; g.enc_ws = 243 * 51; g.enc_rows = 81; g.enc_jf = 51; g.enc_cur = 81 * 51; g.enc_bytes = (unsigned)(hx.size() * 4); }
-        sp.push_back({M, N, K / BK});
+        sp.push_back({M, N, K / BK, enc == 0});
     }
     std::vector<int4> tiles;
     std::vector<int> wgoff;
@@ -80,8 +80,8 @@ int main(int argc, char **argv) {
     CK(hipMemset(ddbg, 0, (1024 + 4 * 1024) * 8));
     CK(hipMemcpy(dt, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice));
     CK(hipMemcpy(dwg, wgoff.data(), wgoff.size() * sizeof(int), hipMemcpyHostToDevice));
-    la.tiles = dt; la.wg_off = dwg; la.dbg = ddbg;
-    printf("grid %d tiles %d imbalance %.3f (CUs %d)\n", ss.nwg, ss.ntiles, ss.imbalance, nwg);
+    la.tiles = dt; la.wg_off = dwg; la.dbg = ddbg; la.ks = ss.ks;
+    printf("grid %d tiles %d ks %d imbalance %.3f (CUs %d)\n", ss.nwg, ss.ntiles, ss.ks, ss.imbalance, nwg);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) CK(launch_gemm_stage(la, ss.nwg, enc != 0, 0));
