@@ -36,13 +36,15 @@ struct GemmProb {
     // --- fused feature-encoding prologue (first layers only; lut == nullptr otherwise) ---
     // A[row][col] is computed on the fly from the raw input instead of being read from memory:
     // row = window * enc_rows + t3 covers input frames 3*t3 .. 3*t3+2 of that window.
-    const int *lut;           // K entries, see encode_lut_entry()
+    const int *lut;           // three tables: minuend byte offsets [K], subtrahend byte offsets [K], chunk flags [K/4]
     const float *x;           // (frames, J*F) ray-encoded keypoints
     long long enc_ws;         // window stride in elements (frames * J*F)
     int enc_rows;             // GEMM rows per window (RF/3 for a temporal branch, 1 for GlobalInfo)
     int enc_jf;               // J*F
     int enc_cur;              // element offset of the "current" frame inside a window (tcur * J*F)
     unsigned enc_bytes;       // size of the raw input in bytes (buffer-descriptor bound)
+    int enc_cur_rel;          // 1: minuends are relative to the window's "current" frame (GlobalInfo input)
+    int pad2_;
 };
 
 // Kernel argument of one persistent GEMM launch.  `tiles`/`wg_off` live in HBM (built once per
@@ -114,6 +116,7 @@ struct Layer {
     int cin;                  // input channels per tap
     int N, K, Npad, Kpad;     // K = taps*cin
     float slope;
+    std::vector<int> colmap;  // optional: GEMM column of torch column (tap*cin + c); empty = identity
     bool frag;                // packed in MFMA fragment order (GEMM layers) or row-major [N][Kpad] (decoder tail)
     size_t w_off, b_off;      // offsets (floats) into the packed arena
 };
@@ -223,7 +226,11 @@ Model *model_create(const r3d_config &cfg);
 int model_set_weight(Model *m, const char *key, const float *host, const int64_t *shape, int rank);
 int model_finalize(Model *m);
 Plan *plan_get(Model *a, Model *b);
-struct SchedProb { int M, N, nk; bool plain; };   // plain: single-buffer operand (eligible for split-K tiles)
+struct SchedProb {
+    int M, N, nk;
+    bool plain;      // single-buffer operand (eligible for split-K tiles)
+    int max_units;   // per-problem cap on 32-row units per tile (0 = the launch default)
+};
 void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units, std::vector<int4> &tiles,
                     std::vector<int> &wgoff, StageSchedule &out);
 // index of weight element (output channel o, GEMM column k) in the fragment-ordered packing
@@ -241,16 +248,18 @@ hipError_t launch_decode(const DecodeArgs &args, hipStream_t stream);
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-// LUT entry of the fused feature-encoding prologue.  A[row][col] = x[base + off1] - x[base2 + off2]:
-//   bits [9:0]   off1: element offset of the minuend from the row's first frame (tap*J*F + joint*F + f)
-//   bits [19:10] off2: element offset of the subtrahend
-//   bits [21:20] kind: 0 = x (no subtrahend), 1 = x - root joint of the same frame (rie.py:301),
-//                      2 = x - same element of the window's "current" frame (rie.py:304; off2 is
-//                      relative to that frame), 3 = zero padding column
-//   bit  22      minuend is relative to the "current" frame instead of the row's first frame
-//                (GlobalInfo input, rie.py:290-292)
-inline int encode_lut_entry(int off1, int off2, int kind, int cur_rel) {
-    return (off1 & 1023) | ((off2 & 1023) << 10) | ((kind & 3) << 20) | ((cur_rel & 1) << 22);
-}
+// Fused feature-encoding prologue tables (built in r3d_model.cpp, consumed by r3d_gemm_enc_f32).
+// The K columns of a first layer are ORDERED BY KIND - all plain values x, then all x - root, then all
+// x - x_current, each group padded to a multiple of four columns - so that the four columns one
+// staging thread handles always share their kind.  (The reference's channel order cat(x, diff, diff_t)
+// per tap, rie.py:308-315, only exists in the packed weight's column map.)  Per column k:
+//   lut1[k] = byte offset of the minuend from the row's first frame (or from the window's current
+//             frame for GlobalInfo), ENC_INVALID for padding columns;
+//   lut2[k] = byte offset of the subtrahend - root joint of the same frame (rie.py:301) relative to
+//             the row's first frame, or the same element of the current frame (rie.py:304) relative
+//             to that frame - ENC_INVALID when there is none;
+//   lutk[k/4] = 1 when the chunk's subtrahends are current-frame relative.
+// ENC_INVALID pushes the address past the buffer descriptor's bound: the load returns 0.
+constexpr int ENC_INVALID = (int)0x80000000u;
 
 }  // namespace r3d

@@ -64,8 +64,8 @@ constexpr int GEMM_BN = 256;
 constexpr int GEMM_MAX_MI = 6;
 constexpr int GEMM_STAGES = 3;
 constexpr int STAGE_FLOATS = GEMM_MAX_MI * 32 * LDS_LD;                  // one A tile: 27,648 B
-constexpr int LUT_LDS_INTS = 512;                                        // fused-prologue LUT copy
-constexpr int GEMM_LDS_BYTES = GEMM_STAGES * STAGE_FLOATS * 4 + LUT_LDS_INTS * 4;   // 84,992 B
+constexpr int LUT_LDS_INTS = 1152;                                       // fused-prologue tables: 2K + K/4 ints, K <= 480
+constexpr int GEMM_LDS_BYTES = GEMM_STAGES * STAGE_FLOATS * 4;                      // 82,944 B
 
 typedef const LaunchArgs __attribute__((address_space(4))) *LaunchArgsPtr;
 typedef const GemmProb __attribute__((address_space(4))) &ProbRef;
@@ -74,10 +74,10 @@ typedef const GemmProb __attribute__((address_space(4))) &ProbRef;
 // tile is 128 columns wide, wavefronts 0-3 take the even and wavefronts 4-7 the odd 32-wide K tiles
 // of the same 128 columns, and the two partial sums are added through LDS at the end.  Twice as many
 // tiles, each with half as many K-loop iterations.
-template <int MI, bool ENC, int KS>
+template <int MI, int KS>
 __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int col0, const bool new_prob, float *smem,
                                           long long *dbg) {
-    static_assert(KS == 1 || (KS == 2 && !ENC && MI <= 2), "split-K tiles are small plain tiles");
+    static_assert(KS == 1 || (KS == 2 && MI <= 2), "split-K tiles are small tiles");
     constexpr int VR = KS * MI * 32;        // staged rows per iteration (KS sub-tiles of MI*32 rows x 32 k)
     constexpr int NA = (VR + 63) / 64;      // A staging slots per thread (64 staged rows per slot)
     constexpr bool PRE = MI <= 3;           // pre-read next tile's first A fragments before the barrier
@@ -90,34 +90,25 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
     const int nk32 = K / BK;                        // 32-wide K tiles
     const int nk = (nk32 + KS - 1) / KS;            // K-loop iterations
     const int srow = tid >> 3, a_kq = (tid & 7) * 4;
-    int *lut_lds = reinterpret_cast<int *>(smem + GEMM_STAGES * STAGE_FLOATS);
 
     // ---- A staging state
     int a_row[NA];
-    int a_voff[ENC ? 1 : NA];               // plain mode: byte offset of the slot's row/column inside the tile's rows
-    unsigned e_first[ENC ? NA : 1], e_cur[ENC ? NA : 1];   // element indices into the raw input
-    const bool multi = !ENC && KS == 1 && P.kend[0] < K;   // A is a virtual concatenation of several buffers
+    int a_voff[NA];                         // byte offset of the slot's row/column inside the tile's rows
+    const bool multi = KS == 1 && P.kend[0] < K;   // A is a virtual concatenation of several buffers
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int vr = srow + 64 * i, sub = vr / (MI * 32);       // staged row -> (sub-tile, row of the tile)
+        // staged row -> (sub-tile, row of the tile); staged rows past the tile (odd MI) re-read valid data
+        const int vr = srow + 64 * i, sub = KS == 1 ? 0 : (vr / (MI * 32) < KS ? vr / (MI * 32) : KS - 1);
         const int gr = row0 + vr - sub * (MI * 32);
         a_row[i] = gr < M ? gr : M - 1;
-        if (ENC) {
-            // where the staged row's first frame and its window's "current" frame start in the raw input
-            const int win = a_row[i] / P.enc_rows, t3 = a_row[i] - win * P.enc_rows;
-            const unsigned wbase = (unsigned)win * (unsigned)P.enc_ws;
-            e_first[i] = wbase + (unsigned)(t3 * 3 * P.enc_jf);
-            e_cur[i] = wbase + (unsigned)P.enc_cur;
-        } else {
-            a_voff[i] = ((a_row[i] - row0) * P.lda[0] + a_kq + sub * BK) * 4;
-        }
+        a_voff[i] = ((a_row[i] - row0) * P.lda[0] + a_kq + sub * BK) * 4;
     }
     // Plain operands are read through buffer descriptors whose base (first row of the tile) and K-tile
     // offset are scalars: a staging load is ONE instruction with no vector address arithmetic.  That
     // matters because a wavefront's VALU instructions crawl (about one per 64 cycles) while its SIMD
     // partner streams MFMAs, whereas memory instructions issue freely.
     __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(ENC ? P.bias : P.a[0] + (size_t)row0 * P.lda[0]), 0, 0x7fffffff, 0x00020000);
+        const_cast<float *>(P.a[0] + (size_t)row0 * P.lda[0]), 0, 0x7fffffff, 0x00020000);
     // concatenated operands: K tiles are issued in increasing order, so the segment state (buffer, leading
     // dimension, first/last K) only ever advances; the descriptor table is touched at segment
     // boundaries only (<= 3 times per tile).  No scalar loads in the steady-state loop: an SMEM load in
@@ -142,41 +133,13 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
         a_rel[i] = (a_row[i] - row0) * 4;
         m_voff[i] = a_rel[i] * seg_ld + a_kq * 4;
     }
-    if (ENC && new_prob) {
-        // LUT copy: one ds_read_b128 per K tile instead of a dependent global load
-        for (int i = tid; i < K; i += GEMM_THREADS) lut_lds[i] = *(const R3D_AS1 int *)(P.lut + i);
-        __syncthreads();
-    }
-    // raw input through a buffer descriptor: one 32-bit offset add per gathered element instead of
-    // 64-bit pointer arithmetic, and out-of-range reads return 0 instead of faulting
-    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ENC ? P.x : P.bias), 0, ENC ? P.enc_bytes : 0, 0x00020000);
-
-    // raw staging registers: plain mode one float4 per slot; ENC mode minuend / subtrahend / codes
     struct Staged {                         // one A tile on its way from HBM to LDS
-        f32x4 a[NA];                        // plain: the data; ENC: minuends
-        f32x4 s[ENC ? NA : 1];              // ENC: subtrahends
-        int4 code;                          // ENC: LUT entries of this thread's 4 columns
+        f32x4 a[NA];
     };
     Staged ra, ra2;                         // tiles in flight: even / odd tile index
     auto issue_a = [&](int kt, Staged &R) {
         const int kb = kt * (BK * KS);
-        if (ENC) {
-            // A[row][k] = x[first/cur + off1] - x[first/cur + off2]: ray differences and body-part
-            // gather (lib/model/rie.py:290-357) evaluated while staging; nothing is materialised
-            R.code = *reinterpret_cast<const int4 *>(lut_lds + kb + a_kq);
-            const int cd[4] = {R.code.x, R.code.y, R.code.z, R.code.w};
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = cd[e], kind = (c >> 20) & 3;
-                    const unsigned b1 = (c >> 22) & 1 ? e_cur[i] : e_first[i];
-                    const unsigned b2 = kind == 2 ? e_cur[i] : e_first[i];
-                    R.a[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (b1 + (c & 1023)) << 2, 0, 0));
-                    R.s[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (b2 + ((c >> 10) & 1023)) << 2, 0, 0));
-                }
-            }
-        } else {
+        {
             // every slot loads unconditionally (rows past the tile are clamped and never consumed): a
             // predicated load would make the compiler wait for ALL outstanding loads at the merge point
             if (multi) {
@@ -197,19 +160,7 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
     auto commit_a = [&](int stage, const Staged &R) {
         // (stage is uniform: three copies of the stores with immediate offsets, no address arithmetic)
         float *s = stage == 0 ? smem + st_off : stage == 1 ? smem + STAGE_FLOATS + st_off : smem + 2 * STAGE_FLOATS + st_off;
-        if (ENC) {
-            const int cd[4] = {R.code.x, R.code.y, R.code.z, R.code.w};
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int kind = (cd[e] >> 20) & 3;
-                    v[e] = kind == 3 ? 0.0f : (kind == 0 ? R.a[i][e] : R.a[i][e] - R.s[i][e]);
-                }
-                *reinterpret_cast<f32x4 *>(s + i * 64 * LDS_LD) = v;
-            }
-        } else {
+        {
 #pragma unroll
             for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(s + i * 64 * LDS_LD) = R.a[i];
         }
@@ -277,16 +228,10 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
     auto k_tile = [&](int kt, f32x4 (&w_use)[4], f32x4 (&w_load)[4], Staged &stg) {
         R3D_STAMP(0);
         const int st_next = st_cur == 2 ? 0 : st_cur + 1, st_next2 = st_next == 2 ? 0 : st_next + 1;
-        // order matters: the LDS write waits for its (old) loads only if no newer load was issued before it
-        commit_a(st_next2, stg);                     // tile kt+2, issued two iterations ago
-        load_w(kt + 1 < last ? kt + 1 : last, w_load);
-        issue_a(kt + 4 < last ? kt + 4 : last, stg);
-        prep_seg(kt + 5 < last ? kt + 5 : last);
-        R3D_STAMP(1);
         const float *s = smem + st_cur * STAGE_FLOATS + a_frag;
-        if (KS == 1 || kt * KS + (wave_u >> 2) < nk32)   // (odd K-tile count: the last iteration has one tile only)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        const bool active = KS == 1 || kt * KS + (wave_u >> 2) < nk32;   // odd K-tile count: last iteration has one tile
+        auto mfma_q = [&](int q) {
+            if (!active) return;
             f32x4 av[MI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
@@ -298,7 +243,31 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
                     acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][kk], w_use[q][kk], acc[mi], 0, 0, 0);
+        };
+        // Where the staging instructions go.  MI >= 3: after the first MFMAs, in the shadow of this
+        // wavefront's OWN matrix work (a 32x32x2 MFMA occupies the pipe for 64 cycles but issues in a few).
+        // MI <= 2: in front - with one or two accumulators the MFMAs form a dependent chain and any
+        // instruction slipped between them costs ~43 cycles (measured: +10 % on the M=256 MLP levels).
+        constexpr bool INTERLEAVE = MI >= 3;
+        if (!INTERLEAVE) {
+            commit_a(st_next2, stg);                 // tile kt+2, issued two iterations ago (before newer loads: vmcnt order)
+            load_w(kt + 1 < last ? kt + 1 : last, w_load);
+            issue_a(kt + 4 < last ? kt + 4 : last, stg);
+            prep_seg(kt + 5 < last ? kt + 5 : last);
         }
+        R3D_STAMP(1);
+        mfma_q(0);
+        if (INTERLEAVE) {
+            commit_a(st_next2, stg);
+            load_w(kt + 1 < last ? kt + 1 : last, w_load);
+        }
+        mfma_q(1);
+        if (INTERLEAVE) {
+            issue_a(kt + 4 < last ? kt + 4 : last, stg);
+            prep_seg(kt + 5 < last ? kt + 5 : last);
+        }
+        mfma_q(2);
+        mfma_q(3);
         R3D_STAMP(2);
         if (PRE) {
             const float *sn = smem + st_next * STAGE_FLOATS + a_frag;
@@ -373,6 +342,158 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
     }
 }
 
+// ------------------------------------------------------------------------------------ first layers
+//
+// r3d_gemm_enc_f32: expand_conv of every temporal branch and GlobalInfo.fc_1, with the input encoding
+// fused in.  A[row][k] = x[.. + off1] - x[.. + off2] (positional / temporal differences and body-part
+// gather, lib/model/rie.py:290-357; window gather from a batch or a sliding clip,
+// lib/train_val/trainer.py:47-58) is address arithmetic - VALU work - and VALU instructions of a
+// wavefront crawl while its SIMD partner streams MFMAs.  So this kernel does not interleave the two:
+// a tile's WHOLE encoded operand (<= 96 rows x K <= 480) is built in LDS first, then a barrier-free
+// MFMA loop consumes it with the weight fragments streaming from HBM.  Two workgroups share a CU
+// (<= 66 KiB LDS, <= 128 VGPRs each), so one workgroup's encoding overlaps the other's MFMAs.
+
+constexpr int ENC_TILE_BYTES = 64 * 1024;                  // encoded tile: rows * (K + 4) floats
+constexpr int ENC_LDS_BYTES = ENC_TILE_BYTES + LUT_LDS_INTS * 4;
+
+template <int MI>
+__device__ __forceinline__ void enc_tile(ProbRef P, const int row0, const int col0, const bool new_prob, float *smem) {
+    constexpr int R = MI * 32;
+    constexpr int NA = (R + 63) / 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int M = P.M, N = P.N, K = P.K;
+    const int nk = K / BK;
+    const int ldt = K + 4;                                  // (K+4)*4 B = odd multiple of 16 B: conflict-free b128 rows
+    const int srow = tid >> 3, a_kq = (tid & 7) * 4;
+    int *lut_lds = reinterpret_cast<int *>(smem + ENC_TILE_BYTES / 4);
+
+    __syncthreads();                                        // the previous tile's MFMA loop is done with LDS
+    const int *lut1 = lut_lds, *lut2 = lut_lds + K, *lutk = lut_lds + 2 * K;
+    if (new_prob) {
+        for (int i = tid; i < 2 * K + K / 4; i += GEMM_THREADS) lut_lds[i] = *(const R3D_AS1 int *)(P.lut + i);
+        __syncthreads();
+    }
+    // ---- build the encoded operand tile.  Columns are grouped by kind (r3d_internal.hpp), so the four
+    // columns of a staging thread share one subtrahend base; every gathered element costs one integer
+    // add for its address and one subtract - padding / absent operands read 0 through the descriptor.
+    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x), 0, P.enc_bytes, 0x00020000);
+    unsigned b_first[NA], b_cur[NA], b_min[NA];      // byte offsets into the raw input
+    bool on[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int vr = srow + 64 * i;
+        on[i] = vr < R;
+        const int gr = row0 + vr;
+        const int row = gr < M ? gr : M - 1;
+        const int win = row / P.enc_rows, t3 = row - win * P.enc_rows;
+        const unsigned wbase = (unsigned)win * (unsigned)P.enc_ws;
+        b_first[i] = (wbase + (unsigned)(t3 * 3 * P.enc_jf)) * 4;   // first frame of the row (3 frames per row)
+        b_cur[i] = (wbase + (unsigned)P.enc_cur) * 4;               // the window's "current" frame (quirk Q1)
+        b_min[i] = P.enc_cur_rel ? b_cur[i] : b_first[i];
+    }
+    struct Raw { f32x4 a[NA], s[NA]; };
+    auto issue = [&](int kt, Raw &r) {
+        const int k = kt * BK + a_kq;
+        const int4 o1 = *reinterpret_cast<const int4 *>(lut1 + k);
+        const int4 o2 = *reinterpret_cast<const int4 *>(lut2 + k);
+        const bool cur2 = lutk[k >> 2] != 0;
+        const int c1[4] = {o1.x, o1.y, o1.z, o1.w}, c2[4] = {o2.x, o2.y, o2.z, o2.w};
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (!on[i]) continue;
+            const unsigned b2 = cur2 ? b_cur[i] : b_first[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                r.a[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, b_min[i] + (unsigned)c1[e], 0, 0));
+                r.s[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, b2 + (unsigned)c2[e], 0, 0));
+            }
+        }
+    };
+    auto commit = [&](int kt, const Raw &r) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (!on[i]) continue;
+            *reinterpret_cast<f32x4 *>(smem + (srow + 64 * i) * ldt + kt * BK + a_kq) = r.a[i] - r.s[i];
+        }
+    };
+    {
+        Raw r0, r1;
+        issue(0, r0);
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            issue(kt + 1, r1);
+            commit(kt, r0);
+            if (kt + 2 < nk) issue(kt + 2, r0);
+            commit(kt + 1, r1);
+        }
+        if (kt < nk) commit(kt, r0);
+    }
+    __syncthreads();
+
+    // ---- barrier-free MFMA loop: A fragments from the LDS tile, W fragments straight from HBM
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.w + ((size_t)((col0 >> 5) + wave_u) * nk) * 1024), 0, nk * 4096, 0x00020000);
+    const int w_voff = lane * 16;
+    f32x4 rb[4], rbn[4];
+    auto load_w = [&](int kt, f32x4 (&dst)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            dst[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff + q * 1024, kt * 4096, 0));
+    };
+    f32x16 acc[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.0f;
+    const float *a_frag = smem + li * ldt + lh * 16;
+    const int last = nk - 1;
+    auto k_tile = [&](int kt, f32x4 (&w_use)[4], f32x4 (&w_load)[4]) {
+        load_w(kt + 1 < last ? kt + 1 : last, w_load);
+        const float *s = a_frag + kt * BK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 av[MI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) av[mi] = *reinterpret_cast<const f32x4 *>(s + mi * 32 * ldt + q * 4);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][kk], w_use[q][kk], acc[mi], 0, 0, 0);
+        }
+    };
+    load_w(0, rb);
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        k_tile(kt, rb, rbn);
+        k_tile(kt + 1, rbn, rb);
+    }
+    if (kt < nk) k_tile(kt, rb, rbn);
+
+    // ---- epilogue: C = lrelu(acc + bias)  (first layers have no residual)
+    const int col = col0 + wave * 32 + li;
+    if (col >= N) return;
+    const float slope = P.slope;
+    float *c = P.c;
+    const int ldc = P.ldc;
+    const float bias = gload1(P.bias + col);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < M) {
+                float v = acc[mi][r] + bias;
+                v = v > 0.0f ? v : v * slope;
+                gstore1(c + (size_t)row * ldc + col, v);
+            }
+        }
+    }
+}
+
 template <bool ENC>
 __device__ __forceinline__ void gemm_persistent(float *smem) {
     LaunchArgsPtr args = (LaunchArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -404,19 +525,28 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
         const int row0 = __builtin_amdgcn_readfirstlane(td.y);
         const int col0 = __builtin_amdgcn_readfirstlane(td.z);
         ProbRef P = args->p[pi];
-        if (!ENC && ks == 2) {
-            if (mi == 1) gemm_tile<1, false, 2>(P, row0, col0, new_prob, smem, dbg);
-            else gemm_tile<2, false, 2>(P, row0, col0, new_prob, smem, dbg);
-            __syncthreads();   // (half of the wavefronts leave a split-K tile early)
-            continue;
-        }
-        switch (mi) {
-            case 1: gemm_tile<1, ENC, 1>(P, row0, col0, new_prob, smem, dbg); break;
-            case 2: gemm_tile<2, ENC, 1>(P, row0, col0, new_prob, smem, dbg); break;
-            case 3: gemm_tile<3, ENC, 1>(P, row0, col0, new_prob, smem, dbg); break;
-            case 4: gemm_tile<4, ENC, 1>(P, row0, col0, new_prob, smem, dbg); break;
-            case 5: gemm_tile<5, ENC, 1>(P, row0, col0, new_prob, smem, dbg); break;
-            default: gemm_tile<6, ENC, 1>(P, row0, col0, new_prob, smem, dbg); break;
+        if constexpr (ENC) {
+            (void)ks; (void)dbg;
+            switch (mi) {
+                case 1: enc_tile<1>(P, row0, col0, new_prob, smem); break;
+                case 2: enc_tile<2>(P, row0, col0, new_prob, smem); break;
+                default: enc_tile<3>(P, row0, col0, new_prob, smem); break;
+            }
+        } else {
+            if (ks == 2) {
+                if (mi == 1) gemm_tile<1, 2>(P, row0, col0, new_prob, smem, dbg);
+                else gemm_tile<2, 2>(P, row0, col0, new_prob, smem, dbg);
+                __syncthreads();   // (half of the wavefronts leave a split-K tile early)
+                continue;
+            }
+            switch (mi) {
+                case 1: gemm_tile<1, 1>(P, row0, col0, new_prob, smem, dbg); break;
+                case 2: gemm_tile<2, 1>(P, row0, col0, new_prob, smem, dbg); break;
+                case 3: gemm_tile<3, 1>(P, row0, col0, new_prob, smem, dbg); break;
+                case 4: gemm_tile<4, 1>(P, row0, col0, new_prob, smem, dbg); break;
+                case 5: gemm_tile<5, 1>(P, row0, col0, new_prob, smem, dbg); break;
+                default: gemm_tile<6, 1>(P, row0, col0, new_prob, smem, dbg); break;
+            }
         }
     }
 #ifdef R3D_TIMING
@@ -427,15 +557,15 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
 #endif
 }
 
-// every layer whose input is an activation matrix in HBM
+// every layer whose input is an activation matrix in HBM: one workgroup per CU
 extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_f32(const LaunchArgs args_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     (void)args_;
     gemm_persistent<false>(smem);
 }
 
-// first layers (expand_conv of every temporal branch, GlobalInfo.fc_1): input encoding fused in
-extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_enc_f32(const LaunchArgs args_) {
+// first layers with the input encoding fused in: two workgroups per CU (4 wavefronts per SIMD)
+extern "C" __global__ __launch_bounds__(GEMM_THREADS, 4) void r3d_gemm_enc_f32(const LaunchArgs args_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     (void)args_;
     gemm_persistent<true>(smem);
@@ -449,12 +579,12 @@ hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, bool encode, hipSt
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(r3d_gemm_enc_f32),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     if (encode)
-        r3d_gemm_enc_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
+        r3d_gemm_enc_f32<<<dim3(nwg), dim3(GEMM_THREADS), ENC_LDS_BYTES, stream>>>(args);
     else
         r3d_gemm_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
     return hipGetLastError();

@@ -186,27 +186,43 @@ Model *model_create(const r3d_config &cfg) {
     }
     // GlobalInfo.fc_1 reads the zero-padded current-frame matrix
     m->layers[m->layer_index["GlobalInfo.fc_1"]].Kpad = CUR_LD;
-    // ---- fused-prologue LUTs: column of a first-layer GEMM -> where its value comes from in the
-    // raw input.  Channel order inside a branch: cat(x_g, diff_g, diff_t_g), lib/model/rie.py:308-315, :540
+    // ---- fused-prologue tables (layout: r3d_internal.hpp) and the matching column maps of the first layers.
+    // Reference channel order inside a branch: cat(x_g, diff_g, diff_t_g) per tap (rie.py:308-315, :540).
     m->iarena.clear();
     const int JF = J * F;
     for (auto &br : m->branches) {
+        const int n = (int)br.joints.size(), nF = n * F;
+        const int G = round_up(3 * nF, 4);                   // columns per kind group (3 taps), padded to 4
+        br.k0 = 3 * G;
+        br.k0pad = round_up(br.k0, BK);
+        Layer &L = m->layers[m->layer_index[br.prefix + ".expand_conv"]];
+        L.Kpad = br.k0pad;
+        L.colmap.assign(3 * br.cin, 0);
+        std::vector<int> l1(br.k0pad, ENC_INVALID), l2(br.k0pad, ENC_INVALID), lk(br.k0pad / 4, 0);
+        for (int kind = 0; kind < 3; ++kind)
+            for (int tap = 0; tap < 3; ++tap)
+                for (int c = 0; c < nF; ++c) {
+                    const int col = kind * G + tap * nF + c;
+                    const int src = br.joints[c / F] * F + c % F;       // element of the (J,F) frame
+                    L.colmap[tap * br.cin + kind * nF + c] = col;       // torch column (tap, channel kind*nF + c)
+                    l1[col] = (tap * JF + src) * 4;
+                    if (kind == 1) l2[col] = (tap * JF + c % F) * 4;    // root joint is joint 0 (rie.py:301)
+                    if (kind == 2) { l2[col] = src * 4; lk[col / 4] = 1; }
+                }
         br.lut_off = m->iarena.size();
-        const int n = (int)br.joints.size();
-        for (int col = 0; col < br.k0pad; ++col) {
-            if (col >= br.k0) { m->iarena.push_back(encode_lut_entry(0, 0, 3, 0)); continue; }
-            const int tap = col / br.cin, c = col % br.cin;
-            const int kind = c / (n * F), jj = (c % (n * F)) / F, ff = c % F;
-            const int src = br.joints[jj] * F + ff;
-            const int off1 = tap * JF + src;
-            const int off2 = kind == 1 ? tap * JF + ff : kind == 2 ? src : 0;   // root joint is joint 0 (rie.py:301)
-            m->iarena.push_back(encode_lut_entry(off1, off2, kind, 0));
-        }
+        m->iarena.insert(m->iarena.end(), l1.begin(), l1.end());
+        m->iarena.insert(m->iarena.end(), l2.begin(), l2.end());
+        m->iarena.insert(m->iarena.end(), lk.begin(), lk.end());
     }
     // GlobalInfo.fc_1 reads in_current = x[:, RF // F] flattened (rie.py:290-292), zero padded to CUR_LD
-    m->global_lut_off = m->iarena.size();
-    for (int col = 0; col < CUR_LD; ++col)
-        m->iarena.push_back(col < JF ? encode_lut_entry(col, 0, 0, 1) : encode_lut_entry(0, 0, 3, 0));
+    {
+        std::vector<int> l1(CUR_LD, ENC_INVALID), l2(CUR_LD, ENC_INVALID), lk(CUR_LD / 4, 0);
+        for (int col = 0; col < JF; ++col) l1[col] = col * 4;
+        m->global_lut_off = m->iarena.size();
+        m->iarena.insert(m->iarena.end(), l1.begin(), l1.end());
+        m->iarena.insert(m->iarena.end(), l2.begin(), l2.end());
+        m->iarena.insert(m->iarena.end(), lk.begin(), lk.end());
+    }
     for (auto &kv : m->layer_index)
         if (kv.first.rfind("Integration", 0) == 0 && kv.first.size() > 5 && kv.first.compare(kv.first.size() - 5, 5, ".fc_2") == 0)
             m->layers[kv.second].frag = false;   // consumed by r3d_decode_f32
@@ -303,7 +319,7 @@ int model_finalize(Model *m) {
         for (int o = 0; o < L.N; ++o)
             for (int c = 0; c < L.cin; ++c)
                 for (int j = 0; j < L.taps; ++j) {
-                    const int k = j * L.cin + c;
+                    const int k = L.colmap.empty() ? j * L.cin + c : L.colmap[j * L.cin + c];
                     const float v = (float)((double)w[((size_t)o * L.cin + c) * L.taps + j] * s[o]);
                     dst[L.frag ? frag_index(o, k, nk) : (size_t)o * L.Kpad + k] = v;
                 }

@@ -43,6 +43,7 @@ struct Segment {
     int units;     // 32-row units
     int M;
     double unit_cost;
+    int max_units; // largest tile of this problem
 };
 
 // cycles of one SIMD for a unit: two wavefronts share the pipe, 16 MFMAs x 64 cycles each per
@@ -71,7 +72,7 @@ void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units,
         const int units = (probs[i].M + 31) / 32;
         const double cost = unit_cycles((probs[i].nk + ks - 1) / ks);
         for (int c0 = 0; c0 < probs[i].N; c0 += bn) {
-            segs.push_back({i, c0, units, probs[i].M, cost});
+            segs.push_back({i, c0, units, probs[i].M, cost, probs[i].max_units > 0 ? std::min(probs[i].max_units, max_units) : max_units});
             total += units * cost;
         }
     }
@@ -103,7 +104,7 @@ void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units,
             take = std::min(take, s.units - u);
             if (take > 0) {
                 // emit `take` units as evenly sized tiles of <= max_units units
-                const int nt = (take + max_units - 1) / max_units;
+                const int nt = (take + s.max_units - 1) / s.max_units;
                 int done = 0;
                 for (int k = 0; k < nt; ++k) {
                     const int sz = (take - done + (nt - k) - 1) / (nt - k);
@@ -130,11 +131,16 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
         const ProbSpec &q = pl->probs[st[i]];
         const Layer &L = pl->m[q.model]->layers[q.layer];
         const int M = (int)(B * q.rows_per_window);
-        probs.push_back({M, L.N, L.Kpad / BK, q.enc_lut < 0 && q.nseg == 1});
+        // fused-prologue tiles hold the whole encoded operand in 64 KiB of LDS: rows * (K + 4) floats
+        const int enc_cap = q.enc_lut >= 0 ? std::max(1, std::min(3, (64 * 1024) / ((L.Kpad + 4) * 4 * 32))) : 0;
+        probs.push_back({M, L.N, L.Kpad / BK, q.enc_lut < 0 && q.nseg == 1, enc_cap});
         flops += q.flops_per_window * (double)B;
         bytes += 4.0 * ((double)M * L.K + (double)L.N * L.K + (double)M * L.N * (q.res_buf >= 0 ? 2.0 : 1.0));
     }
-    schedule_stage(probs, nwg, 6, tiles, wgoff, out);
+    bool enc = false;
+    for (int id : st) enc = enc || pl->probs[id].enc_lut >= 0;
+    // the fused-prologue kernel runs two workgroups per CU (one encodes while the other multiplies)
+    schedule_stage(probs, enc ? 2 * nwg : nwg, 6, tiles, wgoff, out);
     out.flops = flops;
     out.bytes = bytes;
 }

@@ -41,19 +41,23 @@ int main(int argc, char **argv) {
     std::vector<SchedProb> sp;
     // fused-prologue inputs: windows of 243 frames x 51 floats, LUT shaped like a temporal branch's
     float *dx = nullptr; int *dlut = nullptr;
-    std::vector<float> hx; std::vector<int> hlut(K);
+    std::vector<float> hx; std::vector<int> hlut(2 * K + K / 4, 0);
     if (enc) {
         const int nwin = M / 81;
         hx.resize((size_t)nwin * 243 * 51);
         for (size_t i = 0; i < hx.size(); ++i) hx[i] = (float)((i * 2246822519u) % 2001) / 1000.f - 1.f;
-        for (int k = 0; k < K; ++k) {
-            const int tap = (k * 3) / K, kind = k % 3, src = (k * 7) % 51;
-            hlut[k] = encode_lut_entry(tap * 51 + src, kind == 1 ? tap * 51 + src % 3 : src, kind, 0);
+        for (int k = 0; k < K; ++k) {   // kind-grouped columns like the real first layers
+            const int kind = (k * 3) / K, tap = k % 3, src = (k * 7) % 51;
+            hlut[k] = (tap * 51 + src) * 4;
+            hlut[K + k] = kind == 0 ? ENC_INVALID : kind == 1 ? (tap * 51 + src % 3) * 4 : src * 4;
+            if (kind == 2) hlut[2 * K + k / 4] = 1;
         }
+        for (int k = 0; k < K; ++k)     // a chunk is cur-relative as a whole
+            if (hlut[2 * K + k / 4] && (k * 3) / K != 2) { hlut[K + k] = ((k * 7) % 51) * 4; }
         CK(hipMalloc((void **)&dx, hx.size() * 4));
-        CK(hipMalloc((void **)&dlut, K * 4));
+        CK(hipMalloc((void **)&dlut, hlut.size() * 4));
         CK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
-        CK(hipMemcpy(dlut, hlut.data(), K * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dlut, hlut.data(), hlut.size() * 4, hipMemcpyHostToDevice));
     }
     for (int i = 0; i < nprob; ++i) {
         CK(hipMalloc((void **)&dA[i], hA.size() * 4));
@@ -66,13 +70,13 @@ int main(int argc, char **argv) {
         g.w = dW[i]; g.bias = dbias; g.res = nullptr; g.c = dC[i]; g.ldr = 0; g.ldc = N;
         g.M = M; g.N = N; g.K = K; g.slope = 0.2f;
         if (enc) { g.lut = dlut; g.x = dx; g.enc_ws = 243 * 51; g.enc_rows = 81; g.enc_jf = 51; g.enc_cur = 81 * 51; g.enc_bytes = (unsigned)(hx.size() * 4); }
-        sp.push_back({M, N, K / BK, enc == 0});
+        sp.push_back({M, N, K / BK, enc == 0, enc ? std::max(1, std::min(3, (64 * 1024) / ((K + 4) * 4 * 32))) : 0});
     }
     std::vector<int4> tiles;
     std::vector<int> wgoff;
     StageSchedule ss{};
     const int nwg = device_cu_count();
-    schedule_stage(sp, nwg, 6, tiles, wgoff, ss);
+    schedule_stage(sp, enc ? 2 * nwg : nwg, 6, tiles, wgoff, ss);
     int4 *dt; int *dwg; long long *ddbg;
     CK(hipMalloc((void **)&dt, tiles.size() * sizeof(int4)));
     CK(hipMalloc((void **)&dwg, wgoff.size() * sizeof(int)));
@@ -108,10 +112,11 @@ int main(int argc, char **argv) {
         for (int k = 0; k < K; ++k) {
             double a = hA[(size_t)r * K + k];
             if (enc) {
-                const int code = hlut[k], kind = (code >> 20) & 3, win = r / 81, t3 = r % 81;
+                const int win = r / 81, t3 = r % 81;
                 const size_t first = (size_t)win * 243 * 51 + (size_t)t3 * 3 * 51, cur = (size_t)win * 243 * 51 + 81 * 51;
-                const double v1 = hx[first + (code & 1023)], v2 = hx[(kind == 2 ? cur : first) + ((code >> 10) & 1023)];
-                a = kind == 0 ? v1 : v1 - v2;
+                const double v1 = hx[first + hlut[k] / 4];
+                const double v2 = hlut[K + k] == ENC_INVALID ? 0.0 : hx[(hlut[2 * K + k / 4] ? cur : first) + hlut[K + k] / 4];
+                a = v1 - v2;
             }
             acc += a * hWr[(size_t)c * K + k];
         }
