@@ -75,13 +75,13 @@ int main(int argc, char **argv) {
     std::vector<int4> tiles;
     std::vector<int> wgoff;
     StageSchedule ss{};
-    const int nwg = device_cu_count();
+    const int nwg = getenv("PROBE_NWG") ? atoi(getenv("PROBE_NWG")) : device_cu_count();
     schedule_stage(sp, enc ? 2 * nwg : nwg, 6, tiles, wgoff, ss);
     int4 *dt; int *dwg; long long *ddbg;
     CK(hipMalloc((void **)&dt, tiles.size() * sizeof(int4)));
     CK(hipMalloc((void **)&dwg, wgoff.size() * sizeof(int)));
-    CK(hipMalloc((void **)&ddbg, (1024 + 4 * 1024) * 8));
-    CK(hipMemset(ddbg, 0, (1024 + 4 * 1024) * 8));
+    CK(hipMalloc((void **)&ddbg, (1024 + 4 * 1024) * 8 + 65536));
+    CK(hipMemset(ddbg, 0, (1024 + 4 * 1024) * 8 + 65536));
     CK(hipMemcpy(dt, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice));
     CK(hipMemcpy(dwg, wgoff.data(), wgoff.size() * sizeof(int), hipMemcpyHostToDevice));
     la.tiles = dt; la.wg_off = dwg; la.dbg = ddbg; la.ks = ss.ks;
@@ -125,6 +125,75 @@ int main(int argc, char **argv) {
         maxerr = err > maxerr ? err : maxerr;
     }
     printf("spot-check max rel err %.2e\n", maxerr);
+    if (getenv("PROBE_LDSDUMP") && enc) {
+        std::vector<float> hl(16384);
+        CK(hipMemcpy(hl.data(), ddbg, 65536, hipMemcpyDeviceToHost));
+        const int ldt = K + 4, r0 = tiles[1].y, rows = (tiles[1].x >> 8) * 32;
+        int bad = 0;
+        for (int r = 0; r < rows && r0 + r < M; ++r)
+            for (int k = 0; k < K; ++k) {
+                const int rr = r0 + r, win = rr / 81, t3 = rr % 81;
+                const size_t first = (size_t)win * 243 * 51 + (size_t)t3 * 3 * 51, cur = (size_t)win * 243 * 51 + 81 * 51;
+                const float v1 = hlut[k] == ENC_INVALID ? 0.f : hx[first + hlut[k] / 4];
+                const float v2 = hlut[K + k] == ENC_INVALID ? 0.f : hx[(hlut[2 * K + k / 4] ? cur : first) + hlut[K + k] / 4];
+                const float want = v1 - v2, got = hl[(size_t)r * ldt + k];
+                if (fabs(want - got) > 1e-5) { if (bad < 0) printf("  lds[row %d][k %d] got %.5f want %.5f (v1 %.5f v2 %.5f)\n", r, k, got, want, v1, v2); ++bad; }
+            }
+        printf("LDS tile 1: %d bad of %d\n", bad, rows * K);
+        for (int r = 0; r < 2; ++r) { printf("row %d got:", r); for (int k = 0; k < K; ++k) printf(" %.3f", hl[(size_t)r * ldt + k]); printf("\n"); }
+        printf("lut1:"); for (int k = 0; k < K; ++k) printf(" %d", hlut[k] / 4); printf("\nlut2:"); for (int k = 0; k < K; ++k) printf(" %d", hlut[K + k] == ENC_INVALID ? -1 : hlut[K + k] / 4); printf("\n");
+    }
+    if (getenv("PROBE_FULLCHECK")) {
+        // per 32-row unit: how many of 8 sampled entries are wrong
+        const int units = (M + 31) / 32;
+        printf("units with errors (unit: bad/8):");
+        int nbad = 0;
+        for (int u = 0; u < units; ++u) {
+            int bad = 0;
+            for (int t = 0; t < 8; ++t) {
+                const int r = std::min(M - 1, u * 32 + (t * 5) % 32), c = (t * 37 + u) % N;
+                double acc = 0;
+                for (int k = 0; k < K; ++k) {
+                    double a = hA[(size_t)r * K + k];
+                    if (enc) {
+                        const int win = r / 81, t3 = r % 81;
+                        const size_t first = (size_t)win * 243 * 51 + (size_t)t3 * 3 * 51, cur = (size_t)win * 243 * 51 + 81 * 51;
+                        const double v1 = hx[first + hlut[k] / 4];
+                        const double v2 = hlut[K + k] == ENC_INVALID ? 0.0 : hx[(hlut[2 * K + k / 4] ? cur : first) + hlut[K + k] / 4];
+                        a = v1 - v2;
+                    }
+                    acc += a * hWr[(size_t)c * K + k];
+                }
+                acc = acc > 0 ? acc : 0.2 * acc;
+                if (fabs(acc - hC[(size_t)r * N + c]) > 1e-3 * (1 + fabs(acc))) ++bad;
+            }
+            if (bad) { if (nbad < 40) printf(" %d:%d", u, bad); ++nbad; }
+        }
+        printf("  (%d of %d units bad)\n", nbad, units);
+        for (int t = 0; t < 12 && t < (int)tiles.size(); ++t) printf("tile %d: prob %d mi %d row0 %d col0 %d\n", t, tiles[t].x & 255, tiles[t].x >> 8, tiles[t].y, tiles[t].z);
+        if (getenv("PROBE_DUMPROW")) {
+            const int r = atoi(getenv("PROBE_DUMPROW"));
+            for (int rr = r; rr < r + 3; ++rr) { printf("row %d got:", rr);
+            for (int c = 0; c < 6; ++c) printf(" %9.4f", hC[(size_t)rr * N + c]); printf("\n"); }
+            printf("\nexpected for rows r-2..r+2 (cols 0..5):\n");
+            for (int rr = 0; rr < M; ++rr) {
+                if (!(rr % 32 < 3)) continue;
+                printf("  row %4d:", rr);
+                for (int c = 0; c < 6; ++c) {
+                    double acc = 0;
+                    for (int k = 0; k < K; ++k) {
+                        const int win = rr / 81, t3 = rr % 81;
+                        const size_t first = (size_t)win * 243 * 51 + (size_t)t3 * 3 * 51, cur = (size_t)win * 243 * 51 + 81 * 51;
+                        const double v1 = hx[first + hlut[k] / 4];
+                        const double v2 = hlut[K + k] == ENC_INVALID ? 0.0 : hx[(hlut[2 * K + k / 4] ? cur : first) + hlut[K + k] / 4];
+                        acc += (v1 - v2) * hWr[(size_t)c * K + k];
+                    }
+                    printf(" %9.4f", acc > 0 ? acc : 0.2 * acc);
+                }
+                printf("\n");
+            }
+        }
+    }
 #ifdef R3D_TIMING
     {
         std::vector<long long> hw(4 * 1024);
