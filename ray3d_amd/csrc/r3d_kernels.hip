@@ -70,6 +70,54 @@ constexpr int GEMM_LDS_BYTES = GEMM_STAGES * STAGE_FLOATS * 4;                  
 typedef const LaunchArgs __attribute__((address_space(4))) *LaunchArgsPtr;
 typedef const GemmProb __attribute__((address_space(4))) &ProbRef;
 
+// Epilogue of a full-width (256-column) tile: C = res + lrelu(acc + bias), written in 1 KiB rows.
+// The MFMA leaves each wavefront with a 32-column slab (C/D layout of v_mfma_f32_32x32x2_f32: col =
+// lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)); storing that directly means 4-byte
+// accesses in 128-byte pieces, and the short-K layers become store-issue bound.  Instead the eight
+// slabs of 32 rows are transposed through LDS (idle after the K loop) so that every lane moves 16
+// bytes and every wavefront instruction covers one whole 1 KiB output row - for the residual read too.
+constexpr int EPI_LD = GEMM_BN + 4;       // 260 floats: the two 32-lane halves of a ds_write_b32 hit different banks
+
+template <int MI>
+__device__ __forceinline__ void store_tile_256(ProbRef P, const f32x16 (&acc)[MI], const int row0, const int col0, float *lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int M = P.M, N = P.N;
+    const float slope = P.slope;
+    const float *res = P.res;
+    float *c = P.c;
+    const int ldc = P.ldc, ldr = P.ldr;
+    const float bias = gload1(P.bias + col0 + wave * 32 + li);
+    float *wr = lds + (4 * lh) * EPI_LD + wave * 32 + li;
+    const int rd_row = tid >> 6, rd_c4 = (tid & 63) * 4;            // 8 rows x 64 float4 per pass, 4 passes
+    const bool vec = (col0 + GEMM_BN <= N);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        __syncthreads();                                            // LDS free: K loop / previous slab done
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[mi][r] + bias;
+            wr[((r & 3) + 8 * (r >> 2)) * EPI_LD] = v > 0.0f ? v : v * slope;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lr = rd_row + 8 * j;
+            const int row = row0 + mi * 32 + lr;
+            if (row >= M) continue;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(lds + lr * EPI_LD + rd_c4);
+            const int col = col0 + rd_c4;
+            if (vec) {
+                if (res) v += gload4(res + (size_t)row * ldr + col);
+                *(R3D_AS1 f32x4 *)(c + (size_t)row * ldc + col) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < N) gstore1(c + (size_t)row * ldc + col + e, v[e] + (res ? gload1(res + (size_t)row * ldr + col + e) : 0.0f));
+            }
+        }
+    }
+}
+
 // KS = 2 ("split-K inside the workgroup") serves levels with too few row units to occupy the chip: the
 // tile is 128 columns wide, wavefronts 0-3 take the even and wavefronts 4-7 the odd 32-wide K tiles
 // of the same 128 columns, and the two partial sums are added through LDS at the end.  Twice as many
@@ -305,6 +353,11 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][r] += red[(mi * 16 + r) * 64];
     }
+    if (KS == 1) {
+        store_tile_256<MI>(P, acc, row0, col0, smem);
+        return;
+    }
+    // split-K tiles (128 columns, small launches): direct stores from the MFMA layout
     const int col = col0 + wn * 32 + li;
     const float slope = P.slope;
     const float *res = P.res;
@@ -363,7 +416,7 @@ __device__ __forceinline__ void enc_tile(ProbRef P, const int row0, const int co
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int M = P.M, N = P.N, K = P.K;
+    const int M = P.M, K = P.K;
     const int nk = K / BK;
     const int ldt = K + 4;                                  // (K+4)*4 B = odd multiple of 16 B: conflict-free b128 rows
     const int srow = tid >> 3, a_kq = (tid & 7) * 4;
@@ -473,25 +526,8 @@ __device__ __forceinline__ void enc_tile(ProbRef P, const int row0, const int co
     }
     if (kt < nk) k_tile(kt, rb, rbn);
 
-    // ---- epilogue: C = lrelu(acc + bias)  (first layers have no residual)
-    const int col = col0 + wave * 32 + li;
-    if (col >= N) return;
-    const float slope = P.slope;
-    float *c = P.c;
-    const int ldc = P.ldc;
-    const float bias = gload1(P.bias + col);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row < M) {
-                float v = acc[mi][r] + bias;
-                v = v > 0.0f ? v : v * slope;
-                gstore1(c + (size_t)row * ldc + col, v);
-            }
-        }
-    }
+    // ---- epilogue: C = lrelu(acc + bias) through the LDS transpose (the encoded tile is dead by now)
+    store_tile_256<MI>(P, acc, row0, col0, smem);
 }
 
 template <bool ENC>
