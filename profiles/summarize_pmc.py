@@ -4,11 +4,12 @@ usage: python profiles/summarize_pmc.py gpurun_out/prof1 > profiles/<round>/pmc_
 import collections
 import csv
 import glob
+import os
 import sys
 
 
 def load(d):
-    f = glob.glob(d + '/runc/*_counter_collection.csv')[0]
+    f = max(glob.glob(d + '/runc/*_counter_collection.csv'), key=os.path.getmtime)   # newest run
     per = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
         k = int(r['Dispatch_Id'])
