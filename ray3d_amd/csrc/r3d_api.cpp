@@ -212,8 +212,10 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             g.slope = L.slope;
         }
         if (n_enc != 0 && n_enc != la.nprob) { set_error("internal: launch mixes encoded and plain operands"); return R3D_ERR_STATE; }
-        if ((e = rec.begin(n_enc ? "r3d_gemm_enc_f32" : "r3d_gemm_f32", stage_no, ss.nwg, ss.flops, ss.bytes)) != hipSuccess) return hip_fail(e, "hipEventRecord");
-        if ((e = launch_gemm_stage(la, ss.nwg, n_enc != 0, stream)) != hipSuccess) return hip_fail(e, "launch r3d_gemm_f32");
+        if ((n_enc != 0) != (ss.kind == STAGE_ENC)) { set_error("internal: schedule and plan disagree on the launch kind"); return R3D_ERR_STATE; }
+        const char *kname = ss.kind == STAGE_ENC ? "r3d_gemm_enc_f32" : "r3d_gemm_f32";
+        if ((e = rec.begin(kname, stage_no, ss.nwg, ss.flops, ss.bytes)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        if ((e = launch_gemm_stage(la, ss.nwg, ss.kind, stream)) != hipSuccess) return hip_fail(e, "launch r3d_gemm_f32");
         if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
         ++stage_no;
     }

@@ -53,7 +53,7 @@ struct LaunchArgs {
     const int4 *tiles;    // {problem | MI << 8, first row, first column, 0}
     const int *wg_off;    // [grid + 1]: chunk c executes tiles [wg_off[c], wg_off[c+1])
     int nprob;
-    int ks;               // 1, or 2 = split-K tiles (128 columns, K halves added through LDS)
+    int ks;               // (unused: the split-K factor travels with each tile)
     long long *dbg;       // optional phase timestamps (R3D_TIMING builds only)
     GemmProb p[MAX_PROB];
 };
@@ -185,7 +185,8 @@ struct ProbSpec {
 // Per-(plan, batch) work distribution of the persistent GEMM launches.
 struct StageSchedule {
     int nwg;               // grid size
-    int ks;                // split-K factor of this launch's tiles (1 or 2)
+    int ks;                // largest split-K factor among this launch's tiles (1, 2 or 4)
+    int kind;              // STAGE_BIG / STAGE_ENC: which kernel runs the launch
     int ntiles;
     size_t tiles_off;      // offsets (in int4 / int) into Schedule::d_tiles / d_wgoff
     size_t wgoff_off;
@@ -228,11 +229,12 @@ int model_finalize(Model *m);
 Plan *plan_get(Model *a, Model *b);
 struct SchedProb {
     int M, N, nk;
-    bool plain;      // single-buffer operand (eligible for split-K tiles)
+    int max_ks;      // largest split-K factor the operand allows (1 = none: fused-prologue operands, or a
+                     // concatenated operand with a boundary that is not a multiple of 32*KS)
     int max_units;   // per-problem cap on 32-row units per tile (0 = the launch default)
 };
 void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units, std::vector<int4> &tiles,
-                    std::vector<int> &wgoff, StageSchedule &out);
+                    std::vector<int> &wgoff, StageSchedule &out, bool enc = false);
 // index of weight element (output channel o, GEMM column k) in the fragment-ordered packing
 inline size_t frag_index(int o, int k, int nk) {
     const int nb = o >> 5, li = o & 31, kt = k >> 5, kin = k & 31, lh = kin >> 4, q = (kin & 15) >> 2, e = kin & 3;
@@ -243,7 +245,8 @@ int device_cu_count();
 
 // kernel launchers (r3d_kernels.hip)
 hipError_t launch_prologue(const PrologueArgs &args, hipStream_t stream);
-hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, bool encode, hipStream_t stream);
+enum { STAGE_BIG = 0, STAGE_ENC = 1 };   // r3d_gemm_f32 / r3d_gemm_enc_f32
+hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, int kind, hipStream_t stream);
 hipError_t launch_decode(const DecodeArgs &args, hipStream_t stream);
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }

@@ -20,6 +20,14 @@
 
 namespace r3d {
 
+// development instrumentation (tools/gemm_probe -DR3D_TIMING): wall-clock stamps of a tile's phases
+#ifdef R3D_TIMING
+#define R3D_TSTAMP(slot) do { if (dbg && threadIdx.x == 0) dbg[slot] = wall_clock64(); } while (0)
+#else
+#define R3D_TSTAMP(slot) do { } while (0)
+#endif
+#define R3D_STAMP(slot) do { } while (0)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -70,45 +78,53 @@ constexpr int GEMM_LDS_BYTES = GEMM_STAGES * STAGE_FLOATS * 4;                  
 typedef const LaunchArgs __attribute__((address_space(4))) *LaunchArgsPtr;
 typedef const GemmProb __attribute__((address_space(4))) &ProbRef;
 
-// Epilogue of a full-width (256-column) tile: C = res + lrelu(acc + bias), written in 1 KiB rows.
-// The MFMA leaves each wavefront with a 32-column slab (C/D layout of v_mfma_f32_32x32x2_f32: col =
-// lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)); storing that directly means 4-byte
-// accesses in 128-byte pieces, and the short-K layers become store-issue bound.  Instead the eight
-// slabs of 32 rows are transposed through LDS (idle after the K loop) so that every lane moves 16
-// bytes and every wavefront instruction covers one whole 1 KiB output row - for the residual read too.
+// Epilogue of a tile of COLS = 256 / KS columns: C = res + lrelu(acc + bias), written in wide rows.
+// The MFMA leaves each (phase-0) wavefront with a 32-column slab (C/D layout of v_mfma_f32_32x32x2_f32:
+// col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)); storing that directly means 4-byte
+// accesses in 128-byte pieces, and the short-K layers become store-issue bound.  Instead the slabs of 32
+// rows are transposed through LDS (idle after the K loop) so that every lane of all eight wavefronts
+// moves 16 bytes and a wavefront instruction covers whole output rows (1 KiB at COLS = 256) - for
+// the residual read too.
 constexpr int EPI_LD = GEMM_BN + 4;       // 260 floats: the two 32-lane halves of a ds_write_b32 hit different banks
 
-template <int MI>
-__device__ __forceinline__ void store_tile_256(ProbRef P, const f32x16 (&acc)[MI], const int row0, const int col0, float *lds) {
+template <int MI, int KS>
+__device__ __forceinline__ void store_tile(ProbRef P, const f32x16 (&acc)[MI], const int row0, const int col0, float *lds) {
+    constexpr int COLS = GEMM_BN / KS, WN = 8 / KS;
+    constexpr int TPR = COLS / 4;                 // threads per output row (16 bytes each)
+    constexpr int RPP = GEMM_THREADS / TPR;       // rows per pass: 8 / 16 / 32
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int M = P.M, N = P.N;
     const float slope = P.slope;
     const float *res = P.res;
     float *c = P.c;
     const int ldc = P.ldc, ldr = P.ldr;
-    const float bias = gload1(P.bias + col0 + wave * 32 + li);
+    const bool writer = wave < WN;                // the wavefronts of K phase 0 hold the sums
+    const float bias = writer ? gload1(P.bias + col0 + wave * 32 + li) : 0.0f;
     float *wr = lds + (4 * lh) * EPI_LD + wave * 32 + li;
-    const int rd_row = tid >> 6, rd_c4 = (tid & 63) * 4;            // 8 rows x 64 float4 per pass, 4 passes
-    const bool vec = (col0 + GEMM_BN <= N);
+    const int rd_row = tid / TPR, rd_c4 = (tid % TPR) * 4;
+    const bool vec = (col0 + COLS <= N);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        __syncthreads();                                            // LDS free: K loop / previous slab done
+        __syncthreads();                                            // LDS free: K loop / reduction / previous slab done
+        if (writer) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = acc[mi][r] + bias;
-            wr[((r & 3) + 8 * (r >> 2)) * EPI_LD] = v > 0.0f ? v : v * slope;
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[mi][r] + bias;
+                wr[((r & 3) + 8 * (r >> 2)) * EPI_LD] = v > 0.0f ? v : v * slope;
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int lr = rd_row + 8 * j;
+        for (int j = 0; j < 32 / RPP; ++j) {
+            const int lr = rd_row + RPP * j;
             const int row = row0 + mi * 32 + lr;
             if (row >= M) continue;
             f32x4 v = *reinterpret_cast<const f32x4 *>(lds + lr * EPI_LD + rd_c4);
             const int col = col0 + rd_c4;
             if (vec) {
                 if (res) v += gload4(res + (size_t)row * ldr + col);
-                *(R3D_AS1 f32x4 *)(c + (size_t)row * ldc + col) = v;
+                // (streaming store: the consumer is the next launch, mostly on other XCDs - no use for the line in this L2)
+                __builtin_nontemporal_store(v, (R3D_AS1 f32x4 *)(c + (size_t)row * ldc + col));
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -116,98 +132,99 @@ __device__ __forceinline__ void store_tile_256(ProbRef P, const f32x16 (&acc)[MI
             }
         }
     }
+    __syncthreads();                                                // the next tile's staging may overwrite the slab
 }
 
-// KS = 2 ("split-K inside the workgroup") serves levels with too few row units to occupy the chip: the
-// tile is 128 columns wide, wavefronts 0-3 take the even and wavefronts 4-7 the odd 32-wide K tiles
-// of the same 128 columns, and the two partial sums are added through LDS at the end.  Twice as many
-// tiles, each with half as many K-loop iterations.
+// KS = 2 / 4 ("split-K inside the workgroup") serves problems with too few row units to occupy the
+// chip or to balance a launch: the tile is 256/KS columns wide, wavefront w multiplies column block
+// w % (8/KS) with every KS-th 32-wide K tile (phase w / (8/KS)), and the KS partial sums are added
+// through LDS at the end.  KS times as many tiles, each with 1/KS of the K-loop iterations.
 template <int MI, int KS>
 __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int col0, const bool new_prob, float *smem,
                                           long long *dbg) {
-    static_assert(KS == 1 || (KS == 2 && MI <= 2), "split-K tiles are small tiles");
+    constexpr int SF = STAGE_FLOATS;        // floats per LDS ring stage
+    R3D_TSTAMP(0);
+    static_assert(KS == 1 || (KS == 2 && MI <= 2) || (KS == 4 && MI == 1), "split-K tiles are small tiles");
+    constexpr int WN = 8 / KS;              // 32-column blocks per tile
     constexpr int VR = KS * MI * 32;        // staged rows per iteration (KS sub-tiles of MI*32 rows x 32 k)
     constexpr int NA = (VR + 63) / 64;      // A staging slots per thread (64 staged rows per slot)
     constexpr bool PRE = MI <= 3;           // pre-read next tile's first A fragments before the barrier
+    // Weight prefetch distance.  A K tile of a small tile is short (MI = 1: ~2k cycles for the two wavefronts
+    // of a SIMD) - shorter than an L2 miss - so W runs two tiles ahead there, with three register sets
+    // rotating (and the A staging registers likewise, loop unrolled by three).  MI >= 5 keeps distance one:
+    // its K tile is long enough and the registers are needed for accumulators.
+    constexpr bool WD2 = MI <= 4;
+    constexpr int AD = WD2 ? 5 : 4;         // A tile t+AD is issued in iteration t, committed to LDS in iteration t+AD-2
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int wn = KS == 2 ? (wave & 3) : wave;     // 32-column block of the tile this wavefront owns
-    const int wk = KS == 2 ? (wave >> 2) : 0;       // which 32-wide K tile of an iteration it multiplies
-    const int M = P.M, N = P.N, K = P.K;
+    const int wn = wave % WN;                       // 32-column block of the tile this wavefront owns
+    const int wk = wave / WN;                       // which 32-wide K tile of an iteration it multiplies
+    const int M = P.M, K = P.K;
     const int nk32 = K / BK;                        // 32-wide K tiles
     const int nk = (nk32 + KS - 1) / KS;            // K-loop iterations
     const int srow = tid >> 3, a_kq = (tid & 7) * 4;
 
     // ---- A staging state
-    int a_row[NA];
-    int a_voff[NA];                         // byte offset of the slot's row/column inside the tile's rows
-    const bool multi = KS == 1 && P.kend[0] < K;   // A is a virtual concatenation of several buffers
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        // staged row -> (sub-tile, row of the tile); staged rows past the tile (odd MI) re-read valid data
-        const int vr = srow + 64 * i, sub = KS == 1 ? 0 : (vr / (MI * 32) < KS ? vr / (MI * 32) : KS - 1);
-        const int gr = row0 + vr - sub * (MI * 32);
-        a_row[i] = gr < M ? gr : M - 1;
-        a_voff[i] = ((a_row[i] - row0) * P.lda[0] + a_kq + sub * BK) * 4;
-    }
-    // Plain operands are read through buffer descriptors whose base (first row of the tile) and K-tile
-    // offset are scalars: a staging load is ONE instruction with no vector address arithmetic.  That
-    // matters because a wavefront's VALU instructions crawl (about one per 64 cycles) while its SIMD
-    // partner streams MFMAs, whereas memory instructions issue freely.
-    __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(P.a[0] + (size_t)row0 * P.lda[0]), 0, 0x7fffffff, 0x00020000);
-    // concatenated operands: K tiles are issued in increasing order, so the segment state (buffer, leading
-    // dimension, first/last K) only ever advances; the descriptor table is touched at segment
-    // boundaries only (<= 3 times per tile).  No scalar loads in the steady-state loop: an SMEM load in
-    // flight would also degrade every counted `s_waitcnt lgkmcnt(N)` in front of the MFMAs to (0).
-    const float *seg_base = P.a[0] + (size_t)row0 * P.lda[0];
+    // A may be a virtual concatenation of up to MAX_SEG buffers (the torch.cat of rie.py:371-407 is never
+    // materialised); a plain operand is the one-segment case.  K tiles are issued in increasing order,
+    // so the segment state (buffer, leading dimension, first/last K) only ever advances and the
+    // descriptor table is touched at segment boundaries only (<= 3 times per tile).  No scalar loads in
+    // the steady-state loop: an SMEM load in flight would also degrade every counted
+    // `s_waitcnt lgkmcnt(N)` in front of the MFMAs to (0).  (Split-K tiles: the scheduler only splits a
+    // concatenated operand when every interior boundary is a multiple of 32*KS, so the KS sub-tiles of
+    // an iteration always lie in one buffer.)
+    // Operands are read through a buffer descriptor whose base (first row of the tile, first column
+    // of the segment) and K-tile offset are scalars: a staging load is ONE instruction with no vector
+    // address arithmetic.  That matters because a wavefront's VALU instructions crawl (about one per
+    // 64 cycles) while its SIMD partner streams MFMAs, whereas memory instructions issue freely.  The
+    // descriptor is bounded at the segment's last valid element: the K tiles a short last split-K
+    // iteration has no use for read zeros instead of memory past the buffer.
+    const bool multi = P.kend[0] < K;
     int seg_ld = P.lda[0], seg_k0 = 0, seg_end = P.kend[0], seg_i = 0;
-    int a_rel[NA], m_voff[NA];              // 4 * (row inside the tile); byte offset of the slot in the current segment
+    int a_voff[NA];                         // byte offset of the slot's 16 bytes inside the segment's tile rows
+    __amdgpu_buffer_rsrc_t arsrc;
+    auto open_seg = [&]() {
+        const float *base = P.a[seg_i] + (size_t)row0 * seg_ld;
+        const long long b = ((long long)(M - 1 - row0) * seg_ld + (seg_end < K ? seg_end : K) - seg_k0) * 4;
+        arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, b < 0x7fffffffLL ? (int)b : 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            // staged row -> (K sub-tile, row of the tile); staged rows past the tile (odd MI) re-read valid data
+            const int vr = srow + 64 * i, sub = KS == 1 ? 0 : (vr / (MI * 32) < KS ? vr / (MI * 32) : KS - 1);
+            const int gr = row0 + vr - sub * (MI * 32);
+            a_voff[i] = (((gr < M ? gr : M - 1) - row0) * seg_ld + a_kq + sub * BK) * 4;
+        }
+    };
+    open_seg();
     auto prep_seg = [&](int kt) {
         if (!multi) return;
-        while (kt * BK >= seg_end) {     // uniform
+        while (kt * (BK * KS) >= seg_end) {     // uniform
             ++seg_i;
             seg_k0 = seg_end;
             seg_ld = P.lda[seg_i];
-            seg_base = P.a[seg_i] + (size_t)row0 * seg_ld;
             seg_end = P.kend[seg_i];
-#pragma unroll
-            for (int i = 0; i < NA; ++i) m_voff[i] = a_rel[i] * seg_ld + a_kq * 4;   // per-segment, not per-tile
+            open_seg();
         }
     };
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        a_rel[i] = (a_row[i] - row0) * 4;
-        m_voff[i] = a_rel[i] * seg_ld + a_kq * 4;
-    }
     struct Staged {                         // one A tile on its way from HBM to LDS
         f32x4 a[NA];
     };
-    Staged ra, ra2;                         // tiles in flight: even / odd tile index
+    Staged ra, ra2, ra3;                    // tiles in flight (ra3: three-set rotation only)
     auto issue_a = [&](int kt, Staged &R) {
-        const int kb = kt * (BK * KS);
-        {
-            // every slot loads unconditionally (rows past the tile are clamped and never consumed): a
-            // predicated load would make the compiler wait for ALL outstanding loads at the merge point
-            if (multi) {
-                // concatenated operand: the K segment of this tile was looked up one iteration ago
-                // (prep_seg), so its scalar-load round trip is off the critical path of short K tiles
-                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(seg_base), 0, 0x7fffffff, 0x00020000);
+        // every slot loads unconditionally (rows past the tile are clamped and never consumed): a
+        // predicated load would make the compiler wait for ALL outstanding loads at the merge point.
+        // The K segment of this tile was looked up one iteration ago (prep_seg), so that scalar-load
+        // round trip is off the critical path of short K tiles.
+        const int kb = kt * (BK * KS) - seg_k0;
 #pragma unroll
-                for (int i = 0; i < NA; ++i)
-                    R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, m_voff[i], (kb - seg_k0) * 4, 0));
-            } else {
-#pragma unroll
-                for (int i = 0; i < NA; ++i)
-                    R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff[i], kb * 4, 0));
-            }
-        }
+        for (int i = 0; i < NA; ++i)
+            R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff[i], kb * 4, 0));
     };
     const int st_off = srow * LDS_LD + a_kq;
     auto commit_a = [&](int stage, const Staged &R) {
         // (stage is uniform: three copies of the stores with immediate offsets, no address arithmetic)
-        float *s = stage == 0 ? smem + st_off : stage == 1 ? smem + STAGE_FLOATS + st_off : smem + 2 * STAGE_FLOATS + st_off;
+        float *s = stage == 0 ? smem + st_off : stage == 1 ? smem + SF + st_off : smem + 2 * SF + st_off;
         {
 #pragma unroll
             for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(s + i * 64 * LDS_LD) = R.a[i];
@@ -217,15 +234,15 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
     // ---- W fragments: [(n/32)][k tile][q][lane][4] in HBM, this wavefront's 32 columns
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // make the descriptor provably wave-uniform
     __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(P.w + ((size_t)((col0 >> 5) + (KS == 2 ? (wave_u & 3) : wave_u)) * nk32) * 1024), 0, nk32 * 4096,
+        const_cast<float *>(P.w + ((size_t)((col0 >> 5) + wave_u % WN) * nk32) * 1024), 0, nk32 * 4096,
         0x00020000);   // (K tiles past the end read as zeros through the descriptor's bound)
     const int w_voff = lane * 16;
-    f32x4 rb[4], rbn[4];                    // W fragments of the current and the next K tile
+    f32x4 rb[4], rbn[4], rbn2[4];           // W fragments of the current and the next K tile(s)
     auto load_w = [&](int kt, f32x4 (&dst)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             dst[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                wrsrc, w_voff + q * 1024, (kt * KS + (KS == 2 ? (wave_u >> 2) : 0)) * 4096, 0));
+                wrsrc, w_voff + q * 1024, (kt * KS + wave_u / WN) * 4096, 0));
     };
 
     f32x16 acc[MI];
@@ -242,8 +259,9 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
     // tile is free, while a branch around a load makes the compiler's s_waitcnt placement pessimistic)
     const int last = nk - 1;
     load_w(0, rb);
+    if (WD2) load_w(1 < last ? 1 : last, rbn);
     {
-        Staged r0, r1;                      // four tiles in flight at once: one HBM latency, not four
+        Staged r0, r1;                      // all prologue tiles in flight at once: one HBM latency, not four
         issue_a(0, r0);
         prep_seg(1 < last ? 1 : last);
         issue_a(1 < last ? 1 : last, r1);
@@ -252,6 +270,10 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
         prep_seg(3 < last ? 3 : last);
         issue_a(3 < last ? 3 : last, ra2);
         prep_seg(4 < last ? 4 : last);
+        if (WD2) {
+            issue_a(4 < last ? 4 : last, ra3);
+            prep_seg(5 < last ? 5 : last);
+        }
         commit_a(0, r0);
         commit_a(1, r1);
     }
@@ -260,11 +282,7 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) av0[mi] = *reinterpret_cast<const f32x4 *>(smem + a_frag + mi * 32 * LDS_LD);
     }
-#ifdef R3D_TIMING
-#define R3D_STAMP(slot) do { if (dbg && lane == 0 && kt < 4) dbg[wave * 32 + kt * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define R3D_STAMP(slot) do { } while (0)
-#endif
+    R3D_TSTAMP(1);
     int st_cur = 0;                              // kt % 3 without a division
     // One K tile.  `w_use` holds this tile's W fragments, `w_load` receives the next tile's: the two
     // register sets swap roles every tile (loop unrolled by two) instead of being copied - a copy
@@ -276,8 +294,8 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
     auto k_tile = [&](int kt, f32x4 (&w_use)[4], f32x4 (&w_load)[4], Staged &stg) {
         R3D_STAMP(0);
         const int st_next = st_cur == 2 ? 0 : st_cur + 1, st_next2 = st_next == 2 ? 0 : st_next + 1;
-        const float *s = smem + st_cur * STAGE_FLOATS + a_frag;
-        const bool active = KS == 1 || kt * KS + (wave_u >> 2) < nk32;   // odd K-tile count: last iteration has one tile
+        const float *s = smem + st_cur * SF + a_frag;
+        const bool active = KS == 1 || kt * KS + wave_u / WN < nk32;   // K-tile count not a multiple of KS: short last iteration
         auto mfma_q = [&](int q) {
             if (!active) return;
             f32x4 av[MI];
@@ -299,26 +317,26 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
         constexpr bool INTERLEAVE = MI >= 3;
         if (!INTERLEAVE) {
             commit_a(st_next2, stg);                 // tile kt+2, issued two iterations ago (before newer loads: vmcnt order)
-            load_w(kt + 1 < last ? kt + 1 : last, w_load);
-            issue_a(kt + 4 < last ? kt + 4 : last, stg);
-            prep_seg(kt + 5 < last ? kt + 5 : last);
+            load_w(kt + (WD2 ? 2 : 1) < last ? kt + (WD2 ? 2 : 1) : last, w_load);
+            issue_a(kt + AD < last ? kt + AD : last, stg);
+            prep_seg(kt + AD + 1 < last ? kt + AD + 1 : last);
         }
         R3D_STAMP(1);
         mfma_q(0);
         if (INTERLEAVE) {
             commit_a(st_next2, stg);
-            load_w(kt + 1 < last ? kt + 1 : last, w_load);
+            load_w(kt + (WD2 ? 2 : 1) < last ? kt + (WD2 ? 2 : 1) : last, w_load);
         }
         mfma_q(1);
         if (INTERLEAVE) {
-            issue_a(kt + 4 < last ? kt + 4 : last, stg);
-            prep_seg(kt + 5 < last ? kt + 5 : last);
+            issue_a(kt + AD < last ? kt + AD : last, stg);
+            prep_seg(kt + AD + 1 < last ? kt + AD + 1 : last);
         }
         mfma_q(2);
         mfma_q(3);
         R3D_STAMP(2);
         if (PRE) {
-            const float *sn = smem + st_next * STAGE_FLOATS + a_frag;
+            const float *sn = smem + st_next * SF + a_frag;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) av0[mi] = *reinterpret_cast<const f32x4 *>(sn + mi * 32 * LDS_LD);
         }
@@ -328,71 +346,52 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
         st_cur = st_next;
     };
     int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        k_tile(kt, rb, rbn, ra);
-        k_tile(kt + 1, rbn, rb, ra2);
+    if (WD2) {
+        // tile t multiplies with W set t % 3 while tile t+2's fragments land in set (t+2) % 3
+        for (; kt + 2 < nk; kt += 3) {
+            k_tile(kt, rb, rbn2, ra);
+            k_tile(kt + 1, rbn, rb, ra2);
+            k_tile(kt + 2, rbn2, rbn, ra3);
+        }
+        if (kt < nk) {
+            k_tile(kt, rb, rbn2, ra);
+            if (kt + 1 < nk) k_tile(kt + 1, rbn, rb, ra2);
+        }
+    } else {
+        for (; kt + 1 < nk; kt += 2) {
+            k_tile(kt, rb, rbn, ra);
+            k_tile(kt + 1, rbn, rb, ra2);
+        }
+        if (kt < nk) k_tile(kt, rb, rbn, ra);
     }
-    if (kt < nk) k_tile(kt, rb, rbn, ra);
 
-    // epilogue: C = res + lrelu(acc + bias).  C/D layout of the 32x32 MFMA: col = lane & 31,
-    // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  A wavefront store instruction writes two
-    // 128-byte row pieces (lanes 0-31 and 32-63).
-    if (KS == 2) {
-        // add the odd-K-tile partial sums (wavefronts 4-7) to the even ones through LDS (ring is idle now)
+    // ---- epilogue
+    R3D_TSTAMP(2);
+    if (KS > 1) {
+        // add the partial sums of the K phases 1..KS-1 to phase 0's through LDS (the ring is idle now)
+        // (slot of phase 0 stays unused: non-negative offsets fold into the ds instructions' immediates)
+        constexpr int PHASE_FLOATS = WN * MI * 16 * 64;
         float *red = smem + ((wn * MI) * 16) * 64 + lane;
-        if (wk == 1) {
+        if (wk > 0) {
+            float *mine = red + wk * PHASE_FLOATS;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[(mi * 16 + r) * 64] = acc[mi][r];
+                for (int r = 0; r < 16; ++r) mine[(mi * 16 + r) * 64] = acc[mi][r];
         }
         __syncthreads();
-        if (wk == 1) return;
+        if (wk == 0) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+            for (int ph = 1; ph < KS; ++ph)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][r] += red[(mi * 16 + r) * 64];
-    }
-    if (KS == 1) {
-        store_tile_256<MI>(P, acc, row0, col0, smem);
-        return;
-    }
-    // split-K tiles (128 columns, small launches): direct stores from the MFMA layout
-    const int col = col0 + wn * 32 + li;
-    const float slope = P.slope;
-    const float *res = P.res;
-    float *c = P.c;
-    const int ldc = P.ldc, ldr = P.ldr;
-    const float bias = gload1(P.bias + col);
-    const bool full = (row0 + MI * 32 <= M) && (col0 + GEMM_BN / KS <= N);   // wave-uniform
-    if (full) {
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const size_t rbase = (size_t)(row0 + mi * 32 + 4 * lh);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const size_t row = rbase + (r & 3) + 8 * (r >> 2);
-                float v = acc[mi][r] + bias;
-                v = v > 0.0f ? v : v * slope;
-                if (res) v += gload1(res + row * ldr + col);
-                gstore1(c + row * ldc + col, v);
-            }
-        }
-    } else if (col < N) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < M) {
-                    float v = acc[mi][r] + bias;
-                    v = v > 0.0f ? v : v * slope;
-                    if (res) v += gload1(res + (size_t)row * ldr + col);
-                    gstore1(c + (size_t)row * ldc + col, v);
-                }
-            }
+                    for (int r = 0; r < 16; ++r) acc[mi][r] += red[ph * PHASE_FLOATS + (mi * 16 + r) * 64];
         }
     }
+    R3D_TSTAMP(3);
+    store_tile<MI, KS>(P, acc, row0, col0, smem);
+    R3D_TSTAMP(4);
 }
 
 // ------------------------------------------------------------------------------------ first layers
@@ -410,7 +409,8 @@ constexpr int ENC_TILE_BYTES = 64 * 1024;                  // encoded tile: rows
 constexpr int ENC_LDS_BYTES = ENC_TILE_BYTES + LUT_LDS_INTS * 4;
 
 template <int MI>
-__device__ __forceinline__ void enc_tile(ProbRef P, const int row0, const int col0, const bool new_prob, float *smem) {
+__device__ __forceinline__ void enc_tile(ProbRef P, const int row0, const int col0, const bool new_prob, float *smem, long long *dbg) {
+    R3D_TSTAMP(0);
     constexpr int R = MI * 32;
     constexpr int NA = (R + 63) / 64;
     const int tid = threadIdx.x;
@@ -484,6 +484,7 @@ __device__ __forceinline__ void enc_tile(ProbRef P, const int row0, const int co
         if (kt < nk) commit(kt, r0);
     }
     __syncthreads();
+    R3D_TSTAMP(1);
 
     // ---- barrier-free MFMA loop: A fragments from the LDS tile, W fragments straight from HBM
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -527,7 +528,10 @@ __device__ __forceinline__ void enc_tile(ProbRef P, const int row0, const int co
     if (kt < nk) k_tile(kt, rb, rbn);
 
     // ---- epilogue: C = lrelu(acc + bias) through the LDS transpose (the encoded tile is dead by now)
-    store_tile_256<MI>(P, acc, row0, col0, smem);
+    R3D_TSTAMP(2);
+    R3D_TSTAMP(3);
+    store_tile<MI, 1>(P, acc, row0, col0, smem);
+    R3D_TSTAMP(4);
 }
 
 template <bool ENC>
@@ -544,14 +548,13 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
     const int t1 = __builtin_amdgcn_readfirstlane(args->wg_off[wg + 1]);
     long long *dbg = nullptr;
 #ifdef R3D_TIMING
-    if (args->dbg && wg < 4) dbg = args->dbg + wg * 256;   // 8 waves x 4 K tiles x 8 stamps
+    long long *dbg_base = args->dbg && wg < 16 ? args->dbg + 6144 + wg * 64 : nullptr;   // 8 tiles x 8 stamps
     if (args->dbg && threadIdx.x == 0) {
         args->dbg[1024 + wg * 4 + 0] = __builtin_readcyclecounter();
         args->dbg[1024 + wg * 4 + 2] = wall_clock64();
     }
 #endif
     int prev_pi = -1;
-    const int ks = args->ks;
     for (int t = t0; t < t1; ++t) {
         const int4 td = args->tiles[t];
         const int pi = __builtin_amdgcn_readfirstlane(td.x & 0xff);
@@ -560,19 +563,23 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
         const int mi = __builtin_amdgcn_readfirstlane(td.x >> 8);
         const int row0 = __builtin_amdgcn_readfirstlane(td.y);
         const int col0 = __builtin_amdgcn_readfirstlane(td.z);
+        const int ks = __builtin_amdgcn_readfirstlane(td.w);      // split-K factor of this tile (1, 2 or 4)
         ProbRef P = args->p[pi];
+#ifdef R3D_TIMING
+        dbg = dbg_base && t - t0 < 8 ? dbg_base + (t - t0) * 8 : nullptr;
+#endif
         if constexpr (ENC) {
-            (void)ks; (void)dbg;
+            (void)ks;
             switch (mi) {
-                case 1: enc_tile<1>(P, row0, col0, new_prob, smem); break;
-                case 2: enc_tile<2>(P, row0, col0, new_prob, smem); break;
-                default: enc_tile<3>(P, row0, col0, new_prob, smem); break;
+                case 1: enc_tile<1>(P, row0, col0, new_prob, smem, dbg); break;
+                case 2: enc_tile<2>(P, row0, col0, new_prob, smem, dbg); break;
+                default: enc_tile<3>(P, row0, col0, new_prob, smem, dbg); break;
             }
         } else {
-            if (ks == 2) {
-                if (mi == 1) gemm_tile<1, 2>(P, row0, col0, new_prob, smem, dbg);
+            if (ks > 1) {
+                if (ks == 4) gemm_tile<1, 4>(P, row0, col0, new_prob, smem, dbg);
+                else if (mi == 1) gemm_tile<1, 2>(P, row0, col0, new_prob, smem, dbg);
                 else gemm_tile<2, 2>(P, row0, col0, new_prob, smem, dbg);
-                __syncthreads();   // (half of the wavefronts leave a split-K tile early)
                 continue;
             }
             switch (mi) {
@@ -607,7 +614,7 @@ extern "C" __global__ __launch_bounds__(GEMM_THREADS, 4) void r3d_gemm_enc_f32(c
     gemm_persistent<true>(smem);
 }
 
-hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, bool encode, hipStream_t stream) {
+hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, int kind, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
         // 83 KiB of dynamic LDS exceeds the 64 KiB default cap
@@ -619,7 +626,7 @@ hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, bool encode, hipSt
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    if (encode)
+    if (kind == STAGE_ENC)
         r3d_gemm_enc_f32<<<dim3(nwg), dim3(GEMM_THREADS), ENC_LDS_BYTES, stream>>>(args);
     else
         r3d_gemm_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
@@ -633,6 +640,7 @@ hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, bool encode, hipSt
 // ray = ((u-cx)/fx, c*y + s, -s*y + c) with y = (v-cy)/fy.  (2) camera-embedding MLP
 // (lib/model/embedding.py:15-18; LeakyReLU slope 0.01, BatchNorm folded) for each network.
 extern "C" __global__ __launch_bounds__(256) void r3d_prologue_f32(const PrologueArgs a) {
+    __shared__ float wl[EMBED_MID * 8 + EMBED_MID + 128 * EMBED_MID + 128];   // w1 | b1 | w2^T | b2 (E <= 8, D <= 128)
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (a.uv) {
         const long long n = a.frames * a.J;
@@ -649,19 +657,50 @@ extern "C" __global__ __launch_bounds__(256) void r3d_prologue_f32(const Prologu
             a.rays[gid * 3 + 2] = (float)(-cam[5] * y + cam[4]);
         }
     }
+    // Embedding MLPs: the (tiny) weights go through LDS once per block instead of one dependent global
+    // load per multiply; w2 is stored transposed so that neighbouring outputs read neighbouring banks.
     for (int m = 0; m < a.nembed; ++m) {
         const int D = a.emb_dim[m], E = a.E;
+        if ((long long)blockIdx.x * blockDim.x >= a.B * D) break;        // block-uniform
+        const float *g = a.emb_w[m];
+        float *w1 = wl, *b1 = w1 + EMBED_MID * E, *w2t = b1 + EMBED_MID, *b2 = w2t + D * EMBED_MID;
+        __syncthreads();
+        {
+            // every load of the block is issued before the first LDS write: one memory round trip, not
+            // one per loop iteration (indices past the packed block are clamped and never stored)
+            const int n1 = EMBED_MID * E + EMBED_MID, n2 = D * EMBED_MID, tot = n1 + n2 + D;
+            float t1[2], t2[16], t3;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) t1[j] = gload1(g + min((int)threadIdx.x + 256 * j, tot - 1));
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t2[j] = gload1(g + min(n1 + (int)threadIdx.x + 256 * j, tot - 1));
+            t3 = gload1(g + min(n1 + n2 + (int)threadIdx.x, tot - 1));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if ((int)threadIdx.x + 256 * j < n1) wl[threadIdx.x + 256 * j] = t1[j];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int i = threadIdx.x + 256 * j;
+                if (i < n2) w2t[(i % EMBED_MID) * D + i / EMBED_MID] = t2[j];
+            }
+            if ((int)threadIdx.x < D) b2[threadIdx.x] = t3;
+        }
+        __syncthreads();
         if (gid >= a.B * D) continue;
         const long long b = gid / D;
         const int o = (int)(gid - b * D);
-        const float *w1 = a.emb_w[m], *b1 = w1 + EMBED_MID * E, *w2 = b1 + EMBED_MID, *b2 = w2 + D * EMBED_MID;
         const float *p = a.param + b * a.param_stride;
+        float pv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pv[e] = e < E ? gload1(p + e) : 0.0f;
         float acc = b2[o];
         for (int k = 0; k < EMBED_MID; ++k) {
             float h = b1[k];
-            for (int e = 0; e < E; ++e) h += w1[k * E + e] * p[e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e < E) h += w1[k * E + e] * pv[e];
             h = h > 0.0f ? h : 0.01f * h;
-            acc += w2[o * EMBED_MID + k] * h;
+            acc += w2t[k * D + o] * h;
         }
         a.emb_out[m][gid] = acc > 0.0f ? acc : 0.01f * acc;
     }
@@ -683,23 +722,32 @@ hipError_t launch_prologue(const PrologueArgs &args, hipStream_t stream) {
 // trajectory broadcast add (lib/train_val/trainer.py:353).  Every body-part wavefront recomputes the
 // 3-output trajectory head itself - cheaper than a dependency between wavefronts.  These layers are
 // 0.05 % of the FLOPs; as GEMMs their N = 3..15 would waste a 256-column tile.
-__device__ __forceinline__ void decode_dot3(const f32x4 (&hv)[4], const float *w, int lane, float (&o)[3]) {
-    f32x4 wv[3][4];
+// NJ joints (3 output rows each) of one decoder: loads first, all of them, then the reductions - the
+// whole group costs one memory round trip.  Rows past the decoder's last are clamped and discarded.
+template <int NJ>
+struct DecodeRows {
+    f32x4 w[NJ * 3][4];
+    __device__ __forceinline__ void load(const float *wbase, int o0, int n_out, int lane) {
 #pragma unroll
-    for (int n = 0; n < 3; ++n)
+        for (int n = 0; n < NJ * 3; ++n) {
+            const int row = o0 + n < n_out ? o0 + n : n_out - 1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wv[n][j] = gload4(w + (size_t)n * MLP_HIDDEN + j * 256 + lane * 4);
-#pragma unroll
-    for (int n = 0; n < 3; ++n) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            acc += hv[j][0] * wv[n][j][0] + hv[j][1] * wv[n][j][1] + hv[j][2] * wv[n][j][2] + hv[j][3] * wv[n][j][3];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
-        o[n] = acc;
+            for (int j = 0; j < 4; ++j) w[n][j] = gload4(wbase + (size_t)row * MLP_HIDDEN + j * 256 + lane * 4);
+        }
     }
-}
+    __device__ __forceinline__ void dot(const f32x4 (&hv)[4], float (&o)[NJ * 3]) const {
+#pragma unroll
+        for (int n = 0; n < NJ * 3; ++n) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc += hv[j][0] * w[n][j][0] + hv[j][1] * w[n][j][1] + hv[j][2] * w[n][j][2] + hv[j][3] * w[n][j][3];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+            o[n] = acc;
+        }
+    }
+};
 
 extern "C" __global__ __launch_bounds__(256) void r3d_decode_f32(const DecodeArgs a) {
     const int lane = threadIdx.x & 63;
@@ -709,13 +757,24 @@ extern "C" __global__ __launch_bounds__(256) void r3d_decode_f32(const DecodeArg
     const long long b = gw / per_win;
     if (b >= a.B) return;
     const int s = (int)(gw - b * per_win);
+    const int ts = a.nsrc - 1;
+    // round A: the trajectory head and the part's first two joints, one memory round trip
+    f32x4 hv[4], ht[4];
+    DecodeRows<1> rt;
+    DecodeRows<2> ra;
+    if (a.has_trj) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ht[j] = gload4(a.h[ts] + b * MLP_HIDDEN + j * 256 + lane * 4);
+        rt.load(a.w[ts], 0, 3, lane);
+    }
+    if (a.has_pos) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hv[j] = gload4(a.h[s] + b * MLP_HIDDEN + j * 256 + lane * 4);
+        ra.load(a.w[s], 0, a.n_out[s], lane);
+    }
     float trj[3] = {0.0f, 0.0f, 0.0f};
     if (a.has_trj) {
-        const int ts = a.nsrc - 1;
-        f32x4 hv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) hv[j] = gload4(a.h[ts] + b * MLP_HIDDEN + j * 256 + lane * 4);
-        decode_dot3(hv, a.w[ts], lane, trj);
+        rt.dot(ht, trj);
 #pragma unroll
         for (int n = 0; n < 3; ++n) trj[n] += a.bias[ts][n];
         if (lane == 0 && s == 0) {
@@ -727,17 +786,29 @@ extern "C" __global__ __launch_bounds__(256) void r3d_decode_f32(const DecodeArg
         }
     }
     if (!a.has_pos) return;
-    f32x4 hv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) hv[j] = gload4(a.h[s] + b * MLP_HIDDEN + j * 256 + lane * 4);
-    for (int o = 0; o < a.n_out[s]; o += 3) {      // one joint per iteration
-        float v[3];
-        decode_dot3(hv, a.w[s] + (size_t)o * MLP_HIDDEN, lane, v);
-        if (lane == 0) {
-            const int e = a.slot[a.first[s] + o];   // (x, y, z) of a joint are consecutive in the output
+    const int n_out = a.n_out[s];
+    // round B's loads go out before round A is reduced
+    DecodeRows<3> rb;
+    if (n_out > 6) rb.load(a.w[s], 6, n_out, lane);
+    auto emit = [&](int o, const float *v) {      // (x, y, z) of a joint are consecutive in the output
+        if (lane == 0 && o < n_out) {
+            const int e = a.slot[a.first[s] + o];
 #pragma unroll
             for (int n = 0; n < 3; ++n) a.out[b * (a.J * 3) + e + n] = v[n] + a.bias[s][o + n] + trj[n];
         }
+    };
+    {
+        float v[6];
+        ra.dot(hv, v);
+        emit(0, v);
+        emit(3, v + 3);
+    }
+    if (n_out > 6) {
+        float v[9];
+        rb.dot(hv, v);
+        emit(6, v);
+        emit(9, v + 3);
+        emit(12, v + 6);
     }
 }
 

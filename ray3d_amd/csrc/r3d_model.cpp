@@ -138,8 +138,8 @@ Model *model_create(const r3d_config &cfg) {
         return nullptr;
     }
     const bool emb = cfg.extrinsic_dim > 0 && cfg.embed_dim > 0;
-    if (emb && (cfg.embed_dim % BK || cfg.extrinsic_dim > 16)) {
-        set_error("embed_dim must be a multiple of %d and extrinsic_dim <= 16", BK);
+    if (emb && (cfg.embed_dim % BK || cfg.embed_dim > 128 || cfg.extrinsic_dim > 8)) {
+        set_error("embed_dim must be a multiple of %d (<= 128) and extrinsic_dim <= 8", BK);
         return nullptr;
     }
     if (cfg.kind == R3D_KIND_POS && cfg.stage < 1) { set_error("stage must be >= 1"); return nullptr; }

@@ -2,6 +2,8 @@
 //
 // A launch (one DAG level of the plan) consists of independent 32-row x 256-column "units", one
 // per (problem, column block, row block); a unit of problem p costs ~ K_p/32 K-tiles of MFMA work.
+// Problems whose units are coarse against a workgroup's share (the M = B MLP layers, the top of the
+// conv pyramid) are cut further along K: 32 x 128 or 32 x 64 split-K units (r3d_kernels.hip, KS).
 // With one workgroup per CU the only scheduling freedom is how many units each workgroup gets, so
 // the host cuts the unit sequence into `nwg` contiguous chunks of (nearly) equal cost.  Contiguity
 // keeps a workgroup - and, through the XCD-aware chunk order in the kernel, an XCD - on one
@@ -37,90 +39,169 @@ int device_cu_count() {
 
 namespace {
 
-struct Segment {
-    int prob;      // index inside the launch
-    int col0;
-    int units;     // 32-row units
-    int M;
-    double unit_cost;
-    int max_units; // largest tile of this problem
+// Cycles of one SIMD for a 32-row unit: two wavefronts share the pipe, 16 MFMAs x 64 cycles each per
+// K-loop iteration (2048), plus staging/barrier overhead per iteration and a share of the tile
+// prologue/epilogue.  Calibrated with the phase stamps of tools/gemm_probe -DR3D_TIMING at 2.2 GHz: a
+// split-K piece (one unit per tile) pays 1.5 us of prologue latency, 0.4 us of reduction, 0.8 us of
+// epilogue and 0.4 us between tiles, and 1.17 us per iteration; units of the wide tiles share one
+// prologue and run at 1.0 us per iteration.
+double unit_cycles(int iters, int ks) { return ks > 1 ? iters * 2600.0 + 6800.0 : iters * 2200.0 + 2500.0; }
+
+struct Run {           // `n` consecutive row units of one column block, all in one workgroup's chunk
+    int prob, col0, ks, u0, n, cap;
 };
 
-// cycles of one SIMD for a unit: two wavefronts share the pipe, 16 MFMAs x 64 cycles each per
-// K tile, plus staging/barrier overhead per K tile and a share of the tile prologue/epilogue
-double unit_cycles(int nk) { return nk * (2048.0 + 120.0) + 1500.0; }
+struct Seg {           // one column block of a problem
+    int prob, col0, units, nk, cap, max_ks;
+    double c1;
+};
+
+struct Assignment {
+    std::vector<std::vector<Run>> bins;
+    double worst = 0;
+};
+
+// First-fit-decreasing feasibility test for a chunk budget T.  Phase 1 places whole units (largest
+// first, consecutive units of a column block into consecutive workgroups: weights and rows stay
+// local).  Units that found no room - or are larger than T altogether - are cut along K into `ksplit`
+// column sub-blocks (split-K tiles) and fill the remaining room.
+bool assign(const std::vector<Seg> &segs, int nbins, double T, int ksplit, Assignment *out) {
+    std::vector<double> room(nbins, T);
+    if (out) out->bins.assign(nbins, {});
+    struct Left { const Seg *s; int u0; };
+    std::vector<Left> left;
+    int cursor = 0;
+    double cursor_cost = -1;
+    for (const Seg &s : segs) {          // sorted by c1, descending
+        if (s.c1 != cursor_cost) { cursor = 0; cursor_cost = s.c1; }
+        int u = 0;
+        if (s.c1 <= T) {
+            while (u < s.units) {
+                while (cursor < nbins && room[cursor] + 1e-6 < s.c1) ++cursor;
+                if (cursor == nbins) break;
+                const int take = std::min((int)std::floor((room[cursor] + 1e-6) / s.c1), s.units - u);
+                room[cursor] -= take * s.c1;
+                if (out) out->bins[cursor].push_back({s.prob, s.col0, 1, u, take, s.cap});
+                u += take;
+            }
+        }
+        if (u < s.units) {
+            if (s.max_ks < 2) return false;
+            left.push_back({&s, u});
+        }
+    }
+    // phase 2: split-K pieces, largest first
+    std::stable_sort(left.begin(), left.end(), [](const Left &a, const Left &b) { return a.s->nk > b.s->nk; });
+    cursor = 0;
+    cursor_cost = -1;
+    for (const Left &l : left) {
+        const Seg &s = *l.s;
+        int ks = std::min(ksplit, s.max_ks);
+        while (ks > 1 && s.nk / ks < 2) ks /= 2;              // keep at least two K-loop iterations
+        if (ks == 1) return false;
+        const double ck = unit_cycles((s.nk + ks - 1) / ks, ks);
+        if (ck > T) return false;
+        if (ck != cursor_cost) { cursor = 0; cursor_cost = ck; }
+        for (int j = 0; j < ks; ++j) {
+            int u = l.u0;
+            while (u < s.units) {
+                while (cursor < nbins && room[cursor] + 1e-6 < ck) ++cursor;
+                if (cursor == nbins) return false;
+                const int take = std::min((int)std::floor((room[cursor] + 1e-6) / ck), s.units - u);
+                room[cursor] -= take * ck;
+                if (out) out->bins[cursor].push_back({s.prob, s.col0 + j * (256 / ks), ks, u, take, ks == 2 ? 2 : 1});
+                u += take;
+            }
+        }
+    }
+    if (out) {
+        out->worst = 0;
+        for (double r : room) out->worst = std::max(out->worst, T - r);
+    }
+    return true;
+}
+
+}  // namespace
+
+namespace {
+
+struct Packed {
+    Assignment a;
+    double T = 0, total = 0;
+    int ks = 0;
+};
+
+// smallest feasible chunk budget for `nbins` workgroups and tiles of at most `max_units` row units
+void pack(const std::vector<SchedProb> &probs, int nbins_max, int max_units, Packed &out) {
+    std::vector<Seg> segs;
+    double total = 0, biggest_fixed = 0;
+    long long total_units = 0;
+    for (int i = 0; i < (int)probs.size(); ++i) {
+        const SchedProb &p = probs[i];
+        const int units = (p.M + 31) / 32;
+        const double c1 = unit_cycles(p.nk, 1);
+        for (int c0 = 0; c0 < p.N; c0 += 256) {
+            segs.push_back({i, c0, units, p.nk, p.max_units > 0 ? std::min(p.max_units, max_units) : max_units, p.max_ks, c1});
+            total += units * c1;
+            total_units += units;
+        }
+        if (p.max_ks < 2) biggest_fixed = std::max(biggest_fixed, c1);
+    }
+    std::stable_sort(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) { return a.c1 > b.c1; });
+    const int nbins = (int)std::min<long long>(nbins_max, std::max<long long>(total_units * 4, 1));
+    // split-K pieces of 128 and of 64 columns; wider pieces win ties
+    out.ks = 0;
+    for (int ksplit = 2; ksplit <= 4; ksplit *= 2) {
+        double lo = std::max(total / nbins, biggest_fixed), hi = std::max(total, lo) + 1.0;
+        for (const Seg &s : segs) hi = std::max(hi, s.c1 * s.units + 1.0);
+        if (assign(segs, nbins, lo, ksplit, nullptr)) hi = lo;
+        for (int it = 0; it < 40 && hi - lo > 16.0; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (assign(segs, nbins, mid, ksplit, nullptr)) hi = mid; else lo = mid;
+        }
+        if (out.ks == 0 || hi < out.T * 0.98) {
+            out.T = hi;
+            out.ks = ksplit;
+        }
+    }
+    assign(segs, nbins, out.T, out.ks, &out.a);
+    out.total = total;
+}
 
 }  // namespace
 
 void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units, std::vector<int4> &tiles,
-                    std::vector<int> &wgoff, StageSchedule &out) {
-    // Launches that cannot give every CU a unit switch to split-K tiles (128 columns wide, the two K
-    // halves computed by different wavefronts of the workgroup): twice the units, half the K loop.
-    long long units256 = 0;
-    bool all_plain = true;
-    for (const auto &p : probs) {
-        units256 += (long long)((p.M + 31) / 32) * ((p.N + 255) / 256);
-        all_plain = all_plain && p.plain;
-    }
-    const int ks = (all_plain && units256 * 2 <= (long long)nwg) ? 2 : 1;   // only pays when the doubled units still fit one round
-    out.ks = ks;
-    if (ks == 2) max_units = 2;
-    const int bn = 256 / ks;
-    std::vector<Segment> segs;
-    double total = 0;
-    for (int i = 0; i < (int)probs.size(); ++i) {
-        const int units = (probs[i].M + 31) / 32;
-        const double cost = unit_cycles((probs[i].nk + ks - 1) / ks);
-        for (int c0 = 0; c0 < probs[i].N; c0 += bn) {
-            segs.push_back({i, c0, units, probs[i].M, cost, probs[i].max_units > 0 ? std::min(probs[i].max_units, max_units) : max_units});
-            total += units * cost;
-        }
-    }
-    long long total_units = 0;
-    for (auto &s : segs) total_units += s.units;
-    const int grid = (int)std::min<long long>(nwg, std::max<long long>(total_units, 1));
-    out.nwg = grid;
+                    std::vector<int> &wgoff, StageSchedule &out, bool enc) {
+    Packed big;
+    const Packed *best = &big;
+    out.kind = enc ? STAGE_ENC : STAGE_BIG;
+    pack(probs, nwg, max_units, big);
+    out.ks = 1;
     out.tiles_off = tiles.size();
     out.wgoff_off = wgoff.size();
-    // sweep: chunk c ends where the running cost crosses (c+1) * total / grid
-    const double target = total / grid;
-    double run = 0, worst = 0, chunk_cost = 0;
-    int chunk = 0;
-    wgoff.push_back((int)(tiles.size() - out.tiles_off));
-    auto close_chunk = [&]() {
-        worst = std::max(worst, chunk_cost);
-        chunk_cost = 0;
-        ++chunk;
-        wgoff.push_back((int)(tiles.size() - out.tiles_off));
-    };
-    for (const Segment &s : segs) {
-        int u = 0;
-        while (u < s.units) {
-            // how many units of this segment still fit in the current chunk
-            const double room = (chunk + 1) * target - run;
-            int take = (int)std::floor(room / s.unit_cost + 0.5);
-            if (chunk == grid - 1) take = s.units - u;          // last chunk absorbs the remainder
-            take = std::max(take, chunk_cost == 0 ? 1 : 0);
-            take = std::min(take, s.units - u);
-            if (take > 0) {
-                // emit `take` units as evenly sized tiles of <= max_units units
-                const int nt = (take + s.max_units - 1) / s.max_units;
-                int done = 0;
-                for (int k = 0; k < nt; ++k) {
-                    const int sz = (take - done + (nt - k) - 1) / (nt - k);
-                    tiles.push_back(make_int4(s.prob | (sz << 8), (u + done) * 32, s.col0, 0));
-                    done += sz;
-                }
-                u += take;
-                run += take * s.unit_cost;
-                chunk_cost += take * s.unit_cost;
+    const size_t t0 = tiles.size();
+    int grid = 0;
+    wgoff.push_back(0);
+    for (const auto &bin : best->a.bins) {
+        if (bin.empty()) continue;
+        for (const Run &r : bin) {
+            // emit the run as evenly sized tiles of <= cap units
+            const int nt = (r.n + r.cap - 1) / r.cap;
+            int done = 0;
+            for (int k = 0; k < nt; ++k) {
+                const int sz = (r.n - done + (nt - k) - 1) / (nt - k);
+                tiles.push_back(make_int4(r.prob | (sz << 8), (r.u0 + done) * 32, r.col0, r.ks));
+                done += sz;
             }
-            if (chunk < grid - 1 && run >= (chunk + 1) * target - 0.5 * s.unit_cost) close_chunk();
+            out.ks = std::max(out.ks, r.ks);
         }
+        wgoff.push_back((int)(tiles.size() - t0));
+        ++grid;
     }
-    while (chunk < grid) close_chunk();
-    out.ntiles = (int)(tiles.size() - out.tiles_off);
-    out.imbalance = worst / std::max(target, 1.0);
+    if (grid == 0) { wgoff.push_back(0); grid = 1; }
+    out.nwg = grid;
+    out.ntiles = (int)(tiles.size() - t0);
+    out.imbalance = best->a.worst / std::max(best->total / grid, 1.0);
 }
 
 static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, int nwg, std::vector<int4> &tiles,
@@ -133,14 +214,20 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
         const int M = (int)(B * q.rows_per_window);
         // fused-prologue tiles hold the whole encoded operand in 64 KiB of LDS: rows * (K + 4) floats
         const int enc_cap = q.enc_lut >= 0 ? std::max(1, std::min(3, (64 * 1024) / ((L.Kpad + 4) * 4 * 32))) : 0;
-        probs.push_back({M, L.N, L.Kpad / BK, q.enc_lut < 0 && q.nseg == 1, enc_cap});
+        // split-K sub-tiles of one iteration must come from one buffer of a concatenated operand
+        int max_ks = q.enc_lut >= 0 ? 1 : 4;
+        for (int sgi = 0, k = 0; sgi + 1 < q.nseg; ++sgi) {
+            k += q.seg[sgi].width;
+            while (max_ks > 1 && k % (BK * max_ks)) max_ks /= 2;
+        }
+        probs.push_back({M, L.N, L.Kpad / BK, max_ks, enc_cap});
         flops += q.flops_per_window * (double)B;
         bytes += 4.0 * ((double)M * L.K + (double)L.N * L.K + (double)M * L.N * (q.res_buf >= 0 ? 2.0 : 1.0));
     }
     bool enc = false;
     for (int id : st) enc = enc || pl->probs[id].enc_lut >= 0;
     // the fused-prologue kernel runs two workgroups per CU (one encodes while the other multiplies)
-    schedule_stage(probs, enc ? 2 * nwg : nwg, 6, tiles, wgoff, out);
+    schedule_stage(probs, enc ? 2 * nwg : nwg, 6, tiles, wgoff, out, enc);
     out.flops = flops;
     out.bytes = bytes;
 }

@@ -70,13 +70,13 @@ int main(int argc, char **argv) {
         g.w = dW[i]; g.bias = dbias; g.res = nullptr; g.c = dC[i]; g.ldr = 0; g.ldc = N;
         g.M = M; g.N = N; g.K = K; g.slope = 0.2f;
         if (enc) { g.lut = dlut; g.x = dx; g.enc_ws = 243 * 51; g.enc_rows = 81; g.enc_jf = 51; g.enc_cur = 81 * 51; g.enc_bytes = (unsigned)(hx.size() * 4); }
-        sp.push_back({M, N, K / BK, enc == 0, enc ? std::max(1, std::min(3, (64 * 1024) / ((K + 4) * 4 * 32))) : 0});
+        sp.push_back({M, N, K / BK, enc ? 1 : 4, enc ? std::max(1, std::min(3, (64 * 1024) / ((K + 4) * 4 * 32))) : 0});
     }
     std::vector<int4> tiles;
     std::vector<int> wgoff;
     StageSchedule ss{};
     const int nwg = getenv("PROBE_NWG") ? atoi(getenv("PROBE_NWG")) : device_cu_count();
-    schedule_stage(sp, enc ? 2 * nwg : nwg, 6, tiles, wgoff, ss);
+    schedule_stage(sp, enc ? 2 * nwg : nwg, 6, tiles, wgoff, ss, enc != 0);
     int4 *dt; int *dwg; long long *ddbg;
     CK(hipMalloc((void **)&dt, tiles.size() * sizeof(int4)));
     CK(hipMalloc((void **)&dwg, wgoff.size() * sizeof(int)));
@@ -85,15 +85,15 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(dt, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice));
     CK(hipMemcpy(dwg, wgoff.data(), wgoff.size() * sizeof(int), hipMemcpyHostToDevice));
     la.tiles = dt; la.wg_off = dwg; la.dbg = ddbg; la.ks = ss.ks;
-    printf("grid %d tiles %d ks %d imbalance %.3f (CUs %d)\n", ss.nwg, ss.ntiles, ss.ks, ss.imbalance, nwg);
+    printf("grid %d tiles %d ks %d kind %d imbalance %.3f (CUs %d)\n", ss.nwg, ss.ntiles, ss.ks, ss.kind, ss.imbalance, nwg);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) CK(launch_gemm_stage(la, ss.nwg, enc != 0, 0));
+    for (int i = 0; i < 3; ++i) CK(launch_gemm_stage(la, ss.nwg, ss.kind, 0));
     CK(hipDeviceSynchronize());
     float best = 1e9, sum = 0;
     for (int i = 0; i < reps; ++i) {
         CK(hipEventRecord(e0, 0));
-        CK(launch_gemm_stage(la, ss.nwg, enc != 0, 0));
+        CK(launch_gemm_stage(la, ss.nwg, ss.kind, 0));
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -201,6 +201,19 @@ int main(int argc, char **argv) {
         long long w0 = 1LL << 62, w1 = 0;
         for (int w = 0; w < ss.nwg; ++w) { w0 = std::min(w0, hw[w * 4 + 2]); w1 = std::max(w1, hw[w * 4 + 3]); }
         printf("wall span %lld ticks (100 MHz => %.1f us)\n", w1 - w0, (w1 - w0) / 100.0);
+        {
+            std::vector<long long> ht(16 * 64);
+            CK(hipMemcpy(ht.data(), ddbg + 6144, ht.size() * 8, hipMemcpyDeviceToHost));
+            printf("tile phases (us from launch start): wg tile | entry  ready  loop_end  reduced  stored | prologue loop reduce store\n");
+            for (int w = 0; w < 16 && w < ss.nwg; ++w)
+                for (int t = 0; t < 8 && t < wgoff[w + 1] - wgoff[w]; ++t) {
+                    const long long *q = &ht[w * 64 + t * 8];
+                    const int4 td = tiles[wgoff[w] + t];
+                    printf("  wg %2d tile %d (p%d mi%d ks%d): %7.2f %7.2f %7.2f %7.2f %7.2f | %6.2f %6.2f %6.2f %6.2f\n", w, t, td.x & 255, td.x >> 8, td.w,
+                           (q[0] - w0) / 100.0, (q[1] - w0) / 100.0, (q[2] - w0) / 100.0, (q[3] - w0) / 100.0, (q[4] - w0) / 100.0,
+                           (q[1] - q[0]) / 100.0, (q[2] - q[1]) / 100.0, (q[3] - q[2]) / 100.0, (q[4] - q[3]) / 100.0);
+                }
+        }
         printf("chunk: tiles units | start_us end_us | cycles | eff GHz\n");
         for (int w = 0; w < ss.nwg; w += (w < 8 || w > ss.nwg - 9) ? 1 : 13) {
             int units = 0;
@@ -209,21 +222,6 @@ int main(int argc, char **argv) {
             printf("  %3d: %d %2d | %7.1f %7.1f | %7lld | %.2f\n", w, wgoff[w + 1] - wgoff[w], units, us0, us1,
                    hw[w * 4 + 1] - hw[w * 4 + 0], (hw[w * 4 + 1] - hw[w * 4 + 0]) / (us1 - us0) / 1e3);
         }
-    }
-    std::vector<long long> hd(4 * 256);
-    CK(hipMemcpy(hd.data(), ddbg, hd.size() * 8, hipMemcpyDeviceToHost));
-    // chunk 1 (chunk 0 also pays for the first-touch of everything): timeline of its 8 wavefronts over the
-    // first 4 K tiles of its last tile, relative to wave 0's first stamp
-    const long long *d = hd.data() + 1 * 256;
-    const long long t0 = d[0];
-    printf("wave: per K tile [top, loads-issued, mfma-done, lds-written, barrier-passed] (cycles since wave0 kt0 top)\n");
-    for (int w = 0; w < 8; ++w) {
-        printf("  w%d:", w);
-        for (int kt = 0; kt < 3; ++kt) {
-            const long long *e = d + w * 32 + kt * 8;
-            printf("  | %6lld %6lld %6lld %6lld %6lld", e[0] - t0, e[1] - t0, e[2] - t0, e[3] - t0, e[4] - t0);
-        }
-        printf("\n");
     }
 #endif
     return 0;
