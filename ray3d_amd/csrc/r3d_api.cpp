@@ -139,18 +139,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         pa.frames = frames;
         x_rays = pa.rays;
     }
-    pa.param = in->param_dev;
-    pa.param_stride = in->param_stride;
-    pa.E = a->cfg.extrinsic_dim;
-    for (int mi = 0; mi < 2; ++mi) {
-        const Model *m = pl->m[mi];
-        if (!m || m->cfg.embed_dim <= 0) continue;
-        pa.emb_w[pa.nembed] = m->d_arena + m->embed_off;
-        pa.emb_out[pa.nembed] = buf_ptr(pl->emb_buf[mi]);
-        pa.emb_dim[pa.nembed] = m->cfg.embed_dim;
-        ++pa.nembed;
-    }
-    if (pa.uv || pa.nembed) {
+    if (pa.uv) {
         if ((e = rec.begin("r3d_prologue_f32", stage_no, 0, 0.0, (double)frames * pa.J * (pa.uv ? 20.0 : 0.0))) != hipSuccess) return hip_fail(e, "hipEventRecord");
         if ((e = launch_prologue(pa, stream)) != hipSuccess) return hip_fail(e, "launch r3d_prologue_f32");
         if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
@@ -179,8 +168,13 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             int kend = 0;
             for (int s = 0; s < MAX_SEG; ++s) {
                 if (s < q.nseg) {
-                    g.a[s] = buf_ptr(q.seg[s].buf) + q.seg[s].col;
-                    g.lda[s] = q.seg[s].ld;
+                    if (pl->buffers[q.seg[s].buf].external == 3) {      // the caller's camera-parameter rows
+                        g.a[s] = in->param_dev;
+                        g.lda[s] = (int)in->param_stride;
+                    } else {
+                        g.a[s] = buf_ptr(q.seg[s].buf) + q.seg[s].col;
+                        g.lda[s] = q.seg[s].ld;
+                    }
                     kend += q.seg[s].width;
                 } else {
                     g.a[s] = g.a[0];
@@ -188,7 +182,9 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
                 }
                 g.kend[s] = s < q.nseg ? kend : 0x7fffffff;
             }
-            if (q.nseg > 0) g.kend[q.nseg - 1] = 0x7fffffff;   // the last real segment absorbs the rest
+            // the last real segment absorbs the rest - unless it is narrower than the padded K (embedder.w1 on
+            // the 2-wide parameter rows): its true width bounds the buffer descriptor, the rest reads as zeros
+            if (q.nseg > 0 && !(q.nseg == 1 && kend < L.Kpad)) g.kend[q.nseg - 1] = 0x7fffffff;
             if (q.enc_lut >= 0) {
                 ++n_enc;
                 g.lut = m->d_iarena + q.enc_lut;

@@ -68,12 +68,6 @@ struct PrologueArgs {
     long long cam_stride;
     long long B;
     int J, RF;
-    const float *param;
-    long long param_stride;
-    int nembed, E;
-    const float *emb_w[2];     // packed [w1 (32,E) | b1 (32) | w2 (D,32) | b2 (D)], BN folded
-    float *emb_out[2];         // (B, D)
-    int emb_dim[2];
 };
 
 constexpr int MAX_DEC = 6;     // 5 body-part decoders + the trajectory decoder
@@ -138,7 +132,6 @@ struct Model {
         size_t lut_off;               // offset (ints) into the int arena
     };
     std::vector<Branch> branches;
-    size_t embed_off = 0;             // packed embedding MLP in the float arena
     size_t global_lut_off = 0;        // LUT of GlobalInfo.fc_1's input (the current frame)
     std::vector<float> arena;         // packed floats (host mirror)
     std::vector<int> iarena;          // LUTs
@@ -163,7 +156,7 @@ struct Model {
 struct BufferSpec {
     std::string name;
     int64_t floats_per_window;   // rows_per_window * ld
-    int external;                // 0 workspace, 1 out_dev, 2 out_trj_dev
+    int external;                // 0 workspace, 1 out_dev, 2 out_trj_dev, 3 the caller's camera-parameter rows (input)
     int64_t offset_per_window;   // workspace offset / B (floats)
 };
 
@@ -209,6 +202,7 @@ struct Plan {
     std::vector<std::vector<int>> stages;      // problem ids per launch
     int64_t floats_per_window = 0;
     int emb_buf[2] = {-1, -1};
+    int param_buf = -1;          // pseudo-buffer standing for r3d_input::param_dev
     int rays_buf = -1;           // UV mode scratch for the encoded rays (sized per call)
     // fused decoder tail: (model, layer, hidden buffer) per Integration block
     struct Dec { int model, layer, hbuf; };

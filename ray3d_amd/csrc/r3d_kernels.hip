@@ -2,9 +2,8 @@
 // the fp32-input matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD, 157 TFLOP/s
 // chip peak) - the path is compute-bound, 1e-4 parity rules out bf16.
 //
-//  r3d_prologue_f32    pointwise: ray encoding (uv -> [(u-cx)/fx, c*y+s, -s*y+c], float64 like the
-//                      reference's NumPy, lib/camera/camera.py:423-471) and the camera-embedding MLP
-//                      (lib/model/embedding.py:15-18).
+//  r3d_prologue_f32    pointwise, UV input mode only: ray encoding (uv -> [(u-cx)/fx, c*y+s, -s*y+c],
+//                      float64 like the reference's NumPy, lib/camera/camera.py:423-471).
 //  r3d_gemm_enc_f32    first layer of every temporal branch / GlobalInfo with the input encoding
 //                      fused into the operand staging: window gather from a batch or a sliding clip
 //                      (lib/train_val/trainer.py:47-58), positional / temporal differences and
@@ -635,80 +634,27 @@ hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, int kind, hipStrea
 
 // ------------------------------------------------------------------------------------ prologue
 
-// Pointwise front end.  (1) UV mode: pixel keypoints -> rays, float64 like the reference's NumPy
+// Pointwise front end of the UV input mode: pixel keypoints -> rays, float64 like the reference's NumPy
 // (lib/camera/camera.py:438-439 then pt_cam @ Rc2n^T, :471, Rc2n = Rx(pitch), :333-338):
-// ray = ((u-cx)/fx, c*y + s, -s*y + c) with y = (v-cy)/fy.  (2) camera-embedding MLP
-// (lib/model/embedding.py:15-18; LeakyReLU slope 0.01, BatchNorm folded) for each network.
+// ray = ((u-cx)/fx, c*y + s, -s*y + c) with y = (v-cy)/fy, cast to float32 as lib/train_val/trainer.py:298 does.
 extern "C" __global__ __launch_bounds__(256) void r3d_prologue_f32(const PrologueArgs a) {
-    __shared__ float wl[EMBED_MID * 8 + EMBED_MID + 128 * EMBED_MID + 128];   // w1 | b1 | w2^T | b2 (E <= 8, D <= 128)
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a.uv) {
-        const long long n = a.frames * a.J;
-        if (gid < n) {
-            const long long frame = gid / a.J;
-            // the camera of the (first) window this frame belongs to
-            long long win = a.window_stride >= a.RF ? frame / a.window_stride : frame - (a.RF - 1);
-            win = win < 0 ? 0 : (win >= a.B ? a.B - 1 : win);
-            const double *cam = a.cam + win * a.cam_stride;
-            const double u = a.uv[gid * 2], v = a.uv[gid * 2 + 1];
-            const double y = (v - cam[3]) / cam[1];
-            a.rays[gid * 3 + 0] = (float)((u - cam[2]) / cam[0]);
-            a.rays[gid * 3 + 1] = (float)(cam[4] * y + cam[5]);
-            a.rays[gid * 3 + 2] = (float)(-cam[5] * y + cam[4]);
-        }
-    }
-    // Embedding MLPs: the (tiny) weights go through LDS once per block instead of one dependent global
-    // load per multiply; w2 is stored transposed so that neighbouring outputs read neighbouring banks.
-    for (int m = 0; m < a.nembed; ++m) {
-        const int D = a.emb_dim[m], E = a.E;
-        if ((long long)blockIdx.x * blockDim.x >= a.B * D) break;        // block-uniform
-        const float *g = a.emb_w[m];
-        float *w1 = wl, *b1 = w1 + EMBED_MID * E, *w2t = b1 + EMBED_MID, *b2 = w2t + D * EMBED_MID;
-        __syncthreads();
-        {
-            // every load of the block is issued before the first LDS write: one memory round trip, not
-            // one per loop iteration (indices past the packed block are clamped and never stored)
-            const int n1 = EMBED_MID * E + EMBED_MID, n2 = D * EMBED_MID, tot = n1 + n2 + D;
-            float t1[2], t2[16], t3;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) t1[j] = gload1(g + min((int)threadIdx.x + 256 * j, tot - 1));
-#pragma unroll
-            for (int j = 0; j < 16; ++j) t2[j] = gload1(g + min(n1 + (int)threadIdx.x + 256 * j, tot - 1));
-            t3 = gload1(g + min(n1 + n2 + (int)threadIdx.x, tot - 1));
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                if ((int)threadIdx.x + 256 * j < n1) wl[threadIdx.x + 256 * j] = t1[j];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int i = threadIdx.x + 256 * j;
-                if (i < n2) w2t[(i % EMBED_MID) * D + i / EMBED_MID] = t2[j];
-            }
-            if ((int)threadIdx.x < D) b2[threadIdx.x] = t3;
-        }
-        __syncthreads();
-        if (gid >= a.B * D) continue;
-        const long long b = gid / D;
-        const int o = (int)(gid - b * D);
-        const float *p = a.param + b * a.param_stride;
-        float pv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pv[e] = e < E ? gload1(p + e) : 0.0f;
-        float acc = b2[o];
-        for (int k = 0; k < EMBED_MID; ++k) {
-            float h = b1[k];
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (e < E) h += w1[k * E + e] * pv[e];
-            h = h > 0.0f ? h : 0.01f * h;
-            acc += w2t[k * D + o] * h;
-        }
-        a.emb_out[m][gid] = acc > 0.0f ? acc : 0.01f * acc;
-    }
+    const long long n = a.frames * a.J;
+    if (gid >= n) return;
+    const long long frame = gid / a.J;
+    // the camera of the (first) window this frame belongs to
+    long long win = a.window_stride >= a.RF ? frame / a.window_stride : frame - (a.RF - 1);
+    win = win < 0 ? 0 : (win >= a.B ? a.B - 1 : win);
+    const double *cam = a.cam + win * a.cam_stride;
+    const double u = a.uv[gid * 2], v = a.uv[gid * 2 + 1];
+    const double y = (v - cam[3]) / cam[1];
+    a.rays[gid * 3 + 0] = (float)((u - cam[2]) / cam[0]);
+    a.rays[gid * 3 + 1] = (float)(cam[4] * y + cam[5]);
+    a.rays[gid * 3 + 2] = (float)(-cam[5] * y + cam[4]);
 }
 
 hipError_t launch_prologue(const PrologueArgs &args, hipStream_t stream) {
-    long long most = args.uv ? args.frames * args.J : 0;
-    for (int m = 0; m < args.nembed; ++m) most = most > args.B * args.emb_dim[m] ? most : args.B * args.emb_dim[m];
+    const long long most = args.uv ? args.frames * args.J : 0;
     if (most == 0) return hipSuccess;
     r3d_prologue_f32<<<dim3((unsigned)((most + 255) / 256)), dim3(256), 0, stream>>>(args);
     return hipGetLastError();

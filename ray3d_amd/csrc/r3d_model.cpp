@@ -104,14 +104,11 @@ struct Grammar {
         }
         layer(p + ".fc_2", 1, MLP_HIDDEN, cout, true, "", 1.0f, false);
     }
-    // Embedding, lib/model/embedding.py:4-13 (not a GEMM layer: evaluated in the prologue kernel)
+    // Embedding, lib/model/embedding.py:4-18: Linear+BN+LeakyReLU(0.01) twice.  Two (tiny) GEMM layers that ride
+    // along the big launches of the conv pyramid - a kernel of their own cost more than their arithmetic.
     void embedding(const std::string &p, int cin, int cout) {
-        tensor(p + ".w1.weight", {EMBED_MID, cin});
-        tensor(p + ".w1.bias", {EMBED_MID});
-        bn(p + ".b1", EMBED_MID);
-        tensor(p + ".w2.weight", {cout, EMBED_MID});
-        tensor(p + ".w2.bias", {cout});
-        bn(p + ".b2", cout);
+        layer(p + ".w1", 1, cin, EMBED_MID, true, p + ".b1", 0.01f, false);
+        layer(p + ".w2", 1, EMBED_MID, cout, true, p + ".b2", 0.01f, false);
     }
 };
 
@@ -300,12 +297,6 @@ int model_finalize(Model *m) {
         L.b_off = off;
         off += (size_t)L.Npad;
     }
-    const int E = m->cfg.extrinsic_dim, D = m->cfg.embed_dim;
-    if (D > 0) {
-        m->embed_off = off;
-        off += (size_t)EMBED_MID * E + EMBED_MID + (size_t)D * EMBED_MID + D;
-        off = (off + 63) / 64 * 64;
-    }
     m->arena.assign(off, 0.0f);
     Folder f{m};
     std::vector<double> s, t;
@@ -325,26 +316,6 @@ int model_finalize(Model *m) {
                 }
         float *bd = m->arena.data() + L.b_off;
         for (int o = 0; o < L.N; ++o) bd[o] = (float)t[o];
-    }
-    if (D > 0) {
-        // Embedding: Linear(E,32)+BN, Linear(32,D)+BN, both folded (embedding.py:15-18)
-        float *e = m->arena.data() + m->embed_off;
-        Layer l1, l2;
-        l1.N = EMBED_MID; l1.bias_key = "embedder.w1.bias"; l1.bn_prefix = "embedder.b1";
-        l2.N = D; l2.bias_key = "embedder.w2.bias"; l2.bn_prefix = "embedder.b2";
-        f.scale_shift(l1, s, t);
-        const float *w1 = f.get("embedder.w1.weight");
-        for (int o = 0; o < EMBED_MID; ++o) {
-            for (int c = 0; c < E; ++c) e[o * E + c] = (float)((double)w1[o * E + c] * s[o]);
-            e[EMBED_MID * E + o] = (float)t[o];
-        }
-        float *e2 = e + EMBED_MID * E + EMBED_MID;
-        f.scale_shift(l2, s, t);
-        const float *w2 = f.get("embedder.w2.weight");
-        for (int o = 0; o < D; ++o) {
-            for (int c = 0; c < EMBED_MID; ++c) e2[o * EMBED_MID + c] = (float)((double)w2[o * EMBED_MID + c] * s[o]);
-            e2[(size_t)D * EMBED_MID + o] = (float)t[o];
-        }
     }
     // ---- upload
     int dev = 0;

@@ -41,7 +41,8 @@ struct Builder {
         q.nseg = (int)ins.size();
         q.enc_lut = enc_lut;
         q.enc_rows = rows_pw;
-        int k = enc_lut >= 0 ? m.layers[q.layer].Kpad : 0;
+        const Layer &L0 = m.layers[q.layer];
+        int k = enc_lut >= 0 ? L0.Kpad : 0;
         for (int s = 0; s < q.nseg; ++s) {
             q.seg[s] = {ins[s].buf, ins[s].col, ins[s].ld, ins[s].width};
             k += ins[s].width;
@@ -50,13 +51,13 @@ struct Builder {
         for (int d : extra_deps)
             if (d >= 0) q.deps.push_back(d);
         const Layer &L = m.layers[q.layer];
-        if (k != L.Kpad) {
+        if (k != L.Kpad && !(q.nseg == 1 && k == L.K)) {   // (one narrow operand: the kernel's descriptor bound zero-fills up to Kpad)
             fprintf(stderr, "r3d: internal plan error: layer %s expects K=%d, operands give %d\n", layer_prefix.c_str(), L.Kpad, k);
             abort();
         }
         q.res_buf = res_buf; q.res_col = res_col; q.res_ld = res_ld;
         q.c_buf = c_buf; q.c_col = c_col; q.c_ld = c_ld;
-        q.depth = 0;
+        q.depth = enc_lut >= 0 ? 0 : 1;     // level 0 is the fused-prologue launch: encoded operands only
         for (int d : q.deps) q.depth = std::max(q.depth, p.probs[d].depth + 1);
         q.flops_per_window = 2.0 * rows_pw * (double)L.K * (double)L.N;
         p.probs.push_back(q);
@@ -119,7 +120,16 @@ static Plan *build_plan(const Model *a, const Model *b) {
         if (!m) continue;
         Builder B{*pl, mi, *m};
         const int lat = m->cfg.latent, D = m->cfg.embed_dim;
-        if (D > 0) pl->emb_buf[mi] = B.buffer("emb", D);
+        int pe = -1;
+        if (D > 0) {
+            // Embedding.forward (lib/model/embedding.py:15-18) on the caller's [height, pitch] rows
+            if (pl->param_buf < 0) pl->param_buf = B.buffer("param", 0, 3);
+            const int eh = B.buffer("emb.h", EMBED_MID);
+            pl->emb_buf[mi] = B.buffer("emb", D);
+            const int E = m->cfg.extrinsic_dim;
+            const int p1 = B.problem("embedder.w1", 1, {{pl->param_buf, 0, 0, E, -1}}, -1, 0, 0, eh, 0, EMBED_MID);
+            pe = B.problem("embedder.w2", 1, {{eh, 0, EMBED_MID, EMBED_MID, p1}}, -1, 0, 0, pl->emb_buf[mi], 0, D);
+        }
         const int g = B.buffer("global", lat);
         const int pg = B.fc_block("GlobalInfo", {}, 2, g, 0, lat, (int)m->global_lut_off);
         if (m->cfg.kind == R3D_KIND_POS) {
@@ -153,7 +163,7 @@ static Plan *build_plan(const Model *a, const Model *b) {
                 ins.push_back({tmp5, bi * lat, 5 * lat, lat, sh[bi]});
                 if (mix5 >= 0) ins.push_back({mix5, bi * lat, 5 * lat, lat, pf[bi]});
                 ins.push_back({g, 0, lat, lat, pg});
-                if (D > 0) ins.push_back({pl->emb_buf[mi], 0, D, D, -1});
+                if (D > 0) ins.push_back({pl->emb_buf[mi], 0, D, D, pe});
                 B.fc_block(std::string("Integration_") + (bi == 0 ? "Torso" : bi == 1 ? "LArm" : bi == 2 ? "RArm" : bi == 3 ? "LLeg" : "RLeg"),
                            ins, 1, -1, 0, 0);
             }
@@ -164,7 +174,7 @@ static Plan *build_plan(const Model *a, const Model *b) {
             std::vector<Builder::In> ins;
             ins.push_back({local, 0, lat, lat, sh});
             ins.push_back({g, 0, lat, lat, pg});
-            if (D > 0) ins.push_back({pl->emb_buf[mi], 0, D, D, -1});
+            if (D > 0) ins.push_back({pl->emb_buf[mi], 0, D, D, pe});
             B.fc_block("Integration", ins, 1, -1, 0, 0);
         }
     }
