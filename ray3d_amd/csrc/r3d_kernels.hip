@@ -668,22 +668,18 @@ hipError_t launch_prologue(const PrologueArgs &args, hipStream_t stream) {
 // trajectory broadcast add (lib/train_val/trainer.py:353).  Every body-part wavefront recomputes the
 // 3-output trajectory head itself - cheaper than a dependency between wavefronts.  These layers are
 // 0.05 % of the FLOPs; as GEMMs their N = 3..15 would waste a 256-column tile.
-// NJ joints (3 output rows each) of one decoder: loads first, all of them, then the reductions - the
-// whole group costs one memory round trip.  Rows past the decoder's last are clamped and discarded.
-template <int NJ>
-struct DecodeRows {
-    f32x4 w[NJ * 3][4];
-    __device__ __forceinline__ void load(const float *wbase, int o0, int n_out, int lane) {
+// Three output rows (one joint) of a decoder against one hidden row: all loads first, then the reductions.
+struct DecodeJoint {
+    f32x4 w[3][4];
+    __device__ __forceinline__ void load(const float *wrows, int lane) {
 #pragma unroll
-        for (int n = 0; n < NJ * 3; ++n) {
-            const int row = o0 + n < n_out ? o0 + n : n_out - 1;
+        for (int n = 0; n < 3; ++n)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) w[n][j] = gload4(wbase + (size_t)row * MLP_HIDDEN + j * 256 + lane * 4);
-        }
+            for (int j = 0; j < 4; ++j) w[n][j] = gload4(wrows + (size_t)n * MLP_HIDDEN + j * 256 + lane * 4);
     }
-    __device__ __forceinline__ void dot(const f32x4 (&hv)[4], float (&o)[NJ * 3]) const {
+    __device__ __forceinline__ void dot(const f32x4 (&hv)[4], float (&o)[3]) const {
 #pragma unroll
-        for (int n = 0; n < NJ * 3; ++n) {
+        for (int n = 0; n < 3; ++n) {
             float acc = 0.0f;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -695,35 +691,41 @@ struct DecodeRows {
     }
 };
 
+// One wavefront per (window, joint): a single memory round trip (the joint's three decoder rows, its hidden
+// row, and - recomputed by every wavefront, cheaper than a dependency - the trajectory head), 64-lane dot
+// products, and the (x, y, z) written straight into the joint slot of the reference's reassembly.
 extern "C" __global__ __launch_bounds__(256) void r3d_decode_f32(const DecodeArgs a) {
     const int lane = threadIdx.x & 63;
     const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // global wavefront index
-    const int npos = a.has_trj ? a.nsrc - 1 : a.nsrc;                        // body-part decoders
-    const int per_win = a.has_pos ? npos : 1;
+    const int per_win = a.has_pos ? a.J : 1;
     const long long b = gw / per_win;
     if (b >= a.B) return;
-    const int s = (int)(gw - b * per_win);
+    const int jf = (int)(gw - b * per_win);          // joint in flat decoder order
     const int ts = a.nsrc - 1;
-    // round A: the trajectory head and the part's first two joints, one memory round trip
+    int s = 0, o = 0;
+    if (a.has_pos) {
+        const int npos = a.has_trj ? a.nsrc - 1 : a.nsrc;
+        for (int q = 0; q < npos; ++q)
+            if (3 * jf >= a.first[q]) { s = q; o = 3 * jf - a.first[q]; }
+    }
     f32x4 hv[4], ht[4];
-    DecodeRows<1> rt;
-    DecodeRows<2> ra;
+    DecodeJoint rt, rj;
     if (a.has_trj) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) ht[j] = gload4(a.h[ts] + b * MLP_HIDDEN + j * 256 + lane * 4);
-        rt.load(a.w[ts], 0, 3, lane);
+        rt.load(a.w[ts], lane);
     }
     if (a.has_pos) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) hv[j] = gload4(a.h[s] + b * MLP_HIDDEN + j * 256 + lane * 4);
-        ra.load(a.w[s], 0, a.n_out[s], lane);
+        rj.load(a.w[s] + (size_t)o * MLP_HIDDEN, lane);
     }
     float trj[3] = {0.0f, 0.0f, 0.0f};
     if (a.has_trj) {
         rt.dot(ht, trj);
 #pragma unroll
         for (int n = 0; n < 3; ++n) trj[n] += a.bias[ts][n];
-        if (lane == 0 && s == 0) {
+        if (lane == 0 && jf == 0) {
 #pragma unroll
             for (int n = 0; n < 3; ++n) {
                 if (a.out_trj) a.out_trj[b * 3 + n] = trj[n];
@@ -732,35 +734,17 @@ extern "C" __global__ __launch_bounds__(256) void r3d_decode_f32(const DecodeArg
         }
     }
     if (!a.has_pos) return;
-    const int n_out = a.n_out[s];
-    // round B's loads go out before round A is reduced
-    DecodeRows<3> rb;
-    if (n_out > 6) rb.load(a.w[s], 6, n_out, lane);
-    auto emit = [&](int o, const float *v) {      // (x, y, z) of a joint are consecutive in the output
-        if (lane == 0 && o < n_out) {
-            const int e = a.slot[a.first[s] + o];
+    float v[3];
+    rj.dot(hv, v);
+    if (lane == 0) {
+        const int e = a.slot[a.first[s] + o];     // (x, y, z) of a joint are consecutive in the output
 #pragma unroll
-            for (int n = 0; n < 3; ++n) a.out[b * (a.J * 3) + e + n] = v[n] + a.bias[s][o + n] + trj[n];
-        }
-    };
-    {
-        float v[6];
-        ra.dot(hv, v);
-        emit(0, v);
-        emit(3, v + 3);
-    }
-    if (n_out > 6) {
-        float v[9];
-        rb.dot(hv, v);
-        emit(6, v);
-        emit(9, v + 3);
-        emit(12, v + 6);
+        for (int n = 0; n < 3; ++n) a.out[b * (a.J * 3) + e + n] = v[n] + a.bias[s][o + n] + trj[n];
     }
 }
 
 hipError_t launch_decode(const DecodeArgs &args, hipStream_t stream) {
-    const int npos = args.has_trj ? args.nsrc - 1 : args.nsrc;
-    const long long waves = args.B * (args.has_pos ? npos : 1);
+    const long long waves = args.B * (args.has_pos ? args.J : 1);
     r3d_decode_f32<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream>>>(args);
     return hipGetLastError();
 }
