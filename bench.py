@@ -110,7 +110,8 @@ def roofline(lifter, x, p, reps=5):
     tfile = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if measured
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get(name)
+            tj = json.load(open(tfile))
+            traffic = tj.get(name) if tj.get("batch") == x.shape[0] else None   # measured at that batch size only
         except Exception:
             traffic = None
     out = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,

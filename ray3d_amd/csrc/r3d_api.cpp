@@ -342,6 +342,45 @@ int r3d_profile_read(r3d_model *m, r3d_launch_record *records, int capacity) {
     return n;
 }
 
+// Test hook (not part of include/ray3d_hip.h): build the static schedule of one launch on the host and verify
+// that its tiles cover every (32-row unit, 64-column granule) of every problem exactly once within the
+// kernel's tile-shape limits.  Returns 0 or a negative code naming the first violated rule.
+int r3d_debug_schedule_check(int nprob, const int *M, const int *N, const int *nk, const int *max_ks, const int *max_units,
+                             int nwg, int enc, int *out_grid, int *out_tiles, double *out_imbalance) {
+    std::vector<SchedProb> probs;
+    for (int i = 0; i < nprob; ++i) probs.push_back({M[i], N[i], nk[i], max_ks[i], max_units[i]});
+    std::vector<int4> tiles;
+    std::vector<int> wgoff;
+    StageSchedule ss{};
+    schedule_stage(probs, nwg, GEMM_SCHED_MAX_UNITS, tiles, wgoff, ss, enc != 0);
+    if (out_grid) *out_grid = ss.nwg;
+    if (out_tiles) *out_tiles = ss.ntiles;
+    if (out_imbalance) *out_imbalance = ss.imbalance;
+    if (ss.nwg < 1 || ss.nwg > nwg) return -1;
+    if ((int)wgoff.size() != ss.nwg + 1 || wgoff.front() != 0 || wgoff.back() != ss.ntiles || (int)tiles.size() != ss.ntiles) return -2;
+    for (size_t i = 1; i < wgoff.size(); ++i)
+        if (wgoff[i] <= wgoff[i - 1] && ss.ntiles > 0) return -3;          // empty or unordered chunk
+    std::vector<std::vector<int>> cover(nprob);
+    for (int i = 0; i < nprob; ++i) cover[i].assign((size_t)((M[i] + 31) / 32) * ((N[i] + 63) / 64), 0);
+    for (const int4 &t : tiles) {
+        const int pi = t.x & 0xff, mi = t.x >> 8, ks = t.w;
+        if (pi >= nprob || mi < 1 || (ks != 1 && ks != 2 && ks != 4)) return -4;
+        if (ks > max_ks[pi]) return -5;
+        if ((ks == 1 && mi > (max_units[pi] > 0 ? std::min(max_units[pi], GEMM_SCHED_MAX_UNITS) : GEMM_SCHED_MAX_UNITS)) || (ks == 2 && mi > 2) || (ks == 4 && mi != 1)) return -6;
+        if (t.y % 32 || t.y < 0 || t.y >= M[pi] || t.z % (256 / ks) || t.z < 0 || t.z >= N[pi]) return -7;
+        if (ks > 1 && (nk[pi] + ks - 1) / ks < 2) return -8;
+        const int gcols = (N[pi] + 63) / 64;
+        for (int u = t.y / 32; u < t.y / 32 + mi; ++u) {
+            if (u * 32 >= M[pi]) return -9;
+            for (int g = t.z / 64; g < (t.z + 256 / ks) / 64 && g < gcols; ++g) ++cover[pi][(size_t)u * gcols + g];
+        }
+    }
+    for (int i = 0; i < nprob; ++i)
+        for (int c : cover[i])
+            if (c != 1) return -10;
+    return 0;
+}
+
 const char *r3d_last_error(void) { return r3d::last_error(); }
 const char *r3d_version(void) { return "ray3d_hip 0.1 (gfx950)"; }
 

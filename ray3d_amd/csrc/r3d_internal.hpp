@@ -221,6 +221,7 @@ Model *model_create(const r3d_config &cfg);
 int model_set_weight(Model *m, const char *key, const float *host, const int64_t *shape, int rank);
 int model_finalize(Model *m);
 Plan *plan_get(Model *a, Model *b);
+constexpr int GEMM_SCHED_MAX_UNITS = 6;   // widest tile of r3d_gemm_f32: 6 x 32 rows
 struct SchedProb {
     int M, N, nk;
     int max_ks;      // largest split-K factor the operand allows (1 = none: fused-prologue operands, or a

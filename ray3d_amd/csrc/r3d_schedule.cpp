@@ -54,6 +54,7 @@ struct Run {           // `n` consecutive row units of one column block, all in 
 struct Seg {           // one column block of a problem
     int prob, col0, units, nk, cap, max_ks;
     double c1;
+    int ncols;         // columns of the problem inside this block (<= 256)
 };
 
 struct Assignment {
@@ -103,6 +104,7 @@ bool assign(const std::vector<Seg> &segs, int nbins, double T, int ksplit, Assig
         if (ck > T) return false;
         if (ck != cursor_cost) { cursor = 0; cursor_cost = ck; }
         for (int j = 0; j < ks; ++j) {
+            if (j * (256 / ks) >= s.ncols) break;               // a ragged last block: nothing to compute there
             int u = l.u0;
             while (u < s.units) {
                 while (cursor < nbins && room[cursor] + 1e-6 < ck) ++cursor;
@@ -141,7 +143,8 @@ void pack(const std::vector<SchedProb> &probs, int nbins_max, int max_units, Pac
         const int units = (p.M + 31) / 32;
         const double c1 = unit_cycles(p.nk, 1);
         for (int c0 = 0; c0 < p.N; c0 += 256) {
-            segs.push_back({i, c0, units, p.nk, p.max_units > 0 ? std::min(p.max_units, max_units) : max_units, p.max_ks, c1});
+            segs.push_back({i, c0, units, p.nk, p.max_units > 0 ? std::min(p.max_units, max_units) : max_units, p.max_ks, c1,
+                            std::min(256, p.N - c0)});
             total += units * c1;
             total_units += units;
         }
@@ -227,7 +230,7 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
     bool enc = false;
     for (int id : st) enc = enc || pl->probs[id].enc_lut >= 0;
     // the fused-prologue kernel runs two workgroups per CU (one encodes while the other multiplies)
-    schedule_stage(probs, enc ? 2 * nwg : nwg, 6, tiles, wgoff, out, enc);
+    schedule_stage(probs, enc ? 2 * nwg : nwg, GEMM_SCHED_MAX_UNITS, tiles, wgoff, out, enc);
     out.flops = flops;
     out.bytes = bytes;
 }

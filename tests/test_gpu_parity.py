@@ -209,3 +209,29 @@ def test_weight_update_is_picked_up():
     d = (b - a)[:, 0].cpu().numpy()
     torso_slots = [0, 7, 8, 9, 10]
     assert np.allclose(d[:, torso_slots], 1.0, atol=1e-5) and np.allclose(np.delete(d, torso_slots, axis=1), 0.0, atol=1e-6)
+
+
+def test_integration_md_ctypes_stub_runs_against_the_library():
+    """The reference-side binding shown in INTEGRATION.md section 2 is executed verbatim (only the
+    library path is made absolute) and must reproduce the reference fixture through the C ABI."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = next(b for b in blocks if "class HipRIE" in b)
+    lib = os.path.join(root, "ray3d_amd", "libray3d_hip.so")
+    stub = stub.replace('C.CDLL("libray3d_hip.so")', "C.CDLL(%r)" % lib)
+    ns = {}
+    exec(compile(stub, "INTEGRATION.md:hip_backend", "exec"), ns)
+    z, mc = load_model_fixture("j17_rf27_s3")
+    (cp, sp), (ct, st) = synth_states(mc)
+    torch.cuda.set_device(0)
+    x = torch.from_numpy(z["x"]).cuda()
+    p = torch.from_numpy(z["param"]).cuda()
+    for kind, sd, ref in ((0, sp, z["out_pos"]), (1, st, z["out_trj"])):
+        mod = ns["HipRIE"](kind, mc, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        out = mod(x, p)
+        torch.cuda.synchronize()
+        assert out.shape == ref.shape
+        assert np.abs(out.cpu().numpy() - ref).max() <= tol_for(ref)

@@ -262,3 +262,62 @@ def test_two_rank_gather_matches_single_process():
         for a in named1:
             assert np.allclose(named[a], named1[a], rtol=0, atol=1e-9)
         assert sorted(rows[:, 0].tolist()) == [0.0, 1.0, 2.0]
+
+
+# ----------------------------------------------------------------- static tile schedule (host code, no GPU)
+
+def _schedule_check(probs, nwg=256, enc=False):
+    """probs: list of (M, N, nk, max_ks, max_units).  Calls the library's own checker
+    (r3d_debug_schedule_check, r3d_api.cpp): exact cover + tile-shape rules."""
+    import ctypes as C
+    from ray3d_amd import _capi
+    lib = _capi.load()
+    fn = lib.r3d_debug_schedule_check
+    fn.restype = C.c_int
+    n = len(probs)
+    cols = [(C.c_int * n)(*[p[i] for p in probs]) for i in range(5)]
+    grid, tiles, imb = C.c_int(), C.c_int(), C.c_double()
+    rc = fn(n, cols[0], cols[1], cols[2], cols[3], cols[4], nwg, int(enc), C.byref(grid), C.byref(tiles), C.byref(imb))
+    return rc, grid.value, tiles.value, imb.value
+
+
+def test_schedule_covers_every_launch_of_the_plan_exactly_once():
+    for B in (1, 3, 8, 100, 256, 1000, 1024):
+        launches = {
+            "pyramid 1a + GlobalInfo": [(B * 27, 256, 24, 4, 0)] * 6 + [(B, 1024, 32, 4, 0)] * 2,
+            "pyramid 3a": [(B * 3, 256, 24, 4, 0)] * 6 + [(B, 256, 32, 4, 0)] * 2,
+            "pyramid top": [(B, 256, 8, 4, 0)] * 6,
+            "fuse fc_1": [(B, 1024, 32, 4, 0)] * 5 + [(B, 1024, 18, 2, 0)],
+            "integration fc_1": [(B, 1024, 26, 4, 0)] * 5,
+            "embedding": [(B, 32, 1, 4, 0), (B, 64, 1, 4, 0)],
+            "ragged N": [(B * 9, 96, 3, 4, 0), (B, 15, 32, 4, 0)],
+        }
+        for name, probs in launches.items():
+            rc, grid, tiles, imb = _schedule_check(probs)
+            assert rc == 0, (B, name, rc)
+            assert 1 <= grid <= 256 and tiles >= 1
+        rc, grid, tiles, imb = _schedule_check([(B * 81, 256, 5, 1, 3)] + [(B * 81, 256, 3, 1, 3)] * 4 +
+                                               [(B * 81, 256, 15, 1, 1), (B, 1024, 2, 1, 3), (B, 1024, 2, 1, 3)], enc=True)
+        assert rc == 0, (B, "first layers", rc)
+
+
+def test_schedule_random_problem_sets():
+    rng = np.random.default_rng(7)
+    for trial in range(200):
+        n = int(rng.integers(1, 13))
+        probs = []
+        for _ in range(n):
+            M = int(rng.integers(1, 9000))
+            N = int(rng.choice([3, 15, 32, 64, 256, 512, 1024]))
+            nk = int(rng.integers(1, 40))
+            probs.append((M, N, nk, int(rng.choice([1, 2, 4])), int(rng.choice([0, 0, 1, 3]))))
+        nwg = int(rng.choice([1, 7, 64, 256, 304]))
+        rc, grid, tiles, imb = _schedule_check(probs, nwg=nwg)
+        assert rc == 0, (trial, probs, nwg, rc)
+
+
+def test_schedule_balances_the_headline_launch():
+    # level-1 3-tap convolutions of all six branches at B = 256: 1296 + 64 units on 256 CUs
+    rc, grid, tiles, imb = _schedule_check([(256 * 27, 256, 24, 4, 0)] * 6 + [(256, 1024, 32, 4, 0)] * 2)
+    assert rc == 0 and grid == 256
+    assert imb < 1.08          # longest chunk within 8 % of the mean (it was 19 % with whole 6-unit tiles only)
