@@ -246,21 +246,24 @@ class Ray3DLifter(nn.Module):
         if not isinstance(self.pos, RIEModel) or not isinstance(self.trj, RIETrajectoryModel):
             raise TypeError("Ray3DLifter(pos_model: RIEModel, trj_model: RIETrajectoryModel)")
         self._ws = _Workspace()
+        self._side_ws: list = []
+        self._side_streams: list = []
 
     def receptive_field(self) -> int:
         return self.pos.receptive_field()
 
     def _run(self, mode, x, window_stride, B, param, param_stride, cam=None, cam_stride=0,
-             return_trj=False):
+             return_trj=False, out=None, workspace=None):
         dev = x.device
         if self.pos.training or self.trj.training:
             raise RuntimeError("ray3d_amd modules are inference-only: call .eval() first")
         if not x.is_cuda:
             raise RuntimeError("ray3d_amd runs on an AMD GPU only (got a %s tensor)" % x.device)
         hp, ht = self.pos.handle(dev), self.trj.handle(dev)
-        out = torch.empty((B, 1, self.pos.num_joints_in, 3), dtype=torch.float32, device=dev)
+        if out is None:
+            out = torch.empty((B, 1, self.pos.num_joints_in, 3), dtype=torch.float32, device=dev)
         out_trj = torch.empty((B, 1, 1, 3), dtype=torch.float32, device=dev) if return_trj else None
-        ws = self._ws.get(_capi.workspace_bytes(hp, ht, B), dev)
+        ws = (workspace or self._ws).get(_capi.workspace_bytes(hp, ht, B), dev)
         inp = _capi.make_input(mode, x.data_ptr(), window_stride,
                                param.data_ptr() if param is not None else None, param_stride,
                                cam.data_ptr() if cam is not None else None, cam_stride)
@@ -277,6 +280,42 @@ class Ray3DLifter(nn.Module):
         p = param.detach().to(x.device, torch.float32).contiguous() if self.pos.camera_embedding else None
         return self._run(_capi.R3D_INPUT_RAYS, x, self.receptive_field(), x.shape[0], p,
                          self.pos.extrinsic_dim, return_trj=return_trj)
+
+    def forward_overlapped(self, x: torch.Tensor, param: Optional[torch.Tensor] = None, parts: int = 2):
+        """forward() with the batch cut into `parts` row ranges that run concurrently on separate HIP
+        streams (windows are independent).  One forward is 18 dependent launches, several of them too
+        small for 256 CUs; a second, independent launch sequence fills the gaps - measured +7 % at B = 256
+        (DESIGN.md).  The result is ordered after the caller's stream on entry and visible to it on exit.
+        Each range is scheduled for its own batch size, so sums may differ from forward() in the last
+        bits (split-K tiles), never by more than the schedule-invariance tests allow."""
+        self.pos._check_inputs(x, param)
+        B = x.shape[0]
+        parts = max(1, min(int(parts), B // 32))
+        if parts == 1:
+            return self.forward(x, param)
+        x = x.detach().to(torch.float32).contiguous()
+        p = param.detach().to(x.device, torch.float32).contiguous() if self.pos.camera_embedding else None
+        dev = x.device
+        while len(self._side_streams) < parts - 1:
+            self._side_streams.append(torch.cuda.Stream(device=dev))
+            self._side_ws.append(_Workspace())
+        out = torch.empty((B, 1, self.pos.num_joints_in, 3), dtype=torch.float32, device=dev)
+        cur = torch.cuda.current_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        bounds = [B * i // parts for i in range(parts + 1)]
+        for i in range(parts):
+            a, b = bounds[i], bounds[i + 1]
+            stream = cur if i == 0 else self._side_streams[i - 1]
+            if i > 0:
+                stream.wait_event(ready)
+            with torch.cuda.stream(stream):
+                self._run(_capi.R3D_INPUT_RAYS, x[a:b], self.receptive_field(), b - a,
+                          p[a:b] if p is not None else None, self.pos.extrinsic_dim, out=out[a:b],
+                          workspace=None if i == 0 else self._side_ws[i - 1])
+        for s in self._side_streams[: parts - 1]:
+            cur.wait_stream(s)
+        return out
 
     def forward_clip(self, clip: torch.Tensor, param_row: Optional[torch.Tensor] = None):
         """clip (N + RF - 1, J, F): an edge-padded sequence; window i = frames [i, i+RF) is gathered

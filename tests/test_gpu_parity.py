@@ -235,3 +235,21 @@ def test_integration_md_ctypes_stub_runs_against_the_library():
         torch.cuda.synchronize()
         assert out.shape == ref.shape
         assert np.abs(out.cpu().numpy() - ref).max() <= tol_for(ref)
+
+
+def test_overlapped_half_batches_equal_the_single_pass():
+    import ray3d_amd
+    from ray3d_amd import synth
+    z, mc = load_model_fixture("j17_rf27_s3")
+    pos, trj, (cp, _), _ = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    x = torch.from_numpy(synth.synth_rays(200, cp, seed=11)).cuda()
+    p = torch.from_numpy(synth.synth_param(200, seed=12, vary=True)).cuda()
+    with torch.no_grad():
+        one = lifter(x, p)
+        two = lifter.forward_overlapped(x, p, parts=2)
+        three = lifter.forward_overlapped(x, p, parts=3)
+        torch.cuda.synchronize()
+    assert two.shape == one.shape
+    assert (one - two).abs().max().item() <= 6e-5
+    assert (one - three).abs().max().item() <= 6e-5
