@@ -206,6 +206,13 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             g.N = L.N;
             g.K = L.Kpad;
             g.slope = L.slope;
+            if (q.layer2 >= 0) {
+                const Layer &L2 = m->layers[q.layer2];
+                g.w2 = m->d_arena + L2.w_off;
+                g.bias2 = m->d_arena + L2.b_off;
+                g.K2 = L2.Kpad;
+                g.slope2 = L2.slope;
+            }
         }
         if (n_enc != 0 && n_enc != la.nprob) { set_error("internal: launch mixes encoded and plain operands"); return R3D_ERR_STATE; }
         if ((n_enc != 0) != (ss.kind == STAGE_ENC)) { set_error("internal: schedule and plan disagree on the launch kind"); return R3D_ERR_STATE; }

@@ -33,6 +33,12 @@ struct GemmProb {
     int ldr, ldc;
     int M, N, K;
     float slope;              // LeakyReLU slope, 1.0f = linear layer
+    // --- fused pair (w2 != nullptr): C = res + lrelu2(lrelu(A W^T + b) W2^T + b2), the 1x1 convolution of a
+    // TemporalBlock level applied to the 3-tap one's output without leaving the CU (N <= 256, K2 == N) ---
+    const float *w2;          // packed weights of the second layer [256][K2]
+    const float *bias2;
+    int K2;
+    float slope2;
     // --- fused feature-encoding prologue (first layers only; lut == nullptr otherwise) ---
     // A[row][col] is computed on the fly from the raw input instead of being read from memory:
     // row = window * enc_rows + t3 covers input frames 3*t3 .. 3*t3+2 of that window.
@@ -168,6 +174,7 @@ struct ProbSpec {
     struct Seg { int buf, col, ld, width; } seg[MAX_SEG];
     int res_buf, res_col, res_ld;
     int c_buf, c_col, c_ld;
+    int layer2;                  // >= 0: second layer of a fused pair (applied to the first one's output tile)
     int enc_lut;                 // >= 0: fused-encode problem, offset of its LUT in the model's int arena
     int enc_rows;
     std::vector<int> deps;
@@ -227,6 +234,7 @@ struct SchedProb {
     int max_ks;      // largest split-K factor the operand allows (1 = none: fused-prologue operands, or a
                      // concatenated operand with a boundary that is not a multiple of 32*KS)
     int max_units;   // per-problem cap on 32-row units per tile (0 = the launch default)
+    int nk2 = 0;     // K tiles of the fused second layer (cost only)
 };
 void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units, std::vector<int4> &tiles,
                     std::vector<int> &wgoff, StageSchedule &out, bool enc = false);

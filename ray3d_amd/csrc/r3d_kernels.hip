@@ -72,7 +72,9 @@ constexpr int GEMM_MAX_MI = 6;
 constexpr int GEMM_STAGES = 3;
 constexpr int STAGE_FLOATS = GEMM_MAX_MI * 32 * LDS_LD;                  // one A tile: 27,648 B
 constexpr int LUT_LDS_INTS = 1152;                                       // fused-prologue tables: 2K + K/4 ints, K <= 480
-constexpr int GEMM_LDS_BYTES = GEMM_STAGES * STAGE_FLOATS * 4;                      // 82,944 B
+constexpr int RING_LDS_BYTES = GEMM_STAGES * STAGE_FLOATS * 4;                      // 82,944 B
+constexpr int GEMM_LDS_BYTES = 4 * 32 * (GEMM_BN + 4) * 4;                          // 133,120 B: the fused pairs' intermediate tile
+static_assert(GEMM_LDS_BYTES >= RING_LDS_BYTES, "the ring and the intermediate tile share the allocation");
 
 typedef const LaunchArgs __attribute__((address_space(4))) *LaunchArgsPtr;
 typedef const GemmProb __attribute__((address_space(4))) &ProbRef;
@@ -87,18 +89,19 @@ typedef const GemmProb __attribute__((address_space(4))) &ProbRef;
 constexpr int EPI_LD = GEMM_BN + 4;       // 260 floats: the two 32-lane halves of a ds_write_b32 hit different banks
 
 template <int MI, int KS>
-__device__ __forceinline__ void store_tile(ProbRef P, const f32x16 (&acc)[MI], const int row0, const int col0, float *lds) {
+__device__ __forceinline__ void store_tile(ProbRef P, const f32x16 (&acc)[MI], const int row0, const int col0, float *lds,
+                                           const bool second = false) {
     constexpr int COLS = GEMM_BN / KS, WN = 8 / KS;
     constexpr int TPR = COLS / 4;                 // threads per output row (16 bytes each)
     constexpr int RPP = GEMM_THREADS / TPR;       // rows per pass: 8 / 16 / 32
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int M = P.M, N = P.N;
-    const float slope = P.slope;
+    const float slope = second ? P.slope2 : P.slope;
     const float *res = P.res;
     float *c = P.c;
     const int ldc = P.ldc, ldr = P.ldr;
     const bool writer = wave < WN;                // the wavefronts of K phase 0 hold the sums
-    const float bias = writer ? gload1(P.bias + col0 + wave * 32 + li) : 0.0f;
+    const float bias = writer ? gload1((second ? P.bias2 : P.bias) + col0 + wave * 32 + li) : 0.0f;
     float *wr = lds + (4 * lh) * EPI_LD + wave * 32 + li;
     const int rd_row = tid / TPR, rd_c4 = (tid % TPR) * 4;
     const bool vec = (col0 + COLS <= N);
@@ -138,9 +141,19 @@ __device__ __forceinline__ void store_tile(ProbRef P, const f32x16 (&acc)[MI], c
 // chip or to balance a launch: the tile is 256/KS columns wide, wavefront w multiplies column block
 // w % (8/KS) with every KS-th 32-wide K tile (phase w / (8/KS)), and the KS partial sums are added
 // through LDS at the end.  KS times as many tiles, each with 1/KS of the K-loop iterations.
-template <int MI, int KS>
+//
+// PAIR: the problem is a fused pair (GemmProb::w2): the tile of the first layer, all N <= 256 columns of it, stays
+// in LDS in the layout an MFMA loop reads and the second layer (K2 = N) runs on it at once - no barriers, no
+// staging, weights streaming - before the one epilogue with the residual.  This is a level of the conv pyramid
+// (lib/model/rie.py:94-97): the 3-tap stride-3 convolution and the 1x1 convolution that follows it.  Unfused, the
+// 1x1 layer is a K = 256 launch whose prologue, residual epilogue and launch cost rival its 8 K tiles of MFMAs,
+// and its input makes a round trip through HBM.
+constexpr int PAIR_LD = GEMM_BN + 4;                                     // 260 floats per row of the intermediate tile
+constexpr int PAIR_MAX_MI = 4;                                           // 128 x 260 floats = 133,120 B of LDS
+template <int MI, int KS, bool PAIR = false>
 __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int col0, const bool new_prob, float *smem,
                                           long long *dbg) {
+    static_assert(!PAIR || (KS == 1 && MI <= PAIR_MAX_MI), "fused pairs are whole tiles of at most 128 rows");
     constexpr int SF = STAGE_FLOATS;        // floats per LDS ring stage
     R3D_TSTAMP(0);
     static_assert(KS == 1 || (KS == 2 && MI <= 2) || (KS == 4 && MI == 1), "split-K tiles are small tiles");
@@ -389,7 +402,67 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
         }
     }
     R3D_TSTAMP(3);
-    store_tile<MI, KS>(P, acc, row0, col0, smem);
+    if constexpr (PAIR) {
+        // ---- first layer's activations -> LDS (the staging ring is dead), as the A operand of the second
+        const float slope1 = P.slope;
+        const float bias1 = gload1(P.bias + wave * 32 + li);
+        __syncthreads();                                            // every wavefront is done with the ring
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            float *wr = smem + (mi * 32 + 4 * lh) * PAIR_LD + wave * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[mi][r] + bias1;
+                wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = v > 0.0f ? v : v * slope1;
+            }
+        }
+        __syncthreads();
+        // ---- second layer: barrier-free MFMA loop over K2 = N, weight fragments two K tiles ahead
+        const int nk2 = P.K2 / BK;
+        __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(P.w2 + ((size_t)wave_u * nk2) * 1024), 0, nk2 * 4096, 0x00020000);
+        auto load_w2 = [&](int kt, f32x4 (&dst)[4]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                dst[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, w_voff + q * 1024, kt * 4096, 0));
+        };
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][r] = 0.0f;
+        const float *h_frag = smem + li * PAIR_LD + lh * 16;
+        const int last2 = nk2 - 1;
+        auto k_tile2 = [&](int kt2, f32x4 (&w_use)[4], f32x4 (&w_load)[4]) {
+            load_w2(kt2 + 2 < last2 ? kt2 + 2 : last2, w_load);
+            const float *s = h_frag + kt2 * BK;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 av[MI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) av[mi] = *reinterpret_cast<const f32x4 *>(s + mi * 32 * PAIR_LD + q * 4);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][kk], w_use[q][kk], acc[mi], 0, 0, 0);
+            }
+        };
+        load_w2(0, rb);
+        load_w2(1 < last2 ? 1 : last2, rbn);
+        int kt2 = 0;
+        for (; kt2 + 2 < nk2; kt2 += 3) {
+            k_tile2(kt2, rb, rbn2);
+            k_tile2(kt2 + 1, rbn, rb);
+            k_tile2(kt2 + 2, rbn2, rbn);
+        }
+        if (kt2 < nk2) {
+            k_tile2(kt2, rb, rbn2);
+            if (kt2 + 1 < nk2) k_tile2(kt2 + 1, rbn, rb);
+        }
+        store_tile<MI, 1>(P, acc, row0, col0, smem, true);      // (begins with a barrier: the tile is dead)
+    } else {
+        store_tile<MI, KS>(P, acc, row0, col0, smem);
+    }
     R3D_TSTAMP(4);
 }
 
@@ -579,6 +652,15 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                 if (ks == 4) gemm_tile<1, 4>(P, row0, col0, new_prob, smem, dbg);
                 else if (mi == 1) gemm_tile<1, 2>(P, row0, col0, new_prob, smem, dbg);
                 else gemm_tile<2, 2>(P, row0, col0, new_prob, smem, dbg);
+                continue;
+            }
+            if (P.w2 != nullptr) {       // fused pair (the scheduler caps these tiles at PAIR_MAX_MI units)
+                switch (mi) {
+                    case 1: gemm_tile<1, 1, true>(P, row0, col0, new_prob, smem, dbg); break;
+                    case 2: gemm_tile<2, 1, true>(P, row0, col0, new_prob, smem, dbg); break;
+                    case 3: gemm_tile<3, 1, true>(P, row0, col0, new_prob, smem, dbg); break;
+                    default: gemm_tile<4, 1, true>(P, row0, col0, new_prob, smem, dbg); break;
+                }
                 continue;
             }
             switch (mi) {

@@ -39,6 +39,7 @@ struct Builder {
         q.layer = m.layer_index.at(layer_prefix);
         q.rows_per_window = rows_pw;
         q.nseg = (int)ins.size();
+        q.layer2 = -1;
         q.enc_lut = enc_lut;
         q.enc_rows = rows_pw;
         const Layer &L0 = m.layers[q.layer];
@@ -91,6 +92,11 @@ struct Builder {
         int rows = m.RF / 3;
         const int pp[2] = {buffer(br.prefix + ".P0", (int64_t)rows * C),
                            L > 1 ? buffer(br.prefix + ".P1", (int64_t)(rows / 3) * C) : -1};
+        // a level's 1x1 convolution is applied to the 3-tap one's output tile inside the kernel when a tile holds
+        // all of its columns (r3d_kernels.hip, PAIR); otherwise the intermediate goes through a buffer
+        // Fusing costs the level its split-K freedom (a fused tile is a whole 32-row unit through both layers), so
+        // the top of the pyramid - one row per window, fewer units than CUs at the usual batch sizes - stays unfused.
+        auto fuse = [&](int level_rows) { return C <= N_ALIGN && level_rows >= 3; };
         const int hb = L > 1 ? buffer(br.prefix + ".H", (int64_t)(rows / 3) * C) : -1;
         // first layer: the A operand is generated from the raw input inside the kernel (fused prologue)
         int last = problem(br.prefix + ".expand_conv", rows, {}, -1, 0, 0, pp[0], 0, C, {}, (int)br.lut_off);
@@ -99,10 +105,17 @@ struct Builder {
             rows /= 3;
             const std::string a = br.prefix + ".layers_conv." + std::to_string(2 * (i - 1));
             const std::string b = br.prefix + ".layers_conv." + std::to_string(2 * (i - 1) + 1);
-            // three consecutive frames of the previous level form one GEMM row (stride == kernel)
-            const int pa = problem(a, rows, {{src, 0, 3 * C, 3 * C, last}}, -1, 0, 0, hb, 0, C);
+            // three consecutive frames of the previous level form one GEMM row (stride == kernel);
             // res = x[:, :, 1::3] is the centre third of that row (rie.py:94)
-            last = problem(b, rows, {{hb, 0, C, C, pa}}, src, C, 3 * C, dst, 0, C, {last});
+            if (fuse(rows)) {
+                last = problem(a, rows, {{src, 0, 3 * C, 3 * C, last}}, src, C, 3 * C, dst, 0, C);
+                ProbSpec &q = p.probs[last];
+                q.layer2 = m.layer_index.at(b);
+                q.flops_per_window += 2.0 * rows * (double)C * (double)C;
+            } else {
+                const int pa = problem(a, rows, {{src, 0, 3 * C, 3 * C, last}}, -1, 0, 0, hb, 0, C);
+                last = problem(b, rows, {{hb, 0, C, C, pa}}, src, C, 3 * C, dst, 0, C, {last});
+            }
         }
         const int fin = pp[(L - 1) & 1];
         return problem(br.prefix + ".shrink", 1, {{fin, 0, C, C, last}}, -1, 0, 0, c_buf, c_col, c_ld);

@@ -141,7 +141,7 @@ void pack(const std::vector<SchedProb> &probs, int nbins_max, int max_units, Pac
     for (int i = 0; i < (int)probs.size(); ++i) {
         const SchedProb &p = probs[i];
         const int units = (p.M + 31) / 32;
-        const double c1 = unit_cycles(p.nk, 1);
+        const double c1 = unit_cycles(p.nk + p.nk2, 1);
         for (int c0 = 0; c0 < p.N; c0 += 256) {
             segs.push_back({i, c0, units, p.nk, p.max_units > 0 ? std::min(p.max_units, max_units) : max_units, p.max_ks, c1,
                             std::min(256, p.N - c0)});
@@ -223,9 +223,16 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
             k += q.seg[sgi].width;
             while (max_ks > 1 && k % (BK * max_ks)) max_ks /= 2;
         }
-        probs.push_back({M, L.N, L.Kpad / BK, max_ks, enc_cap});
+        SchedProb sp{M, L.N, L.Kpad / BK, max_ks, enc_cap};
+        if (q.layer2 >= 0) {                       // fused pair: whole tiles of <= 128 rows, no split
+            sp.max_ks = 1;
+            sp.max_units = 4;
+            sp.nk2 = pl->m[q.model]->layers[q.layer2].Kpad / BK;
+        }
+        probs.push_back(sp);
         flops += q.flops_per_window * (double)B;
         bytes += 4.0 * ((double)M * L.K + (double)L.N * L.K + (double)M * L.N * (q.res_buf >= 0 ? 2.0 : 1.0));
+        if (q.layer2 >= 0) bytes += 4.0 * (double)L.N * L.N;
     }
     bool enc = false;
     for (int id : st) enc = enc || pl->probs[id].enc_lut >= 0;
