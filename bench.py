@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-stream", action="store_true", help="also time Ray3DLifter.forward_overlapped (two half batches on two streams)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -192,8 +193,9 @@ def main():
         }
         with torch.no_grad():
             line["roofline"] = roofline(lifter, x, p)
-        if n_gpus == 1:
-            # informative, not the headline: the same batch as two independent half batches on two HIP streams
+        if n_gpus == 1 and args.two_stream:
+            # informative, not the headline (opt-in so that the default command - the one profiles/prof_recipe.sh
+            # traces - launches full batches only): the same batch as two independent half batches on two HIP streams
             # (Ray3DLifter.forward_overlapped) - launch tails and small levels of one half overlap the other's work
             with torch.no_grad():
                 for _ in range(args.warmup):
