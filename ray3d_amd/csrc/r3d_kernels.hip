@@ -25,7 +25,6 @@ namespace r3d {
 #else
 #define R3D_TSTAMP(slot) do { } while (0)
 #endif
-#define R3D_STAMP(slot) do { } while (0)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -151,8 +150,7 @@ __device__ __forceinline__ void store_tile(ProbRef P, const f32x16 (&acc)[MI], c
 constexpr int PAIR_LD = GEMM_BN + 4;                                     // 260 floats per row of the intermediate tile
 constexpr int PAIR_MAX_MI = 4;                                           // 128 x 260 floats = 133,120 B of LDS
 template <int MI, int KS, bool PAIR = false>
-__device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int col0, const bool new_prob, float *smem,
-                                          long long *dbg) {
+__device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int col0, float *smem, long long *dbg) {
     static_assert(!PAIR || (KS == 1 && MI <= PAIR_MAX_MI), "fused pairs are whole tiles of at most 128 rows");
     constexpr int SF = STAGE_FLOATS;        // floats per LDS ring stage
     R3D_TSTAMP(0);
@@ -304,7 +302,6 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
     // MFMA of its SIMD partner, so anything that is not an MFMA belongs in the gap after the barrier
     // (an asymmetric compute-first/stage-first split between the partners was measured slower).
     auto k_tile = [&](int kt, f32x4 (&w_use)[4], f32x4 (&w_load)[4], Staged &stg) {
-        R3D_STAMP(0);
         const int st_next = st_cur == 2 ? 0 : st_cur + 1, st_next2 = st_next == 2 ? 0 : st_next + 1;
         const float *s = smem + st_cur * SF + a_frag;
         const bool active = KS == 1 || kt * KS + wave_u / WN < nk32;   // K-tile count not a multiple of KS: short last iteration
@@ -333,7 +330,6 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
             issue_a(kt + AD < last ? kt + AD : last, stg);
             prep_seg(kt + AD + 1 < last ? kt + AD + 1 : last);
         }
-        R3D_STAMP(1);
         mfma_q(0);
         if (INTERLEAVE) {
             commit_a(st_next2, stg);
@@ -346,15 +342,12 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
         }
         mfma_q(2);
         mfma_q(3);
-        R3D_STAMP(2);
         if (PRE) {
             const float *sn = smem + st_next * SF + a_frag;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) av0[mi] = *reinterpret_cast<const f32x4 *>(sn + mi * 32 * LDS_LD);
         }
-        R3D_STAMP(3);
         __syncthreads();
-        R3D_STAMP(4);
         st_cur = st_next;
     };
     int kt = 0;
@@ -649,27 +642,27 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
             }
         } else {
             if (ks > 1) {
-                if (ks == 4) gemm_tile<1, 4>(P, row0, col0, new_prob, smem, dbg);
-                else if (mi == 1) gemm_tile<1, 2>(P, row0, col0, new_prob, smem, dbg);
-                else gemm_tile<2, 2>(P, row0, col0, new_prob, smem, dbg);
+                if (ks == 4) gemm_tile<1, 4>(P, row0, col0, smem, dbg);
+                else if (mi == 1) gemm_tile<1, 2>(P, row0, col0, smem, dbg);
+                else gemm_tile<2, 2>(P, row0, col0, smem, dbg);
                 continue;
             }
             if (P.w2 != nullptr) {       // fused pair (the scheduler caps these tiles at PAIR_MAX_MI units)
                 switch (mi) {
-                    case 1: gemm_tile<1, 1, true>(P, row0, col0, new_prob, smem, dbg); break;
-                    case 2: gemm_tile<2, 1, true>(P, row0, col0, new_prob, smem, dbg); break;
-                    case 3: gemm_tile<3, 1, true>(P, row0, col0, new_prob, smem, dbg); break;
-                    default: gemm_tile<4, 1, true>(P, row0, col0, new_prob, smem, dbg); break;
+                    case 1: gemm_tile<1, 1, true>(P, row0, col0, smem, dbg); break;
+                    case 2: gemm_tile<2, 1, true>(P, row0, col0, smem, dbg); break;
+                    case 3: gemm_tile<3, 1, true>(P, row0, col0, smem, dbg); break;
+                    default: gemm_tile<4, 1, true>(P, row0, col0, smem, dbg); break;
                 }
                 continue;
             }
             switch (mi) {
-                case 1: gemm_tile<1, 1>(P, row0, col0, new_prob, smem, dbg); break;
-                case 2: gemm_tile<2, 1>(P, row0, col0, new_prob, smem, dbg); break;
-                case 3: gemm_tile<3, 1>(P, row0, col0, new_prob, smem, dbg); break;
-                case 4: gemm_tile<4, 1>(P, row0, col0, new_prob, smem, dbg); break;
-                case 5: gemm_tile<5, 1>(P, row0, col0, new_prob, smem, dbg); break;
-                default: gemm_tile<6, 1>(P, row0, col0, new_prob, smem, dbg); break;
+                case 1: gemm_tile<1, 1>(P, row0, col0, smem, dbg); break;
+                case 2: gemm_tile<2, 1>(P, row0, col0, smem, dbg); break;
+                case 3: gemm_tile<3, 1>(P, row0, col0, smem, dbg); break;
+                case 4: gemm_tile<4, 1>(P, row0, col0, smem, dbg); break;
+                case 5: gemm_tile<5, 1>(P, row0, col0, smem, dbg); break;
+                default: gemm_tile<6, 1>(P, row0, col0, smem, dbg); break;
             }
         }
     }

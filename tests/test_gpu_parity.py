@@ -253,3 +253,31 @@ def test_overlapped_half_batches_equal_the_single_pass():
     assert two.shape == one.shape
     assert (one - two).abs().max().item() <= 6e-5
     assert (one - three).abs().max().item() <= 6e-5
+
+
+@pytest.mark.parametrize("over", [
+    dict(ARCHITECTURE="3,3,3", CHANNELS=128, LATENT_FEATURES_DIM=160, EMBEDD_DIM=32, STAGE=2),            # narrow fused-pair tiles
+    dict(ARCHITECTURE="3,3,3", CHANNELS=512, LATENT_FEATURES_DIM=128, NUM_KPTS=15, STAGE=3),              # C > 256: levels not fused
+    dict(ARCHITECTURE="3,3,3,3", CHANNELS=96, LATENT_FEATURES_DIM=96, NUM_KPTS=14, INPUT_DIM=2,
+         CAMERA_EMBDDING=False, STAGE=1),                                                                   # 2D input, no embedding
+    dict(ARCHITECTURE="3,3", CHANNELS=1024, LATENT_FEATURES_DIM=256, EXTRINSIC_DIM=3, EMBEDD_DIM=96),      # the class-default width
+])
+def test_other_widths_match_oracle(over):
+    """Configurations no golden fixture has (the reference's cfg files all use C = 256): channel counts that
+    are not a tile width, more channels than a tile, other latent / embedding sizes."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    from oracle import oracle
+    mc = ray3d_amd.default_model_config(**over)
+    pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    batch = 70
+    x = synth.synth_rays(batch, cp, seed=31)
+    p = synth.synth_param(batch, seed=32)
+    if cp.extrinsic_dim != 2:
+        p = np.ascontiguousarray(np.tile(p, (1, 2))[:, : max(cp.extrinsic_dim, 1)])
+    pt = torch.from_numpy(p).cuda() if cp.camera_embedding else None
+    with torch.no_grad():
+        out = lifter(torch.from_numpy(x).cuda(), pt).cpu().numpy()
+    ref = oracle.forward(cp, sp, x, p if cp.camera_embedding else None) + oracle.forward(ct, st, x, p if cp.camera_embedding else None)
+    assert np.abs(out - ref).max() <= tol_for(ref), np.abs(out - ref).max()
