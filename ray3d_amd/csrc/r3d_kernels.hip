@@ -165,7 +165,10 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
     // its K tile is long enough and the registers are needed for accumulators.
     constexpr bool WD2 = MI <= 4;
     constexpr int AD = WD2 ? 5 : 4;         // A tile t+AD is issued in iteration t, committed to LDS in iteration t+AD-2
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    // (opaque to the optimiser: otherwise the per-thread constants of every tile shape are hoisted out of the
+    // persistent loop and stay live across the 6-unit tiles, which have no register to spare)
+    asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wn = wave % WN;                       // 32-column block of the tile this wavefront owns
