@@ -194,7 +194,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
                 g.enc_jf = JF;
                 g.enc_cur = (a->RF / a->cfg.in_features) * JF;   // quirk Q1: "current" frame is RF // in_features
                 g.enc_bytes = (unsigned)((size_t)frames * JF * sizeof(float));
-                g.enc_cur_rel = q.enc_rows == 1 && L.Kpad == CUR_LD && q.enc_lut == (int)m->global_lut_off;
+                g.enc_cur_rel = 0;
             }
             g.w = m->d_arena + L.w_off;
             g.bias = m->d_arena + L.b_off;

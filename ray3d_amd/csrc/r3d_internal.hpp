@@ -42,14 +42,14 @@ struct GemmProb {
     // --- fused feature-encoding prologue (first layers only; lut == nullptr otherwise) ---
     // A[row][col] is computed on the fly from the raw input instead of being read from memory:
     // row = window * enc_rows + t3 covers input frames 3*t3 .. 3*t3+2 of that window.
-    const int *lut;           // three tables: minuend byte offsets [K], subtrahend byte offsets [K], chunk flags [K/4]
+    const int *lut;           // two tables: element byte offsets [K], chunk flags [K/4] (layout below)
     const float *x;           // (frames, J*F) ray-encoded keypoints
     long long enc_ws;         // window stride in elements (frames * J*F)
     int enc_rows;             // GEMM rows per window (RF/3 for a temporal branch, 1 for GlobalInfo)
     int enc_jf;               // J*F
     int enc_cur;              // element offset of the "current" frame inside a window (tcur * J*F)
     unsigned enc_bytes;       // size of the raw input in bytes (buffer-descriptor bound)
-    int enc_cur_rel;          // 1: minuends are relative to the window's "current" frame (GlobalInfo input)
+    int enc_cur_rel;          // (unused: per-chunk flags in the table say which base a column uses)
     int pad2_;
 };
 
@@ -117,6 +117,7 @@ struct Layer {
     int N, K, Npad, Kpad;     // K = taps*cin
     float slope;
     std::vector<int> colmap;  // optional: GEMM column of torch column (tap*cin + c); empty = identity
+    std::vector<int> colmap_neg;   // first layers: column the same weight is SUBTRACTED from (-1: none)
     bool frag;                // packed in MFMA fragment order (GEMM layers) or row-major [N][Kpad] (decoder tail)
     size_t w_off, b_off;      // offsets (floats) into the packed arena
 };
@@ -255,16 +256,15 @@ hipError_t launch_decode(const DecodeArgs &args, hipStream_t stream);
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // Fused feature-encoding prologue tables (built in r3d_model.cpp, consumed by r3d_gemm_enc_f32).
-// The K columns of a first layer are ORDERED BY KIND - all plain values x, then all x - root, then all
-// x - x_current, each group padded to a multiple of four columns - so that the four columns one
-// staging thread handles always share their kind.  (The reference's channel order cat(x, diff, diff_t)
-// per tap, rie.py:308-315, only exists in the packed weight's column map.)  Per column k:
-//   lut1[k] = byte offset of the minuend from the row's first frame (or from the window's current
-//             frame for GlobalInfo), ENC_INVALID for padding columns;
-//   lut2[k] = byte offset of the subtrahend - root joint of the same frame (rie.py:301) relative to
-//             the row's first frame, or the same element of the current frame (rie.py:304) relative
-//             to that frame - ENC_INVALID when there is none;
-//   lutk[k/4] = 1 when the chunk's subtrahends are current-frame relative.
+// The reference feeds a branch cat(x, x - root, x - x_current) per tap (rie.py:301-315); the layer being linear, the
+// kernel multiplies the raw values instead - (W1+W2+W3) x - W2 root - W3 x_current, folded into the packed
+// weights in float64 - so an operand column is ONE gathered input element.  Columns are grouped: the x values of
+// the three taps, the root joint's values (when the group does not contain joint 0 itself), the window's
+// current frame; each group padded to a multiple of four columns so that the four columns one staging thread
+// handles share their base.  Per column k:
+//   lut1[k]   = byte offset of the element from the row's first frame - or from the window's current frame
+//               (quirk Q1) when lutk[k/4] is set; ENC_INVALID for padding columns;
+//   lutk[k/4] = 1 when the chunk is current-frame relative (GlobalInfo's input: every chunk).
 // ENC_INVALID pushes the address past the buffer descriptor's bound: the load returns 0.
 constexpr int ENC_INVALID = (int)0x80000000u;
 

@@ -70,7 +70,7 @@ constexpr int GEMM_BN = 256;
 constexpr int GEMM_MAX_MI = 6;
 constexpr int GEMM_STAGES = 3;
 constexpr int STAGE_FLOATS = GEMM_MAX_MI * 32 * LDS_LD;                  // one A tile: 27,648 B
-constexpr int LUT_LDS_INTS = 1152;                                       // fused-prologue tables: 2K + K/4 ints, K <= 480
+constexpr int LUT_LDS_INTS = 1152;                                       // fused-prologue tables: K + K/4 ints (K <= 480 with room to spare)
 constexpr int RING_LDS_BYTES = GEMM_STAGES * STAGE_FLOATS * 4;                      // 82,944 B
 constexpr int GEMM_LDS_BYTES = 4 * 32 * (GEMM_BN + 4) * 4;                          // 133,120 B: the fused pairs' intermediate tile
 static_assert(GEMM_LDS_BYTES >= RING_LDS_BYTES, "the ring and the intermediate tile share the allocation");
@@ -491,16 +491,16 @@ __device__ __forceinline__ void enc_tile(ProbRef P, const int row0, const int co
     int *lut_lds = reinterpret_cast<int *>(smem + ENC_TILE_BYTES / 4);
 
     __syncthreads();                                        // the previous tile's MFMA loop is done with LDS
-    const int *lut1 = lut_lds, *lut2 = lut_lds + K, *lutk = lut_lds + 2 * K;
+    const int *lut1 = lut_lds, *lutk = lut_lds + K;
     if (new_prob) {
-        for (int i = tid; i < 2 * K + K / 4; i += GEMM_THREADS) lut_lds[i] = *(const R3D_AS1 int *)(P.lut + i);
+        for (int i = tid; i < K + K / 4; i += GEMM_THREADS) lut_lds[i] = *(const R3D_AS1 int *)(P.lut + i);
         __syncthreads();
     }
-    // ---- build the encoded operand tile.  Columns are grouped by kind (r3d_internal.hpp), so the four
-    // columns of a staging thread share one subtrahend base; every gathered element costs one integer
-    // add for its address and one subtract - padding / absent operands read 0 through the descriptor.
+    // ---- build the operand tile: one gathered input element per column (the differences of the reference's
+    // encoding live in the folded weights, r3d_internal.hpp).  Columns are grouped by base, so the four columns of
+    // a staging thread share it; padding columns read 0 through the descriptor.
     __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x), 0, P.enc_bytes, 0x00020000);
-    unsigned b_first[NA], b_cur[NA], b_min[NA];      // byte offsets into the raw input
+    unsigned b_first[NA], b_cur[NA];                 // byte offsets into the raw input
     bool on[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -512,31 +512,27 @@ __device__ __forceinline__ void enc_tile(ProbRef P, const int row0, const int co
         const unsigned wbase = (unsigned)win * (unsigned)P.enc_ws;
         b_first[i] = (wbase + (unsigned)(t3 * 3 * P.enc_jf)) * 4;   // first frame of the row (3 frames per row)
         b_cur[i] = (wbase + (unsigned)P.enc_cur) * 4;               // the window's "current" frame (quirk Q1)
-        b_min[i] = P.enc_cur_rel ? b_cur[i] : b_first[i];
     }
-    struct Raw { f32x4 a[NA], s[NA]; };
+    struct Raw { f32x4 a[NA]; };
     auto issue = [&](int kt, Raw &r) {
         const int k = kt * BK + a_kq;
         const int4 o1 = *reinterpret_cast<const int4 *>(lut1 + k);
-        const int4 o2 = *reinterpret_cast<const int4 *>(lut2 + k);
-        const bool cur2 = lutk[k >> 2] != 0;
-        const int c1[4] = {o1.x, o1.y, o1.z, o1.w}, c2[4] = {o2.x, o2.y, o2.z, o2.w};
+        const bool cur = lutk[k >> 2] != 0;
+        const int c1[4] = {o1.x, o1.y, o1.z, o1.w};
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if (!on[i]) continue;
-            const unsigned b2 = cur2 ? b_cur[i] : b_first[i];
+            const unsigned b = cur ? b_cur[i] : b_first[i];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                r.a[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, b_min[i] + (unsigned)c1[e], 0, 0));
-                r.s[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, b2 + (unsigned)c2[e], 0, 0));
-            }
+            for (int e = 0; e < 4; ++e)
+                r.a[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, b + (unsigned)c1[e], 0, 0));
         }
     };
     auto commit = [&](int kt, const Raw &r) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if (!on[i]) continue;
-            *reinterpret_cast<f32x4 *>(smem + (srow + 64 * i) * ldt + kt * BK + a_kq) = r.a[i] - r.s[i];
+            *reinterpret_cast<f32x4 *>(smem + (srow + 64 * i) * ldt + kt * BK + a_kq) = r.a[i];
         }
     };
     {

@@ -184,40 +184,53 @@ Model *model_create(const r3d_config &cfg) {
     // GlobalInfo.fc_1 reads the zero-padded current-frame matrix
     m->layers[m->layer_index["GlobalInfo.fc_1"]].Kpad = CUR_LD;
     // ---- fused-prologue tables (layout: r3d_internal.hpp) and the matching column maps of the first layers.
-    // Reference channel order inside a branch: cat(x_g, diff_g, diff_t_g) per tap (rie.py:308-315, :540).
+    // Reference channel order inside a branch: cat(x_g, diff_g, diff_t_g) per tap (rie.py:308-315, :540).  The
+    // layer is linear in its input, so  W1 x + W2 (x - root) + W3 (x - x_cur)  is evaluated as
+    // (W1 + W2 + W3) x - W2 root - W3 x_cur:  a third of the operand columns and no subtraction in the kernel.
     m->iarena.clear();
     const int JF = J * F;
     for (auto &br : m->branches) {
         const int n = (int)br.joints.size(), nF = n * F;
-        const int G = round_up(3 * nF, 4);                   // columns per kind group (3 taps), padded to 4
-        br.k0 = 3 * G;
+        int root_pos = -1;                                   // position of joint 0 (the root, rie.py:301) in the group
+        for (int q = 0; q < n; ++q)
+            if (br.joints[q] == 0) root_pos = q;
+        const int GX = round_up(3 * nF, 4);                  // x columns (tap-major), padded to 4
+        const int GR = root_pos >= 0 ? 0 : round_up(3 * F, 4);   // root-joint columns (only when the group lacks joint 0)
+        const int GC = round_up(nF, 4);                      // current-frame columns
+        br.k0 = GX + GR + GC;
         br.k0pad = round_up(br.k0, BK);
         Layer &L = m->layers[m->layer_index[br.prefix + ".expand_conv"]];
         L.Kpad = br.k0pad;
-        L.colmap.assign(3 * br.cin, 0);
-        std::vector<int> l1(br.k0pad, ENC_INVALID), l2(br.k0pad, ENC_INVALID), lk(br.k0pad / 4, 0);
-        for (int kind = 0; kind < 3; ++kind)
-            for (int tap = 0; tap < 3; ++tap)
-                for (int c = 0; c < nF; ++c) {
-                    const int col = kind * G + tap * nF + c;
-                    const int src = br.joints[c / F] * F + c % F;       // element of the (J,F) frame
-                    L.colmap[tap * br.cin + kind * nF + c] = col;       // torch column (tap, channel kind*nF + c)
-                    l1[col] = (tap * JF + src) * 4;
-                    if (kind == 1) l2[col] = (tap * JF + c % F) * 4;    // root joint is joint 0 (rie.py:301)
-                    if (kind == 2) { l2[col] = src * 4; lk[col / 4] = 1; }
+        L.colmap.assign(3 * br.cin, -1);
+        L.colmap_neg.assign(3 * br.cin, -1);
+        std::vector<int> l1(br.k0pad, ENC_INVALID), lk(br.k0pad / 4, 0);
+        for (int tap = 0; tap < 3; ++tap)
+            for (int c = 0; c < nF; ++c) {
+                const int src = br.joints[c / F] * F + c % F;           // element of the (J,F) frame
+                const int xcol = tap * nF + c;
+                l1[xcol] = (tap * JF + src) * 4;
+                // the root term's column: the group's own joint-0 column, or a dedicated one
+                const int rcol = root_pos >= 0 ? tap * nF + root_pos * F + c % F : GX + tap * F + c % F;
+                if (root_pos < 0) l1[rcol] = (tap * JF + c % F) * 4;
+                const int ccol = GX + GR + c;
+                l1[ccol] = src * 4;
+                lk[ccol / 4] = 1;                                       // relative to the window's current frame
+                for (int kind = 0; kind < 3; ++kind) {
+                    const int t = tap * br.cin + kind * nF + c;         // torch column (tap, channel kind*nF + c)
+                    L.colmap[t] = xcol;
+                    L.colmap_neg[t] = kind == 1 ? rcol : kind == 2 ? ccol : -1;
                 }
+            }
         br.lut_off = m->iarena.size();
         m->iarena.insert(m->iarena.end(), l1.begin(), l1.end());
-        m->iarena.insert(m->iarena.end(), l2.begin(), l2.end());
         m->iarena.insert(m->iarena.end(), lk.begin(), lk.end());
     }
     // GlobalInfo.fc_1 reads in_current = x[:, RF // F] flattened (rie.py:290-292), zero padded to CUR_LD
     {
-        std::vector<int> l1(CUR_LD, ENC_INVALID), l2(CUR_LD, ENC_INVALID), lk(CUR_LD / 4, 0);
+        std::vector<int> l1(CUR_LD, ENC_INVALID), lk(CUR_LD / 4, 1);
         for (int col = 0; col < JF; ++col) l1[col] = col * 4;
         m->global_lut_off = m->iarena.size();
         m->iarena.insert(m->iarena.end(), l1.begin(), l1.end());
-        m->iarena.insert(m->iarena.end(), l2.begin(), l2.end());
         m->iarena.insert(m->iarena.end(), lk.begin(), lk.end());
     }
     for (auto &kv : m->layer_index)
@@ -307,13 +320,29 @@ int model_finalize(Model *m) {
         // torch layout (N, cin, taps) [Linear: taps == 1]; GEMM column index = tap*cin + c.
         // GEMM layers are stored in MFMA fragment order (see r3d_kernels.hip), the decoder tail row-major.
         const int nk = L.Kpad / BK;
-        for (int o = 0; o < L.N; ++o)
-            for (int c = 0; c < L.cin; ++c)
-                for (int j = 0; j < L.taps; ++j) {
-                    const int k = L.colmap.empty() ? j * L.cin + c : L.colmap[j * L.cin + c];
-                    const float v = (float)((double)w[((size_t)o * L.cin + c) * L.taps + j] * s[o]);
-                    dst[L.frag ? frag_index(o, k, nk) : (size_t)o * L.Kpad + k] = v;
-                }
+        if (L.colmap.empty()) {
+            for (int o = 0; o < L.N; ++o)
+                for (int c = 0; c < L.cin; ++c)
+                    for (int j = 0; j < L.taps; ++j) {
+                        const int k = j * L.cin + c;
+                        const float v = (float)((double)w[((size_t)o * L.cin + c) * L.taps + j] * s[o]);
+                        dst[L.frag ? frag_index(o, k, nk) : (size_t)o * L.Kpad + k] = v;
+                    }
+        } else {
+            // first layers: several reference columns add up (with sign) in one operand column; summed in double
+            std::vector<double> rowacc(L.Kpad);
+            for (int o = 0; o < L.N; ++o) {
+                std::fill(rowacc.begin(), rowacc.end(), 0.0);
+                for (int c = 0; c < L.cin; ++c)
+                    for (int j = 0; j < L.taps; ++j) {
+                        const double v = (double)w[((size_t)o * L.cin + c) * L.taps + j] * s[o];
+                        const int t = j * L.cin + c;
+                        rowacc[L.colmap[t]] += v;
+                        if (L.colmap_neg[t] >= 0) rowacc[L.colmap_neg[t]] -= v;
+                    }
+                for (int k = 0; k < L.Kpad; ++k) dst[frag_index(o, k, nk)] = (float)rowacc[k];
+            }
+        }
         float *bd = m->arena.data() + L.b_off;
         for (int o = 0; o < L.N; ++o) bd[o] = (float)t[o];
     }

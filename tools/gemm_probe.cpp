@@ -41,19 +41,16 @@ int main(int argc, char **argv) {
     std::vector<SchedProb> sp;
     // fused-prologue inputs: windows of 243 frames x 51 floats, LUT shaped like a temporal branch's
     float *dx = nullptr; int *dlut = nullptr;
-    std::vector<float> hx; std::vector<int> hlut(2 * K + K / 4, 0);
+    std::vector<float> hx; std::vector<int> hlut(K + K / 4, 0);
     if (enc) {
         const int nwin = M / 81;
         hx.resize((size_t)nwin * 243 * 51);
         for (size_t i = 0; i < hx.size(); ++i) hx[i] = (float)((i * 2246822519u) % 2001) / 1000.f - 1.f;
-        for (int k = 0; k < K; ++k) {   // kind-grouped columns like the real first layers
-            const int kind = (k * 3) / K, tap = k % 3, src = (k * 7) % 51;
-            hlut[k] = (tap * 51 + src) * 4;
-            hlut[K + k] = kind == 0 ? ENC_INVALID : kind == 1 ? (tap * 51 + src % 3) * 4 : src * 4;
-            if (kind == 2) hlut[2 * K + k / 4] = 1;
+        for (int k = 0; k < K; ++k) {   // base-grouped columns like the real first layers: 3/4 row-relative, 1/4 current-frame relative
+            const bool cur = k >= (K * 3 / 4) / 4 * 4;
+            hlut[k] = cur ? ((k * 7) % 51) * 4 : ((k % 3) * 51 + (k * 7) % 51) * 4;
+            if (cur) hlut[K + k / 4] = 1;
         }
-        for (int k = 0; k < K; ++k)     // a chunk is cur-relative as a whole
-            if (hlut[2 * K + k / 4] && (k * 3) / K != 2) { hlut[K + k] = ((k * 7) % 51) * 4; }
         CK(hipMalloc((void **)&dx, hx.size() * 4));
         CK(hipMalloc((void **)&dlut, hlut.size() * 4));
         CK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
@@ -114,9 +111,7 @@ int main(int argc, char **argv) {
             if (enc) {
                 const int win = r / 81, t3 = r % 81;
                 const size_t first = (size_t)win * 243 * 51 + (size_t)t3 * 3 * 51, cur = (size_t)win * 243 * 51 + 81 * 51;
-                const double v1 = hx[first + hlut[k] / 4];
-                const double v2 = hlut[K + k] == ENC_INVALID ? 0.0 : hx[(hlut[2 * K + k / 4] ? cur : first) + hlut[K + k] / 4];
-                a = v1 - v2;
+                a = hx[(hlut[K + k / 4] ? cur : first) + hlut[k] / 4];
             }
             acc += a * hWr[(size_t)c * K + k];
         }
@@ -125,24 +120,6 @@ int main(int argc, char **argv) {
         maxerr = err > maxerr ? err : maxerr;
     }
     printf("spot-check max rel err %.2e\n", maxerr);
-    if (getenv("PROBE_LDSDUMP") && enc) {
-        std::vector<float> hl(16384);
-        CK(hipMemcpy(hl.data(), ddbg, 65536, hipMemcpyDeviceToHost));
-        const int ldt = K + 4, r0 = tiles[1].y, rows = (tiles[1].x >> 8) * 32;
-        int bad = 0;
-        for (int r = 0; r < rows && r0 + r < M; ++r)
-            for (int k = 0; k < K; ++k) {
-                const int rr = r0 + r, win = rr / 81, t3 = rr % 81;
-                const size_t first = (size_t)win * 243 * 51 + (size_t)t3 * 3 * 51, cur = (size_t)win * 243 * 51 + 81 * 51;
-                const float v1 = hlut[k] == ENC_INVALID ? 0.f : hx[first + hlut[k] / 4];
-                const float v2 = hlut[K + k] == ENC_INVALID ? 0.f : hx[(hlut[2 * K + k / 4] ? cur : first) + hlut[K + k] / 4];
-                const float want = v1 - v2, got = hl[(size_t)r * ldt + k];
-                if (fabs(want - got) > 1e-5) { if (bad < 0) printf("  lds[row %d][k %d] got %.5f want %.5f (v1 %.5f v2 %.5f)\n", r, k, got, want, v1, v2); ++bad; }
-            }
-        printf("LDS tile 1: %d bad of %d\n", bad, rows * K);
-        for (int r = 0; r < 2; ++r) { printf("row %d got:", r); for (int k = 0; k < K; ++k) printf(" %.3f", hl[(size_t)r * ldt + k]); printf("\n"); }
-        printf("lut1:"); for (int k = 0; k < K; ++k) printf(" %d", hlut[k] / 4); printf("\nlut2:"); for (int k = 0; k < K; ++k) printf(" %d", hlut[K + k] == ENC_INVALID ? -1 : hlut[K + k] / 4); printf("\n");
-    }
     if (getenv("PROBE_FULLCHECK")) {
         // per 32-row unit: how many of 8 sampled entries are wrong
         const int units = (M + 31) / 32;
@@ -158,9 +135,7 @@ int main(int argc, char **argv) {
                     if (enc) {
                         const int win = r / 81, t3 = r % 81;
                         const size_t first = (size_t)win * 243 * 51 + (size_t)t3 * 3 * 51, cur = (size_t)win * 243 * 51 + 81 * 51;
-                        const double v1 = hx[first + hlut[k] / 4];
-                        const double v2 = hlut[K + k] == ENC_INVALID ? 0.0 : hx[(hlut[2 * K + k / 4] ? cur : first) + hlut[K + k] / 4];
-                        a = v1 - v2;
+                        a = hx[(hlut[K + k / 4] ? cur : first) + hlut[k] / 4];
                     }
                     acc += a * hWr[(size_t)c * K + k];
                 }
@@ -184,9 +159,7 @@ int main(int argc, char **argv) {
                     for (int k = 0; k < K; ++k) {
                         const int win = rr / 81, t3 = rr % 81;
                         const size_t first = (size_t)win * 243 * 51 + (size_t)t3 * 3 * 51, cur = (size_t)win * 243 * 51 + 81 * 51;
-                        const double v1 = hx[first + hlut[k] / 4];
-                        const double v2 = hlut[K + k] == ENC_INVALID ? 0.0 : hx[(hlut[2 * K + k / 4] ? cur : first) + hlut[K + k] / 4];
-                        acc += (v1 - v2) * hWr[(size_t)c * K + k];
+                        acc += (double)hx[(hlut[K + k / 4] ? cur : first) + hlut[k] / 4] * hWr[(size_t)c * K + k];
                     }
                     printf(" %9.4f", acc > 0 ? acc : 0.2 * acc);
                 }
