@@ -171,6 +171,9 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
                     if (pl->buffers[q.seg[s].buf].external == 3) {      // the caller's camera-parameter rows
                         g.a[s] = in->param_dev;
                         g.lda[s] = (int)in->param_stride;
+                    } else if (pl->buffers[q.seg[s].buf].external == 4) {   // the windows' current frames (quirk Q1), in place
+                        g.a[s] = x_rays + (size_t)(a->RF / a->cfg.in_features) * JF;
+                        g.lda[s] = (int)(in->window_stride * JF);
                     } else {
                         g.a[s] = buf_ptr(q.seg[s].buf) + q.seg[s].col;
                         g.lda[s] = q.seg[s].ld;
@@ -186,7 +189,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             // the 2-wide parameter rows): its true width bounds the buffer descriptor, the rest reads as zeros
             if (q.nseg > 0 && !(q.nseg == 1 && kend < L.Kpad)) g.kend[q.nseg - 1] = 0x7fffffff;
             if (q.enc_lut >= 0) {
-                ++n_enc;
+                if (q.layer3 < 0) ++n_enc;                  // (the fused first level runs in the GEMM kernel)
                 g.lut = m->d_iarena + q.enc_lut;
                 g.x = x_rays;
                 g.enc_ws = in->window_stride * JF;
@@ -212,6 +215,13 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
                 g.bias2 = m->d_arena + L2.b_off;
                 g.K2 = L2.Kpad;
                 g.slope2 = L2.slope;
+            }
+            if (q.layer3 >= 0) {
+                const Layer &L3 = m->layers[q.layer3];
+                g.w3 = m->d_arena + L3.w_off;
+                g.bias3 = m->d_arena + L3.b_off;
+                g.K3 = L3.Kpad;
+                g.slope3 = L3.slope;
             }
         }
         if (n_enc != 0 && n_enc != la.nprob) { set_error("internal: launch mixes encoded and plain operands"); return R3D_ERR_STATE; }

@@ -39,6 +39,13 @@ struct GemmProb {
     const float *bias2;
     int K2;
     float slope2;
+    // --- first level of the pyramid in one tile (w3 != nullptr; lut != nullptr): w/bias = expand_conv on the gathered
+    // input (three rows per output row), w2/bias2 = the level's 3-tap convolution, w3/bias3 = its 1x1 convolution;
+    // the residual is the centre one of the three expand_conv rows.  M counts OUTPUT rows. ---
+    const float *w3;
+    const float *bias3;
+    int K3;
+    float slope3;
     // --- fused feature-encoding prologue (first layers only; lut == nullptr otherwise) ---
     // A[row][col] is computed on the fly from the raw input instead of being read from memory:
     // row = window * enc_rows + t3 covers input frames 3*t3 .. 3*t3+2 of that window.
@@ -163,7 +170,8 @@ struct Model {
 struct BufferSpec {
     std::string name;
     int64_t floats_per_window;   // rows_per_window * ld
-    int external;                // 0 workspace, 1 out_dev, 2 out_trj_dev, 3 the caller's camera-parameter rows (input)
+    int external;                // 0 workspace, 1 out_dev, 2 out_trj_dev, 3 the caller's camera-parameter rows (input),
+                                 // 4 the windows' "current" frames inside the caller's input (row stride = window stride)
     int64_t offset_per_window;   // workspace offset / B (floats)
 };
 
@@ -176,6 +184,7 @@ struct ProbSpec {
     int res_buf, res_col, res_ld;
     int c_buf, c_col, c_ld;
     int layer2;                  // >= 0: second layer of a fused pair (applied to the first one's output tile)
+    int layer3;                  // >= 0 (with enc_lut >= 0): third layer of the fused first level
     int enc_lut;                 // >= 0: fused-encode problem, offset of its LUT in the model's int arena
     int enc_rows;
     std::vector<int> deps;
@@ -211,6 +220,7 @@ struct Plan {
     int64_t floats_per_window = 0;
     int emb_buf[2] = {-1, -1};
     int param_buf = -1;          // pseudo-buffer standing for r3d_input::param_dev
+    int xcur_buf = -1;           // pseudo-buffer: the windows' current frames inside r3d_input::x_dev
     int rays_buf = -1;           // UV mode scratch for the encoded rays (sized per call)
     // fused decoder tail: (model, layer, hidden buffer) per Integration block
     struct Dec { int model, layer, hbuf; };
@@ -235,7 +245,7 @@ struct SchedProb {
     int max_ks;      // largest split-K factor the operand allows (1 = none: fused-prologue operands, or a
                      // concatenated operand with a boundary that is not a multiple of 32*KS)
     int max_units;   // per-problem cap on 32-row units per tile (0 = the launch default)
-    int nk2 = 0;     // K tiles of the fused second layer (cost only)
+    int nk2 = 0;     // K-loop iterations of the fused further layers, in 32-row units (cost only)
 };
 void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units, std::vector<int4> &tiles,
                     std::vector<int> &wgoff, StageSchedule &out, bool enc = false);

@@ -10,6 +10,7 @@
 // never materialised: a problem's A operand is a list of column segments of other buffers.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 
 #include "r3d_internal.hpp"
 
@@ -31,6 +32,7 @@ struct Builder {
         p.buffers.push_back(b);
         return (int)p.buffers.size() - 1;
     }
+    bool first_level_fused = false;
     struct In { int buf, col, ld, width, dep; };
     int problem(const std::string &layer_prefix, int rows_pw, const std::vector<In> &ins, int res_buf, int res_col,
                 int res_ld, int c_buf, int c_col, int c_ld, std::vector<int> extra_deps = {}, int enc_lut = -1) {
@@ -40,6 +42,7 @@ struct Builder {
         q.rows_per_window = rows_pw;
         q.nseg = (int)ins.size();
         q.layer2 = -1;
+        q.layer3 = -1;
         q.enc_lut = enc_lut;
         q.enc_rows = rows_pw;
         const Layer &L0 = m.layers[q.layer];
@@ -58,7 +61,9 @@ struct Builder {
         }
         q.res_buf = res_buf; q.res_col = res_col; q.res_ld = res_ld;
         q.c_buf = c_buf; q.c_col = c_col; q.c_ld = c_ld;
-        q.depth = enc_lut >= 0 ? 0 : 1;     // level 0 is the fused-prologue launch: encoded operands only
+        // level 0 is the fused-prologue launch (encoded operands only) - unless the first level runs fused in the
+        // GEMM kernel, which takes plain problems alongside
+        q.depth = enc_lut >= 0 || first_level_fused ? 0 : 1;
         for (int d : q.deps) q.depth = std::max(q.depth, p.probs[d].depth + 1);
         q.flops_per_window = 2.0 * rows_pw * (double)L.K * (double)L.N;
         p.probs.push_back(q);
@@ -90,7 +95,8 @@ struct Builder {
         const Model::Branch &br = m.branches[bi];
         const int C = m.cfg.channels, L = m.cfg.num_levels;
         int rows = m.RF / 3;
-        const int pp[2] = {buffer(br.prefix + ".P0", (int64_t)rows * C),
+        // (with the first level fused the expand_conv output never exists in memory: P0 only serves level >= 2)
+        const int pp[2] = {buffer(br.prefix + ".P0", first_level_fused ? (int64_t)std::max(rows / 9, 1) * C : (int64_t)rows * C),
                            L > 1 ? buffer(br.prefix + ".P1", (int64_t)(rows / 3) * C) : -1};
         // a level's 1x1 convolution is applied to the 3-tap one's output tile inside the kernel when a tile holds
         // all of its columns (r3d_kernels.hip, PAIR); otherwise the intermediate goes through a buffer
@@ -99,8 +105,22 @@ struct Builder {
         auto fuse = [&](int level_rows) { return C <= N_ALIGN && level_rows >= 3; };
         const int hb = L > 1 ? buffer(br.prefix + ".H", (int64_t)(rows / 3) * C) : -1;
         // first layer: the A operand is generated from the raw input inside the kernel (fused prologue)
-        int last = problem(br.prefix + ".expand_conv", rows, {}, -1, 0, 0, pp[0], 0, C, {}, (int)br.lut_off);
-        for (int i = 1; i < L; ++i) {
+        int last, i0 = 1;
+        if (first_level_fused) {
+            // expand_conv + level 1 (3-tap and 1x1 convolutions) as one problem of rows/3 output rows per window
+            const std::string a = br.prefix + ".layers_conv.0", b = br.prefix + ".layers_conv.1";
+            last = problem(br.prefix + ".expand_conv", rows / 3, {}, -1, 0, 0, pp[1], 0, C, {}, (int)br.lut_off);
+            ProbSpec &q = p.probs[last];
+            q.enc_rows = rows;
+            q.layer2 = m.layer_index.at(a);
+            q.layer3 = m.layer_index.at(b);
+            q.flops_per_window = 2.0 * rows * (double)m.layers[q.layer].K * C + 2.0 * (rows / 3) * (3.0 * C * C + (double)C * C);
+            rows /= 3;
+            i0 = 2;
+        } else {
+            last = problem(br.prefix + ".expand_conv", rows, {}, -1, 0, 0, pp[0], 0, C, {}, (int)br.lut_off);
+        }
+        for (int i = i0; i < L; ++i) {
             const int src = pp[(i - 1) & 1], dst = pp[i & 1];
             rows /= 3;
             const std::string a = br.prefix + ".layers_conv." + std::to_string(2 * (i - 1));
@@ -132,6 +152,13 @@ static Plan *build_plan(const Model *a, const Model *b) {
         const Model *m = pl->m[mi];
         if (!m) continue;
         Builder B{*pl, mi, *m};
+        // the first pyramid level runs fused (r3d_kernels.hip, first_level_tile) when a tile can hold it: at least two
+        // levels, all channels in one 256-column tile, first-layer operand tile next to the intermediate
+        {
+            int k0max = 0;
+            for (const auto &br : m->branches) k0max = std::max(k0max, br.k0pad);
+            B.first_level_fused = m->cfg.num_levels >= 2 && m->cfg.channels <= N_ALIGN && k0max <= 256 && !getenv("R3D_NO_FIRST_FUSE");
+        }
         const int lat = m->cfg.latent, D = m->cfg.embed_dim;
         int pe = -1;
         if (D > 0) {
@@ -144,7 +171,15 @@ static Plan *build_plan(const Model *a, const Model *b) {
             pe = B.problem("embedder.w2", 1, {{eh, 0, EMBED_MID, EMBED_MID, p1}}, -1, 0, 0, pl->emb_buf[mi], 0, D);
         }
         const int g = B.buffer("global", lat);
-        const int pg = B.fc_block("GlobalInfo", {}, 2, g, 0, lat, (int)m->global_lut_off);
+        int pg;
+        if (B.first_level_fused) {
+            // in_current = x[:, RF // F] (rie.py:290-292) read in place: a matrix whose rows are a window stride apart
+            if (pl->xcur_buf < 0) pl->xcur_buf = B.buffer("x.current", 0, 4);
+            const int JF = m->cfg.num_joints * m->cfg.in_features;
+            pg = B.fc_block("GlobalInfo", {{pl->xcur_buf, 0, 0, JF, -1}}, 2, g, 0, lat);
+        } else {
+            pg = B.fc_block("GlobalInfo", {}, 2, g, 0, lat, (int)m->global_lut_off);
+        }
         if (m->cfg.kind == R3D_KIND_POS) {
             pl->pos_model = mi;
             const int tmp5 = B.buffer("tmp5", 5 * lat);

@@ -224,7 +224,13 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
             while (max_ks > 1 && k % (BK * max_ks)) max_ks /= 2;
         }
         SchedProb sp{M, L.N, L.Kpad / BK, max_ks, enc_cap};
-        if (q.layer2 >= 0) {                       // fused pair: whole tiles of <= 128 rows, no split
+        if (q.nseg == 1 && q.seg[0].width < L.Kpad) sp.max_ks = 1;   // an operand narrower than its padded K: one bounded descriptor
+        if (q.layer3 >= 0) {                       // fused first level: one 32-row tile runs three layers (three input rows per row)
+            const Model *mm = pl->m[q.model];
+            sp.max_ks = 1;
+            sp.max_units = 1;
+            sp.nk2 = 2 * sp.nk + mm->layers[q.layer2].Kpad / BK + mm->layers[q.layer3].Kpad / BK;
+        } else if (q.layer2 >= 0) {                // fused pair: whole tiles of <= 128 rows, no split
             sp.max_ks = 1;
             sp.max_units = 4;
             sp.nk2 = pl->m[q.model]->layers[q.layer2].Kpad / BK;
@@ -232,10 +238,11 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
         probs.push_back(sp);
         flops += q.flops_per_window * (double)B;
         bytes += 4.0 * ((double)M * L.K + (double)L.N * L.K + (double)M * L.N * (q.res_buf >= 0 ? 2.0 : 1.0));
-        if (q.layer2 >= 0) bytes += 4.0 * (double)L.N * L.N;
+        if (q.layer2 >= 0) bytes += 4.0 * (double)L.N * pl->m[q.model]->layers[q.layer2].K;
+        if (q.layer3 >= 0) bytes += 4.0 * (double)L.N * L.N + 4.0 * 2.0 * (double)M * L.K;   // (three input rows per output row)
     }
     bool enc = false;
-    for (int id : st) enc = enc || pl->probs[id].enc_lut >= 0;
+    for (int id : st) enc = enc || (pl->probs[id].enc_lut >= 0 && pl->probs[id].layer3 < 0);
     // the fused-prologue kernel runs two workgroups per CU (one encodes while the other multiplies)
     schedule_stage(probs, enc ? 2 * nwg : nwg, GEMM_SCHED_MAX_UNITS, tiles, wgoff, out, enc);
     out.flops = flops;
