@@ -20,11 +20,12 @@ def load(d):
 
 
 def one_forward(per):
+    """Dispatches of the last complete forward: everything after the previous decoder launch up to and
+    including the last one (r3d_decode_f32 closes every forward)."""
     ids = sorted(per)
-    first = [i for i in ids if per[i]['name'].startswith('r3d_')]
-    starts = [i for i in first if per[i]['name'] == per[first[0]]['name']]
-    s, e = starts[-2], starts[-1]
-    return [per[i] for i in ids if s <= i < e and per[i]['name'].startswith('r3d')]
+    ends = [i for i in ids if per[i]['name'].startswith('r3d_decode')]
+    s, e = ends[-2], ends[-1]
+    return [per[i] for i in ids if s < i <= e and per[i]['name'].startswith('r3d')]
 
 
 root = sys.argv[1]
