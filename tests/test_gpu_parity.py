@@ -281,3 +281,38 @@ def test_other_widths_match_oracle(over):
         out = lifter(torch.from_numpy(x).cuda(), pt).cpu().numpy()
     ref = oracle.forward(cp, sp, x, p if cp.camera_embedding else None) + oracle.forward(ct, st, x, p if cp.camera_embedding else None)
     assert np.abs(out - ref).max() <= tol_for(ref), np.abs(out - ref).max()
+
+
+def test_rccl_gather_of_clip_partials_single_rank():
+    """The exchange step of the sharded evaluation on the real backend: one all_gather of device-resident
+    per-clip rows through RCCL (backend "nccl"), here with a single rank (the GPU box has one device; the
+    world_size-2 logic is covered on CPU with gloo in tests/test_host.py)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    import ray3d_amd
+    from conftest import GOLDEN
+    from ray3d_amd import evaluate
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    try:
+        z = np.load(os.path.join(GOLDEN, "evalcore.npz"))
+        mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
+        pos, trj, _, _ = build_modules(mc)
+        lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+        clips = [evaluate.Clip(ray3d_amd.Camera(z["clip%d/K" % i], z["clip%d/R" % i], z["clip%d/t" % i]),
+                               z["clip%d/rays" % i], z["clip%d/gt_norm" % i], "A", i) for i in range(3)]
+        with torch.no_grad():
+            named, avg, rows = evaluate.evaluate_clips(lifter.forward_clip, clips, 27, torch.device("cuda:0"))
+            gathered = evaluate.gather_partials(rows, [rows.shape[0]])
+        assert gathered.is_cuda and torch.equal(gathered, rows)
+        ref = z["metrics_flip0"]
+        assert np.abs(np.array(evaluate.reduce_partials(gathered)[0]) - ref).max() < 5e-2
+    finally:
+        dist.destroy_process_group()
