@@ -26,12 +26,13 @@ class Camera:
         self.Rw2c = np.asarray(R, dtype=np.float64).reshape(3, 3)
         self.Tw2c = np.asarray(t, dtype=np.float64).reshape(3, 1)
         self.dist_coeff = None if dist_coeff is None else np.asarray(dist_coeff, dtype=np.float64).reshape(5)
-        if undistort:
-            # cv2.undistortPoints (opencv-python 4.4, camera.py:420) is not available offline and no
-            # reference fixture pins it; refuse rather than ship an unpinned approximation.
-            raise NotImplementedError("undistort=True needs OpenCV's undistortPoints; encode H36M "
-                                      "keypoints with undistort=False or undistort them upstream")
-        self.undistort = False
+        if undistort and self.dist_coeff is None:
+            raise ValueError("undistort=True needs dist_coeff (k1, k2, p1, p2, k3)")
+        # undistort=True (the H36M default, lib/dataset/h36m_dataset.py:383-385): pixel keypoints go through
+        # undistort_points() before the ray encoding, as lib/camera/camera.py:423-441 does.  PARITY UNPINNED: the
+        # reference calls cv2.undistortPoints (opencv-python 4.4.0.42), absent here and pinned by no reference
+        # test; undistort_points restates OpenCV's documented algorithm (see its docstring).
+        self.undistort = bool(undistort)
         self.fx, self.fy = self.K[0, 0], self.K[1, 1]
         self.cx, self.cy = self.K[0, 2], self.K[1, 2]
 
@@ -62,8 +63,49 @@ class Camera:
                         dtype=np.float64)
 
     # -- host-side equivalents (dataset-load time in the reference, lib/dataset/__init__.py:191-203)
-    def rays_from_uv(self, uv: np.ndarray) -> np.ndarray:
+    def undistort_points(self, uv: np.ndarray) -> np.ndarray:
+        """Pixel keypoints (..., 2) with the lens distortion removed, float64: the counterpart of
+        CameraInfoPacket.undistort_point (lib/camera/camera.py:412-421), i.e.
+        ``cv2.undistortPoints(points2d, K, dist_coeff, P=K)``.  PARITY UNPINNED - OpenCV is a third-party
+        dependency absent from the reference tree and from this image; this is OpenCV's documented method for
+        the 5-coefficient Brown-Conrady model (k1, k2, p1, p2, k3): five fixed-point iterations of
+        x <- (x0 - tangential(x)) / radial(x) on normalised coordinates, then re-projection with K.  Checked only
+        by the distort(undistort(p)) round trip and the principal-point fixed point (tests/test_host.py)."""
+        if self.dist_coeff is None:
+            raise ValueError("this camera has no distortion coefficients")
+        k1, k2, p1, p2, k3 = (float(v) for v in self.dist_coeff)
         uv = np.asarray(uv, dtype=np.float64)
+        x0 = (uv[..., 0] - self.cx) / self.fx
+        y0 = (uv[..., 1] - self.cy) / self.fy
+        x, y = x0.copy(), y0.copy()
+        for _ in range(5):
+            r2 = x * x + y * y
+            icd = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2)
+            dx = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
+            dy = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
+            x = (x0 - dx) * icd
+            y = (y0 - dy) * icd
+        return np.stack([x * self.fx + self.cx, y * self.fy + self.cy], axis=-1)
+
+    def distort_points(self, uv: np.ndarray) -> np.ndarray:
+        """Forward Brown-Conrady model on ideal pixels (data/camera_augmentation.py:502-542), for round trips."""
+        k1, k2, p1, p2, k3 = (float(v) for v in self.dist_coeff)
+        uv = np.asarray(uv, dtype=np.float64)
+        x = (uv[..., 0] - self.cx) / self.fx
+        y = (uv[..., 1] - self.cy) / self.fy
+        r2 = x * x + y * y
+        rad = 1.0 + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2
+        xd = x * rad + (2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x))
+        yd = y * rad + (p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y)
+        return np.stack([xd * self.fx + self.cx, yd * self.fy + self.cy], axis=-1)
+
+    def pixels_for_encoding(self, uv: np.ndarray) -> np.ndarray:
+        """What encode_uv_with_intrinsic (camera.py:423-441) subtracts the principal point from: the keypoints,
+        undistorted first when the camera was built with undistort=True.  Feed this to Ray3DLifter.forward_uv."""
+        return self.undistort_points(uv) if self.undistort else np.asarray(uv, dtype=np.float64)
+
+    def rays_from_uv(self, uv: np.ndarray) -> np.ndarray:
+        uv = self.pixels_for_encoding(uv)
         x = (uv[..., 0] - self.cx) / self.fx
         y = (uv[..., 1] - self.cy) / self.fy
         return np.stack([x, self.cos_p * y + self.sin_p, -self.sin_p * y + self.cos_p], axis=-1)

@@ -156,8 +156,29 @@ def test_camera_matches_reference():
         assert cam.param().dtype == np.float32 and cam.cam_row().shape == (8,)
     s9 = ray3d_amd.Camera(z["h36m_S9_0/K"], z["h36m_S9_0/R"], z["h36m_S9_0/t"])
     assert np.allclose(s9.param(), [1.4812, 0.18404], atol=2e-4)    # the constants BASELINE.md quotes
-    with pytest.raises(NotImplementedError):
-        ray3d_amd.Camera(z["h36m_S9_0/K"], z["h36m_S9_0/R"], z["h36m_S9_0/t"], undistort=True)
+    with pytest.raises(ValueError):
+        ray3d_amd.Camera(z["h36m_S9_0/K"], z["h36m_S9_0/R"], z["h36m_S9_0/t"], undistort=True)   # no coefficients given
+
+
+def test_camera_undistortion_is_unpinned_but_consistent():
+    """undistort=True (H36M default): no reference vector exists (OpenCV absent) - the product code must agree
+    with the oracle's restatement and satisfy the weak known-answer relations of SURVEY 8c."""
+    import ray3d_amd
+    from oracle import oracle
+    z = np.load(os.path.join(GOLDEN, "cameras.npz"))
+    K = z["h36m_S9_0/K"]
+    dist = np.array([-0.207098910824901, 0.247775183068982, -0.00142447157470321, -0.000975698859470499,
+                     -0.00307515035078854])                                  # (rad0, rad1, tan0, tan1, rad2): h36m_dataset.py:378-380
+    cam = ray3d_amd.Camera(K, z["h36m_S9_0/R"], z["h36m_S9_0/t"], dist_coeff=dist, undistort=True)
+    pts = np.stack(np.meshgrid(np.linspace(100, 900, 9), np.linspace(100, 900, 9)), -1).reshape(-1, 2)
+    und = cam.undistort_points(pts)
+    assert np.abs(und - oracle.undistort_points(K, dist, pts)).max() < 1e-9
+    assert np.abs(cam.distort_points(und) - pts).max() < 2e-2              # centi-pixel round trip after 5 iterations
+    pp = np.array([[K[0, 2], K[1, 2]]])
+    assert np.abs(cam.undistort_points(pp) - pp).max() < 1e-9             # the principal point is a fixed point
+    plain = ray3d_amd.Camera(K, z["h36m_S9_0/R"], z["h36m_S9_0/t"])
+    assert np.abs(cam.rays_from_uv(pts) - plain.rays_from_uv(und)).max() < 1e-12   # encode = undistort, then the usual rays
+    assert np.abs(cam.rays_from_uv(pts) - plain.rays_from_uv(pts)).max() > 1e-4    # ... and it is not a no-op
 
 
 def test_metrics_match_reference():
