@@ -952,9 +952,12 @@ extern "C" __global__ __launch_bounds__(GEMM_THREADS, 4) void r3d_gemm_enc_f32(c
 }
 
 hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, int kind, hipStream_t stream) {
-    static bool attr_done = false;
+    // more dynamic LDS than the 64 KiB default cap: raised once per device (a process may drive several)
+    static bool attr_done_dev[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    bool &attr_done = attr_done_dev[dev];
     if (!attr_done) {
-        // 83 KiB of dynamic LDS exceeds the 64 KiB default cap
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(r3d_gemm_f32),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
         if (e != hipSuccess) return e;
