@@ -226,6 +226,48 @@ static Plan *build_plan(const Model *a, const Model *b) {
             B.fc_block("Integration", ins, 1, -1, 0, 0);
         }
     }
+    // The GlobalInfo MLP (rie.py:362) is independent of the conv pyramid and only needed by the Integration blocks.
+    // As early as possible its 32-iteration units ride in the short launches at the top of the pyramid and define
+    // their length; as LATE as possible (below) they ride in the FuseBlock launches, which have idle CUs anyway.
+    {
+        const int n = (int)pl->probs.size();
+        std::vector<std::vector<int>> users(n);
+        for (int i = 0; i < n; ++i)
+            for (int d : pl->probs[i].deps) users[d].push_back(i);
+        int deepest = 0;
+        for (const auto &q : pl->probs) deepest = std::max(deepest, q.depth);
+        // ... and so does the trajectory model's decoder MLP ("Integration."; the body-part decoders are
+        // "Integration_<part>."), which only the final decoder kernel waits for
+        auto movable = [&](const ProbSpec &q) {
+            const std::string &key = pl->m[q.model]->layers[q.layer].weight_key;
+            return (key.rfind("GlobalInfo.", 0) == 0 && key.rfind("GlobalInfo.fc_1", 0) != 0) || key.rfind("Integration.", 0) == 0;
+        };
+        auto iterations = [&](const ProbSpec &q) {      // K-loop iterations of one 32-row unit through the problem
+            const Model *mm = pl->m[q.model];
+            int it = mm->layers[q.layer].Kpad / BK;
+            if (q.layer3 >= 0) it = 3 * it + mm->layers[q.layer2].Kpad / BK + mm->layers[q.layer3].Kpad / BK;
+            else if (q.layer2 >= 0) it += mm->layers[q.layer2].Kpad / BK;
+            return it;
+        };
+        // longest unit among the problems that stay where they are, per level: a launch that long takes a
+        // movable problem's units along for free (as long as there are CUs to spare)
+        std::vector<int> level_iters(deepest + 1, 0);
+        for (const auto &q : pl->probs)
+            if (!movable(q)) level_iters[q.depth] = std::max(level_iters[q.depth], iterations(q));
+        for (int i = n - 1; i >= 0; --i) {
+            ProbSpec &q = pl->probs[i];
+            if (!movable(q)) continue;
+            int latest = users[i].empty() ? deepest : 1 << 30;
+            for (int u : users[i]) latest = std::min(latest, pl->probs[u].depth - 1);
+            if (latest >= (1 << 30) || latest <= q.depth) continue;
+            // the latest level in [earliest, latest] whose launch is at least as long as this problem's units;
+            // failing that, the latest one
+            int pick = latest;
+            for (int l = latest; l >= q.depth; --l)
+                if (level_iters[l] >= iterations(q)) { pick = l; break; }
+            q.depth = pick;
+        }
+    }
     // levelise
     int maxd = 0;
     for (auto &q : pl->probs) maxd = std::max(maxd, q.depth);
