@@ -1,18 +1,24 @@
 // gfx950 (MI355X, CDNA4) kernels of the lifting forward pass.  Written for 64-lane wavefronts and
 // the fp32-input matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD, 157 TFLOP/s
-// chip peak) - the path is compute-bound, 1e-4 parity rules out bf16.
+// chip peak) - the path is compute-bound, and the 1e-4 parity budget rules out
+// plain bf16 (tools/bf16x3_probe.cpp measures the three-term alternative).
 //
-//  r3d_prologue_f32    pointwise, UV input mode only: ray encoding (uv -> [(u-cx)/fx, c*y+s, -s*y+c],
-//                      float64 like the reference's NumPy, lib/camera/camera.py:423-471).
-//  r3d_gemm_enc_f32    first layer of every temporal branch / GlobalInfo with the input encoding
-//                      fused into the operand staging: window gather from a batch or a sliding clip
-//                      (lib/train_val/trainer.py:47-58), positional / temporal differences and
-//                      body-part grouping (lib/model/rie.py:290-357).
-//  r3d_gemm_f32        persistent grouped GEMM + fused epilogue  C = res + lrelu(A W^T + b): every
-//                      Conv1d / Linear of TemporalBlock / FCBlock (rie.py:85-105, :122-135, :159-169)
-//                      with eval BatchNorm folded.
+//  r3d_gemm_f32        persistent grouped GEMM, one launch per level of the plan's DAG.  Tile kinds:
+//                        gemm_tile         C = res + lrelu(A W^T + b): every Conv1d / Linear of TemporalBlock /
+//                                          FCBlock / Embedding (rie.py:85-105, :122-135, :159-169) with eval
+//                                          BatchNorm folded; split-K variants for the small launches;
+//                        gemm_tile<PAIR>   a pyramid level's 3-tap and 1x1 convolutions (rie.py:94-97), the
+//                                          intermediate tile staying in LDS;
+//                        first_level_tile  expand_conv on the gathered input (window gather,
+//                                          lib/train_val/trainer.py:47-58; body-part grouping and the
+//                                          positional / temporal differences of rie.py:290-357 folded into the
+//                                          weights) + the first pyramid level, for 32 output rows.
+//  r3d_gemm_enc_f32    fallback for configurations first_level_tile does not cover (one-level architectures,
+//                      more than 256 channels): expand_conv / GlobalInfo.fc_1 with the gather fused.
 //  r3d_decode_f32      last Linear of the decoders + joint reassembly (rie.py:409-432) + trajectory
 //                      add (lib/train_val/trainer.py:353).
+//  r3d_prologue_f32    pointwise, UV input mode only: ray encoding (uv -> [(u-cx)/fx, c*y+s, -s*y+c],
+//                      float64 like the reference's NumPy, lib/camera/camera.py:423-471).
 #include <hip/hip_runtime.h>
 
 #include "r3d_internal.hpp"

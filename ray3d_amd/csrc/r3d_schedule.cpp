@@ -4,12 +4,14 @@
 // per (problem, column block, row block); a unit of problem p costs ~ K_p/32 K-tiles of MFMA work.
 // Problems whose units are coarse against a workgroup's share (the M = B MLP layers, the top of the
 // conv pyramid) are cut further along K: 32 x 128 or 32 x 64 split-K units (r3d_kernels.hip, KS).
-// With one workgroup per CU the only scheduling freedom is how many units each workgroup gets, so
-// the host cuts the unit sequence into `nwg` contiguous chunks of (nearly) equal cost.  Contiguity
-// keeps a workgroup - and, through the XCD-aware chunk order in the kernel, an XCD - on one
-// problem's weights.  A chunk is then emitted as tiles of at most 6 units (BM <= 192 rows).
-// This replaces the hardware dispatcher's "first free slot" placement, which left the second
-// round of 128x128 tiles one-third occupied (profiles/r01_v0/pmc_table.txt).
+// With one workgroup per CU the only scheduling freedom is which units each workgroup gets: the host packs
+// them into at most `nwg` chunks under the smallest feasible chunk budget (first-fit decreasing inside a
+// binary search; whole units first - consecutive units of a column block in consecutive workgroups, so a
+// workgroup and, through the XCD-aware chunk order in the kernel, an XCD stays on one problem's weights -
+// then the units that found no room, cut along K).  A chunk is emitted as tiles of at most 6 units
+// (BM <= 192 rows; 4 for fused pairs, 1 for the fused first level).  This replaces the hardware
+// dispatcher's "first free slot" placement, which left the second round of 128x128 tiles one-third
+// occupied (profiles/r01_v0/pmc_table.txt).
 #include <algorithm>
 #include <cmath>
 
