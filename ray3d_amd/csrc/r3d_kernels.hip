@@ -468,6 +468,180 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
     R3D_TSTAMP(4);
 }
 
+// ------------------------------------------------------------------------------------ fp32 on the bf16 matrix cores
+//
+// gemm_tile_b3: C = res + lrelu(A W^T + b) like gemm_tile, evaluated by v_mfma_f32_32x32x16_bf16 (16x the FLOP
+// rate of the fp32 MFMA).  Every fp32 operand is split EXACTLY into three bf16 terms, x = x0 + x1 + x2 (each the
+// bf16 rounding of what the previous ones left: 8 + 8 + 8 mantissa bits), and the six products a0b0, a0b1, a1b0,
+// a0b2, a1b1, a2b0 are accumulated in fp32, smallest first; the three dropped products are below 2^-24 of the
+// leading one.  Measured (tools/bf16x3_probe.cpp): the same error against float64 as an fp32 dot product.
+// Weights are split and packed on the host (r3d_model.cpp: [32-col block][K tile][k16 half][term][lane][8]);
+// activations are split when their fp32 staging registers are written to the LDS ring (a few VALU instructions per
+// thread and K tile), which then holds three bf16 planes.  Used for the M = B layers (the FCBlocks' 1024-wide
+// Linears), whose 32-row tiles are bound by the fp32 matrix rate; opt-in (r3d_api.cpp, R3D_BF16X3).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int B3_LD = 20;                  // floats per staged row of one plane: 32 bf16 = 64 B + 16 B pad (conflict-free b128 reads)
+
+__device__ __forceinline__ unsigned b3_pack(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float b3_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float b3_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+template <int MI>
+__device__ __forceinline__ void gemm_tile_b3(ProbRef P, const int row0, const int col0, float *smem, long long *dbg) {
+    R3D_TSTAMP(0);
+    constexpr int VR = MI * 32, NA = (VR + 63) / 64;
+    constexpr int PLANE = VR * B3_LD, SFB = 3 * PLANE;      // floats per plane / per ring stage
+    static_assert(3 * SFB * 4 <= GEMM_LDS_BYTES, "three stages of three planes must fit");
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int M = P.M, K = P.K;
+    const int nk = K / BK;
+    const int srow = tid >> 3, a_kq = (tid & 7) * 4;
+    // ---- A staging (fp32 from HBM, as in gemm_tile)
+    const bool multi = P.kend[0] < K;
+    int seg_ld = P.lda[0], seg_k0 = 0, seg_end = P.kend[0], seg_i = 0;
+    int a_voff[NA];
+    __amdgpu_buffer_rsrc_t arsrc;
+    auto open_seg = [&]() {
+        const float *base = P.a[seg_i] + (size_t)row0 * seg_ld;
+        const long long b = ((long long)(M - 1 - row0) * seg_ld + (seg_end < K ? seg_end : K) - seg_k0) * 4;
+        arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, b < 0x7fffffffLL ? (int)b : 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int gr = row0 + srow + 64 * i;
+            a_voff[i] = (((gr < M ? gr : M - 1) - row0) * seg_ld + a_kq) * 4;
+        }
+    };
+    open_seg();
+    auto prep_seg = [&](int kt) {
+        if (!multi) return;
+        while (kt * BK >= seg_end) {
+            ++seg_i;
+            seg_k0 = seg_end;
+            seg_ld = P.lda[seg_i];
+            seg_end = P.kend[seg_i];
+            open_seg();
+        }
+    };
+    struct Staged { f32x4 a[NA]; };
+    Staged ra, ra2, ra3;
+    auto issue_a = [&](int kt, Staged &R) {
+        const int kb = kt * BK - seg_k0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff[i], kb * 4, 0));
+    };
+    // registers -> ring stage: split into three bf16 planes (exact: each remainder is representable in fp32)
+    const int st_off = srow * B3_LD + (a_kq >> 1);
+    auto commit_a = [&](int stage, const Staged &R) {
+        float *s = smem + stage * SFB + st_off;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (srow + 64 * i >= VR) continue;
+            const f32x4 x = R.a[i];
+            const unsigned h0 = b3_pack(x[0], x[1]), h1 = b3_pack(x[2], x[3]);
+            const float r0 = x[0] - b3_lo(h0), r1 = x[1] - b3_hi(h0), r2 = x[2] - b3_lo(h1), r3 = x[3] - b3_hi(h1);
+            const unsigned m0 = b3_pack(r0, r1), m1 = b3_pack(r2, r3);
+            const unsigned l0 = b3_pack(r0 - b3_lo(m0), r1 - b3_hi(m0)), l1 = b3_pack(r2 - b3_lo(m1), r3 - b3_hi(m1));
+            float *d = s + i * 64 * B3_LD;
+            *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2 *>(d + 2 * PLANE) = make_uint2(l0, l1);
+        }
+    };
+    // ---- W fragments: three pre-split planes, [(n/32)][K tile][k16 half][term][lane][8 bf16]
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short *>(P.wb3 + ((size_t)((col0 >> 5) + wave_u) * nk) * 3072), 0, nk * 6144, 0x00020000);
+    const int w_voff = lane * 16;
+    struct WFrag { bf16x8 f[2][3]; };
+    WFrag wa, wb, wc;                        // three sets rotating: weights run two K tiles ahead (an iteration of
+                                             // a 32-row tile is shorter than an L2 miss)
+    auto load_w = [&](int kt, WFrag &dst) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                dst.f[h][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff + (h * 3 + p) * 1024, kt * 6144, 0));
+    };
+    f32x16 acc[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.0f;
+    const int a_frag = li * B3_LD + lh * 4;      // + h * 8 floats per k16 half, + mi * 32 rows, + plane
+    const int last = nk - 1;
+    load_w(0, wa);
+    load_w(1 < last ? 1 : last, wb);
+    {
+        Staged r0, r1;
+        issue_a(0, r0);
+        prep_seg(1 < last ? 1 : last);
+        issue_a(1 < last ? 1 : last, r1);
+        prep_seg(2 < last ? 2 : last);
+        issue_a(2 < last ? 2 : last, ra);
+        prep_seg(3 < last ? 3 : last);
+        issue_a(3 < last ? 3 : last, ra2);
+        prep_seg(4 < last ? 4 : last);
+        issue_a(4 < last ? 4 : last, ra3);
+        prep_seg(5 < last ? 5 : last);
+        commit_a(0, r0);
+        commit_a(1, r1);
+    }
+    __syncthreads();
+    R3D_TSTAMP(1);
+    int st_cur = 0;
+    auto k_tile = [&](int kt, const WFrag &w_use, WFrag &w_load, Staged &stg) {
+        const int st_next = st_cur == 2 ? 0 : st_cur + 1, st_next2 = st_next == 2 ? 0 : st_next + 1;
+        commit_a(st_next2, stg);                 // tile kt+2
+        load_w(kt + 2 < last ? kt + 2 : last, w_load);
+        issue_a(kt + 5 < last ? kt + 5 : last, stg);
+        prep_seg(kt + 6 < last ? kt + 6 : last);
+        const float *s = smem + st_cur * SFB + a_frag;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 av[MI][3];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    av[mi][p] = *reinterpret_cast<const bf16x8 *>(s + p * PLANE + mi * 32 * B3_LD + h * 8);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][2], w_use.f[h][0], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][1], w_use.f[h][1], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][0], w_use.f[h][2], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][1], w_use.f[h][0], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][0], w_use.f[h][1], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][0], w_use.f[h][0], acc[mi], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        st_cur = st_next;
+    };
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 3) {
+        k_tile(kt, wa, wc, ra);
+        k_tile(kt + 1, wb, wa, ra2);
+        k_tile(kt + 2, wc, wb, ra3);
+    }
+    if (kt < nk) {
+        k_tile(kt, wa, wc, ra);
+        if (kt + 1 < nk) k_tile(kt + 1, wb, wa, ra2);
+    }
+    R3D_TSTAMP(2);
+    R3D_TSTAMP(3);
+    store_tile<MI, 1>(P, acc, row0, col0, smem);
+    R3D_TSTAMP(4);
+}
+
 // ------------------------------------------------------------------------------------ first layers
 //
 // r3d_gemm_enc_f32: expand_conv of every temporal branch and GlobalInfo.fc_1, with the input encoding
@@ -908,6 +1082,15 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
             if (P.w3 != nullptr) {       // first level of the pyramid, fused (32 output rows per tile)
                 if (P.K <= 64) first_level_tile<3>(P, row0, new_prob, smem, dbg);
                 else first_level_tile<1>(P, row0, new_prob, smem, dbg);
+                continue;
+            }
+            if (P.wb3 != nullptr) {      // fp32 on the bf16 matrix cores (whole tiles of <= 128 rows)
+                switch (mi) {
+                    case 1: gemm_tile_b3<1>(P, row0, col0, smem, dbg); break;
+                    case 2: gemm_tile_b3<2>(P, row0, col0, smem, dbg); break;
+                    case 3: gemm_tile_b3<3>(P, row0, col0, smem, dbg); break;
+                    default: gemm_tile_b3<4>(P, row0, col0, smem, dbg); break;
+                }
                 continue;
             }
             if (ks > 1) {

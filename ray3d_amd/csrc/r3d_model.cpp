@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "r3d_internal.hpp"
@@ -79,6 +81,8 @@ struct Grammar {
             tensor(L.weight_key, {n, cin});
         if (bias) tensor(L.bias_key, {n});
         if (!bn_prefix.empty()) bn(bn_prefix, n);
+        // the FCBlocks' wide Linears can also run on the bf16 matrix cores (three-term split, r3d_kernels.hip)
+        L.bf3 = m->use_b3 && !conv && n == MLP_HIDDEN && cin % BK == 0 && cin >= 256;
         m->layer_index[prefix] = (int)m->layers.size();
         m->layers.push_back(L);
         return (int)m->layers.size() - 1;
@@ -143,6 +147,10 @@ Model *model_create(const r3d_config &cfg) {
 
     Model *m = new Model();
     m->cfg = cfg;
+    {
+        const char *e = getenv("R3D_BF16X3");
+        m->use_b3 = e && atoi(e) != 0;
+    }
     if (!emb) m->cfg.extrinsic_dim = m->cfg.embed_dim = 0;
     m->RF = 1;
     for (int i = 0; i < cfg.num_levels; ++i) m->RF *= 3;
@@ -309,6 +317,11 @@ int model_finalize(Model *m) {
         off += (size_t)L.Npad * L.Kpad;
         L.b_off = off;
         off += (size_t)L.Npad;
+        if (L.bf3) {
+            off = (off + 3) / 4 * 4;                       // 16-byte aligned planes
+            L.wb3_off = off;
+            off += (size_t)L.Npad * L.Kpad * 3 / 2;
+        }
     }
     m->arena.assign(off, 0.0f);
     Folder f{m};
@@ -345,6 +358,29 @@ int model_finalize(Model *m) {
         }
         float *bd = m->arena.data() + L.b_off;
         for (int o = 0; o < L.N; ++o) bd[o] = (float)t[o];
+        if (L.bf3) {
+            // the same folded weights as three bf16 terms, w = w0 + w1 + w2 exactly (each term the bf16 rounding of
+            // what the previous ones left), in v_mfma_f32_32x32x16_bf16 B-operand order:
+            // [32-col block][K tile][k16 half][term][lane][8], lane l holding column l % 32, k = 8 * (l / 32) + e
+            auto bf16_rne = [](float x) {
+                uint32_t u; memcpy(&u, &x, 4);
+                return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+            };
+            auto bf16_f = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+            uint16_t *pl16 = reinterpret_cast<uint16_t *>(m->arena.data() + L.wb3_off);
+            for (int o = 0; o < L.N; ++o)
+                for (int k = 0; k < L.K; ++k) {
+                    const float v = (float)((double)w[(size_t)o * L.cin + k] * s[o]);
+                    uint16_t tr[3];
+                    tr[0] = bf16_rne(v);
+                    const float r1 = v - bf16_f(tr[0]);
+                    tr[1] = bf16_rne(r1);
+                    tr[2] = bf16_rne(r1 - bf16_f(tr[1]));
+                    const int nb = o >> 5, kt = k >> 5, kin = k & 31, h = kin >> 4, lane = ((kin & 15) >> 3) * 32 + (o & 31), e = kin & 7;
+                    for (int p3 = 0; p3 < 3; ++p3)
+                        pl16[((((size_t)(nb * nk + kt) * 2 + h) * 3 + p3) * 64 + lane) * 8 + e] = tr[p3];
+                }
+        }
     }
     // ---- upload
     int dev = 0;

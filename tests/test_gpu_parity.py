@@ -316,3 +316,23 @@ def test_rccl_gather_of_clip_partials_single_rank():
         assert np.abs(np.array(evaluate.reduce_partials(gathered)[0]) - ref).max() < 5e-2
     finally:
         dist.destroy_process_group()
+
+
+def test_bf16x3_mode_keeps_parity(monkeypatch):
+    """R3D_BF16X3=1 (read at r3d_create): the FCBlocks' 1024-wide Linears run on the bf16 matrix cores with every
+    fp32 operand split exactly into three bf16 terms (six products, fp32 accumulate).  Same tolerance as fp32."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    from oracle import oracle
+    monkeypatch.setenv("R3D_BF16X3", "1")
+    # (the mode applies to problems of >= 512 rows, i.e. batches of >= 512 windows in these layers: the fixtures'
+    # 4-8 windows would not exercise it, hence the oracle)
+    mc2 = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
+    pos2, trj2, (cp2, sp2), (ct2, st2) = build_modules(mc2)
+    lifter = ray3d_amd.Ray3DLifter(pos2, trj2).eval()
+    xb = synth.synth_rays(600, cp2, seed=41)          # >= B3_MIN_ROWS (512) rows: the mode is active
+    pb = synth.synth_param(600, seed=42)
+    with torch.no_grad():
+        out = lifter(torch.from_numpy(xb).cuda(), torch.from_numpy(pb).cuda()).cpu().numpy()
+    ref = oracle.forward(cp2, sp2, xb, pb) + oracle.forward(ct2, st2, xb, pb)
+    assert np.abs(out - ref).max() <= tol_for(ref)
