@@ -45,6 +45,12 @@ typedef struct {
     int32_t stage;         /* STAGE (pos only; 1 = no FuseBlocks)                       */
     int32_t extrinsic_dim; /* EXTRINSIC_DIM, or 0 when CAMERA_EMBDDING is False         */
     int32_t embed_dim;     /* EMBEDD_DIM (multiple of 32), or 0 when CAMERA_EMBDDING off */
+    int32_t causal;        /* CAUSAL with DISABLE_OPTIMIZATIONS: each level's residual is the
+                            * last of its three input frames instead of the centre one
+                            * (rie.py:43-47,88-92).  CAUSAL with the strided convolutions is
+                            * not a configuration the reference can run (rie.py:94-97 raises);
+                            * DISABLE_OPTIMIZATIONS alone computes the same function for an
+                            * RF-long window and needs no flag.                             */
 } r3d_config;
 
 typedef struct r3d_model r3d_model;

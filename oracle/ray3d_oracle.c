@@ -147,7 +147,8 @@ static void emit(r3o_tap_fn tap, void *user, const char *name, const float *d, i
 
 /* ------------------------------------------------------------------ sub-modules */
 
-/* TemporalBlock.forward (Optimize1f=True, causal=False), lib/model/rie.py:85-105.
+/* TemporalBlock.forward, lib/model/rie.py:85-105, on one RF-long window: the strided (Optimize1f) form; the
+ * dilated form (:91-92) evaluates the same ternary tree, with the residual at the last tap when causal.
  * x: channels-last (B*T, Cin) with T = 3^L.  out: (B, latent). */
 static int temporal_block(store *s, const r3o_config *cfg, const char *prefix, const float *x,
                           int64_t B, int64_t T, int64_t Cin, float *out, r3o_tap_fn tap, void *user) {
@@ -186,9 +187,11 @@ static int temporal_block(store *s, const r3o_config *cfg, const char *prefix, c
         snprintf(tapname, sizeof tapname, "%s.level%d.pre", prefix, 2 * i + 2);
         emit(tap, user, tapname, g, B, Tcur / 3, C, 3);
         leaky(g, rows2 * C, 0.2f);
-        /* res = x[:, :, 1::3] (centre tap of each triple), :94; x = res + ..., :97 */
+        /* res = x[:, :, 1::3] (centre tap of each triple), :94 - or, causal and dilated (:92 with shift == pad),
+         * the last tap; x = res + ..., :97 */
+        const int64_t tapi = cfg->causal ? 2 : 1;
         for (int64_t r = 0; r < rows2; ++r)
-            for (int64_t c = 0; c < C; ++c) g[r * C + c] = cur[(3 * r + 1) * C + c] + g[r * C + c];
+            for (int64_t c = 0; c < C; ++c) g[r * C + c] = cur[(3 * r + tapi) * C + c] + g[r * C + c];
         free(h);
         free(cur);
         cur = g;

@@ -40,6 +40,7 @@ typedef struct {
     int stage;         /* STAGE (pos only) */
     int extrinsic_dim; /* 0 when CAMERA_EMBDDING is False */
     int embed_dim;     /* 0 when CAMERA_EMBDDING is False */
+    int causal;        /* CAUSAL (with the dilated convolutions, the only pairing the reference runs) */
 } r3o_config;
 
 /* Tap sink: called with intermediate tensors (float32, row-major).  Names:

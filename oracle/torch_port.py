@@ -25,11 +25,12 @@ def _bn(x, sd, p):
                         sd[p + ".bias"], training=False, eps=1e-5)
 
 
-def temporal_block(sd: Dict[str, torch.Tensor], p: str, x: torch.Tensor, nlev: int) -> torch.Tensor:
-    """:85-105 with Optimize1f=True, causal=False; x (B, Cin, RF) -> (B, latent)."""
+def temporal_block(sd: Dict[str, torch.Tensor], p: str, x: torch.Tensor, nlev: int, tap: int = 1) -> torch.Tensor:
+    """:85-105 in the strided (Optimize1f) form; x (B, Cin, RF) -> (B, latent).  tap = 1: res is the centre frame
+    (:94); tap = 2: the causal, dilated model's residual (:92 with shift == pad), the last frame of each triple."""
     x = F.leaky_relu(_bn(F.conv1d(x, sd[p + ".expand_conv.weight"], stride=3), sd, p + ".expand_bn"), 0.2)
     for i in range(nlev - 1):
-        res = x[:, :, 1::3]                                                              # :94
+        res = x[:, :, tap::3]                                                            # :94 / :92
         x = F.leaky_relu(_bn(F.conv1d(x, sd["%s.layers_conv.%d.weight" % (p, 2 * i)], stride=3),
                              sd, "%s.layers_bn.%d" % (p, 2 * i)), 0.2)                   # :96
         x = res + F.leaky_relu(_bn(F.conv1d(x, sd["%s.layers_conv.%d.weight" % (p, 2 * i + 1)]),
@@ -78,14 +79,15 @@ def forward(cfg: LiftConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor,
     x_global = fc_block(sd, "GlobalInfo", in_current, 2)
     emb = embedding(sd, "embedder", param) if cfg.camera_embedding else None
     if cfg.kind == "trj":
-        local = temporal_block(sd, "LocalLayer", torch.cat((xc, diff, diff_t), dim=1), L)       # :540-546
+        local = temporal_block(sd, "LocalLayer", torch.cat((xc, diff, diff_t), dim=1), L, cfg.residual_tap)       # :540-546
         feats = [local, x_global] + ([emb] if emb is not None else [])
         return fc_block(sd, "Integration", torch.cat(feats, dim=1), 1).view(B, 1, 1, 3)
     locals_ = []
     for b in BRANCHES:                                                                            # :306-369
         idx = _rows(GROUPS[J][b], Fd)
         locals_.append(temporal_block(sd, "LocalLayer_" + b,
-                                      torch.cat((xc[:, idx], diff[:, idx], diff_t[:, idx]), dim=1), L))
+                                      torch.cat((xc[:, idx], diff[:, idx], diff_t[:, idx]), dim=1), L,
+                                      cfg.residual_tap))
     dec = {}
     for i, b in enumerate(BRANCHES):
         feats = [locals_[i]]

@@ -197,7 +197,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
                 g.enc_jf = JF;
                 g.enc_cur = (a->RF / a->cfg.in_features) * JF;   // quirk Q1: "current" frame is RF // in_features
                 g.enc_bytes = (unsigned)((size_t)frames * JF * sizeof(float));
-                g.enc_cur_rel = 0;
+                g.res_tap = 1 + m->cfg.causal;
             }
             g.w = m->d_arena + L.w_off;
             // (below B3_MIN_ROWS rows the tiles are single units, whose bound is the weight stream, not the matrix rate)

@@ -58,7 +58,7 @@ struct GemmProb {
     int enc_jf;               // J*F
     int enc_cur;              // element offset of the "current" frame inside a window (tcur * J*F)
     unsigned enc_bytes;       // size of the raw input in bytes (buffer-descriptor bound)
-    int enc_cur_rel;          // (unused: per-chunk flags in the table say which base a column uses)
+    int res_tap;              // fused first level: which frame of a triple is the residual (1 centre, 2 causal)
     int pad2_;
 };
 

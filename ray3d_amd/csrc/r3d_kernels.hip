@@ -789,7 +789,8 @@ __device__ __forceinline__ void enc_tile(ProbRef P, const int row0, const int co
 //   2. expand_conv: MFMA loop per pass, activations -> H0 [96 x C] in MFMA operand order;
 //   3. the 3-tap convolution: output row r reads H0 rows 3r..3r+2 as one K = 3C operand row; barrier-free loop,
 //      weights streaming; activations -> H1 [32 x C];
-//   4. the 1x1 convolution on H1; epilogue: + H0 row 3r+1 (the centre tap: rie.py:94), rows stored 1 KiB wide.
+//   4. the 1x1 convolution on H1; epilogue: + H0 row 3r+1 (the centre tap: rie.py:94; 3r+2 for causal models,
+//      rie.py:92), rows stored 1 KiB wide.
 constexpr int FL_H0_FLOATS = 96 * PAIR_LD;                 // 24,960
 constexpr int FL_R2_FLOATS = 32 * PAIR_LD;                 //  8,320: gather tile / H1 / epilogue rows
 constexpr int FL_LUT_OFF = FL_H0_FLOATS + FL_R2_FLOATS;
@@ -1003,12 +1004,12 @@ __device__ __forceinline__ void first_level_tile(ProbRef P, const int row0, cons
         }
     }
     R3D_TSTAMP(3);
-    // ---- epilogue: + centre expand_conv row (still in H0), rows transposed through the second region
+    // ---- epilogue: + centre (causal: last) expand_conv row (still in H0), rows transposed through the second region
     {
         const float bias2 = gload1(P.bias3 + wave * 32 + li), slope2 = P.slope3;
         __syncthreads();                                     // every wavefront is done reading H1
         float *wr = r2 + (4 * lh) * PAIR_LD + wave * 32 + li;
-        const float *rs = h0 + (3 * (4 * lh) + 1) * PAIR_LD + wave * 32 + li;
+        const float *rs = h0 + (3 * (4 * lh) + P.res_tap) * PAIR_LD + wave * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int lr = (r & 3) + 8 * (r >> 2);

@@ -144,6 +144,7 @@ Model *model_create(const r3d_config &cfg) {
         return nullptr;
     }
     if (cfg.kind == R3D_KIND_POS && cfg.stage < 1) { set_error("stage must be >= 1"); return nullptr; }
+    if (cfg.causal != 0 && cfg.causal != 1) { set_error("causal must be 0 or 1 (got %d)", cfg.causal); return nullptr; }
 
     Model *m = new Model();
     m->cfg = cfg;

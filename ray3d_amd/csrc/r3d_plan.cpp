@@ -126,15 +126,17 @@ struct Builder {
             const std::string a = br.prefix + ".layers_conv." + std::to_string(2 * (i - 1));
             const std::string b = br.prefix + ".layers_conv." + std::to_string(2 * (i - 1) + 1);
             // three consecutive frames of the previous level form one GEMM row (stride == kernel);
-            // res = x[:, :, 1::3] is the centre third of that row (rie.py:94)
+            // res = x[:, :, 1::3] is the centre third of that row (rie.py:94); the last third for causal models
+            // (rie.py:92 with shift == pad)
+            const int rc = (1 + m.cfg.causal) * C;
             if (fuse(rows)) {
-                last = problem(a, rows, {{src, 0, 3 * C, 3 * C, last}}, src, C, 3 * C, dst, 0, C);
+                last = problem(a, rows, {{src, 0, 3 * C, 3 * C, last}}, src, rc, 3 * C, dst, 0, C);
                 ProbSpec &q = p.probs[last];
                 q.layer2 = m.layer_index.at(b);
                 q.flops_per_window += 2.0 * rows * (double)C * (double)C;
             } else {
                 const int pa = problem(a, rows, {{src, 0, 3 * C, 3 * C, last}}, -1, 0, 0, hb, 0, C);
-                last = problem(b, rows, {{hb, 0, C, C, pa}}, src, C, 3 * C, dst, 0, C, {last});
+                last = problem(b, rows, {{hb, 0, C, C, pa}}, src, rc, 3 * C, dst, 0, C, {last});
             }
         }
         const int fin = pp[(L - 1) & 1];

@@ -39,9 +39,11 @@ class Clip:
     clip_id: int = 0
 
 
-def pad_clip(rays: np.ndarray, pad: int) -> np.ndarray:
-    """np.pad(seq, ((pad, pad), (0,0), (0,0)), 'edge') - generators.py:213-216 with causal_shift 0."""
-    return np.concatenate([np.repeat(rays[:1], pad, axis=0), rays, np.repeat(rays[-1:], pad, axis=0)], axis=0)
+def pad_clip(rays: np.ndarray, pad: int, causal_shift: int = 0) -> np.ndarray:
+    """np.pad(seq, ((pad + shift, pad - shift), (0,0), (0,0)), 'edge') - generators.py:213-216;
+    shift = pad for CAUSAL models (main.py:85-89: the window then ends at the frame it predicts)."""
+    return np.concatenate([np.repeat(rays[:1], pad + causal_shift, axis=0), rays,
+                           np.repeat(rays[-1:], pad - causal_shift, axis=0)], axis=0)
 
 
 def mirror_input(clip: torch.Tensor, kps_left: Sequence[int], kps_right: Sequence[int]) -> torch.Tensor:
@@ -61,11 +63,11 @@ def mirror_output(pred: torch.Tensor, joints_left: Sequence[int], joints_right: 
 
 
 def predict_clip(lift_clip: Callable, clip: Clip, rf: int, device, flip: bool = False,
-                 kps_left: Sequence[int] = (), kps_right: Sequence[int] = ()) -> torch.Tensor:
+                 kps_left: Sequence[int] = (), kps_right: Sequence[int] = (), causal: bool = False) -> torch.Tensor:
     """(N,1,J,3) absolute poses in the normalised frame for one clip.
     `lift_clip(padded (N+RF-1,J,F) tensor, param_row (E,) tensor) -> (N,1,J,3)`."""
     pad = (rf - 1) // 2
-    padded = torch.from_numpy(pad_clip(np.asarray(clip.rays, dtype=np.float32), pad)).to(device)
+    padded = torch.from_numpy(pad_clip(np.asarray(clip.rays, dtype=np.float32), pad, pad if causal else 0)).to(device)
     prow = torch.from_numpy(clip.camera.param()).to(device)
     pred = lift_clip(padded, prow)
     if flip:
@@ -138,8 +140,9 @@ def gather_partials(local_rows: torch.Tensor, counts: Sequence[int], group=None)
 
 def evaluate_clips(lift_clip: Callable, clips: Sequence[Clip], rf: int, device, flip: bool = False,
                    kps_left: Sequence[int] = (), kps_right: Sequence[int] = (),
-                   rank: int = 0, world_size: int = 1, group=None):
-    """Evaluate `clips` (sharded over `world_size` ranks when > 1).  Every rank returns
+                   rank: int = 0, world_size: int = 1, group=None, causal: bool = False):
+    """Evaluate `clips` (sharded over `world_size` ranks when > 1; `causal`: pad as main.py:85-89 does for
+    CAUSAL models).  Every rank returns
     (per_action {name: (e1,e2,e3,ev,er) mm}, action-wise average, gathered partial rows)."""
     actions = sorted(set(c.action for c in clips))
     aid = {a: i for i, a in enumerate(actions)}
@@ -147,7 +150,7 @@ def evaluate_clips(lift_clip: Callable, clips: Sequence[Clip], rf: int, device, 
     rows = []
     for idx in shards[rank]:
         c = clips[idx]
-        pred = predict_clip(lift_clip, c, rf, device, flip, kps_left, kps_right)
+        pred = predict_clip(lift_clip, c, rf, device, flip, kps_left, kps_right, causal)
         rows.append(clip_partials(pred, Clip(c.camera, c.rays, c.gt_norm, c.action, idx), aid[c.action]))
     local = torch.stack(rows) if rows else torch.zeros((0, PARTIAL_COLS), dtype=torch.float64, device=device)
     if world_size > 1:

@@ -79,9 +79,23 @@ class LiftConfig:
             # every shipped cfg uses width-3 filters; the ternary-tree kernels rely on it
             raise NotImplementedError("only ARCHITECTURE made of 3s is supported, got %r"
                                       % (self.filter_widths,))
-        if self.causal or self.dense or not self.optimize1f:
-            raise NotImplementedError("CAUSAL / DENSE / DISABLE_OPTIMIZATIONS variants are out of "
-                                      "scope (SURVEY.md section 8f item 4)")
+        if self.dense:
+            # dense=True swaps the dilated 3-tap convolutions for (2*pad+1)-tap ones (rie.py:49-53):
+            # a different network (ablation only, no shipped cfg), not a variant of this path
+            raise NotImplementedError("DENSE=True (dense-convolution ablation, rie.py:49-53) is out of scope")
+        if self.causal and self.optimize1f:
+            # the reference itself cannot run this pair: rie.py:94 slices the residual with the
+            # dilated causal_shift of :47 and the add at :97 fails on mismatched lengths
+            raise NotImplementedError("CAUSAL=True needs DISABLE_OPTIMIZATIONS=True: with the strided "
+                                      "(Optimize1f) convolutions the reference forward raises at rie.py:97")
+
+    @property
+    def residual_tap(self) -> int:
+        """Which of a level's three input frames is the residual (rie.py:88-94): the centre one, or -
+        CAUSAL with the dilated convolutions, res = x[:, :, pad+shift : T-pad+shift], shift == pad -
+        the last one.  DISABLE_OPTIMIZATIONS alone changes nothing for an RF-long window: the dilated
+        stack evaluates the same ternary tree as the strided one."""
+        return 2 if self.causal else 1
 
     @property
     def camera_embedding(self) -> bool:

@@ -55,6 +55,9 @@ CASES = {
     "j15_rf9_s3": (dict(ARCHITECTURE="3,3", NUM_KPTS=15), 3, 1.0),
     "j17_f2_rf27_noemb_s3": (dict(ARCHITECTURE="3,3,3", INPUT_DIM=2, CAMERA_EMBDDING=False), 3, 1.0),
     "j17_rf81_s2_big": (dict(ARCHITECTURE="3,3,3,3", STAGE=2), 2, 8.0),
+    # the dilated (non-Optimize1f) convolutions on RF-long windows, plain and causal (rie.py:91-92)
+    "j17_rf27_dilated_s3": (dict(ARCHITECTURE="3,3,3", DISABLE_OPTIMIZATIONS=True), 3, 1.0),
+    "j17_rf81_causal_s3": (dict(ARCHITECTURE="3,3,3,3", DISABLE_OPTIMIZATIONS=True, CAUSAL=True), 3, 1.0),
 }
 
 
@@ -82,8 +85,10 @@ def run_with_taps(module, x, p, tap_names):
     return out, taps
 
 
-def gen_models():
+def gen_models(only=None):
     for name, (over, batch, out_scale) in CASES.items():
+        if only and name not in only:
+            continue
         mc = default_model_config(**over)
         ref = RefModel(mc, {}, is_train=False)
         pos, trj = ref.get_pos_model(), ref.get_trj_model()
@@ -100,10 +105,14 @@ def gen_models():
         if cpos.camera_embedding:
             pos_taps += ["embedder"]
         # per-level pre-activation BN outputs, Torso only (clone happens before inplace LeakyReLU)
-        pos_taps += ["LocalLayer_Torso.expand_bn"] + ["LocalLayer_Torso.layers_bn.%d" % i
-                                                     for i in range(2 * (nlev - 1))]
-        trj_taps = ["LocalLayer", "GlobalInfo", "Integration", "LocalLayer.expand_bn"] + \
-                   ["LocalLayer.layers_bn.%d" % i for i in range(2 * (nlev - 1))]
+        # (the dilated form keeps every frame of every level: its per-level tensors are not the strided ones)
+        per_level = not mc["DISABLE_OPTIMIZATIONS"]
+        if per_level:
+            pos_taps += ["LocalLayer_Torso.expand_bn"] + ["LocalLayer_Torso.layers_bn.%d" % i
+                                                         for i in range(2 * (nlev - 1))]
+        trj_taps = ["LocalLayer", "GlobalInfo", "Integration"]
+        if per_level:
+            trj_taps += ["LocalLayer.expand_bn"] + ["LocalLayer.layers_bn.%d" % i for i in range(2 * (nlev - 1))]
         if ctrj.camera_embedding:
             trj_taps += ["embedder"]
         out_pos, tp = run_with_taps(pos, x, p, pos_taps)
@@ -253,6 +262,9 @@ def gen_losses():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                      # python make_golden.py <case> ...: only those model cases
+        gen_models(only=set(sys.argv[1:]))
+        sys.exit(0)
     gen_cameras()
     gen_losses()
     gen_models()

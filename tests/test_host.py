@@ -61,9 +61,16 @@ def test_create_rejects_unsupported_configs():
     for over in (dict(NUM_KPTS=16), dict(INPUT_DIM=4), dict(CHANNELS=250)):
         with pytest.raises((ValueError, _capi.Ray3DHipError)):
             _capi.Handle(config_from_dicts(default_model_config(**over), "pos"))
-    for over in (dict(CAUSAL=True), dict(DENSE=True), dict(DISABLE_OPTIMIZATIONS=True), dict(ARCHITECTURE="3,5")):
+    # CAUSAL with the strided convolutions is the pairing the reference's own forward raises on (rie.py:94-97)
+    for over in (dict(CAUSAL=True), dict(DENSE=True), dict(DENSE=True, DISABLE_OPTIMIZATIONS=True),
+                 dict(ARCHITECTURE="3,5")):
         with pytest.raises(NotImplementedError):
             config_from_dicts(default_model_config(**over), "pos")
+    assert config_from_dicts(default_model_config(DISABLE_OPTIMIZATIONS=True), "pos").residual_tap == 1
+    assert config_from_dicts(default_model_config(DISABLE_OPTIMIZATIONS=True, CAUSAL=True), "trj").residual_tap == 2
+    bad = _capi.Config(0, 17, 3, 2, 256, 256, 3, 2, 64, 7)
+    with pytest.raises(_capi.Ray3DHipError, match="causal"):
+        _capi.check(_capi.load().r3d_create(_capi.C.byref(bad), _capi.C.byref(_capi.C.c_void_p())), "r3d_create")
 
 
 def test_forward_before_finalize_fails():
@@ -236,6 +243,7 @@ def test_evaluate_reproduces_reference_evaluate_core(flip):
 def test_pad_clip_is_edge_padding():
     a = np.arange(24, dtype=np.float32).reshape(4, 2, 3)
     assert np.array_equal(evaluate.pad_clip(a, 3), np.pad(a, ((3, 3), (0, 0), (0, 0)), "edge"))
+    assert np.array_equal(evaluate.pad_clip(a, 3, 3), np.pad(a, ((6, 0), (0, 0), (0, 0)), "edge"))   # causal
 
 
 def test_shard_clips_partitions_and_balances():

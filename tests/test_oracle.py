@@ -37,7 +37,7 @@ def test_c_oracle_matches_reference(name):
                 o = _tap_from_oracle(taps, k.split("/", 1)[1]).reshape(r.shape)
                 assert np.abs(o - r).max() <= 5e-5 * max(1.0, np.abs(r).max()), k
                 checked += 1
-        assert checked >= 5
+        assert checked >= (5 if not mc["DISABLE_OPTIMIZATIONS"] else 4)
     assert int(z["receptive_field"]) == cfg.receptive_field
 
 
