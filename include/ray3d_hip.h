@@ -131,6 +131,30 @@ typedef struct {
 int r3d_profile_enable(r3d_model *m, int on);
 int r3d_profile_read(r3d_model *m, r3d_launch_record *records, int capacity);
 
+/* ---- per-clip error sums: the host side of Trainer.evaluate_core after the forward ---- */
+
+/* lib/train_val/trainer.py:355-397 for one clip: prediction and ground truth (float32, (n_frames, J, 3), normalised
+ * frame, device memory) go to world coordinates in float64 (camera.py:401-410: p @ Rn2w^T + Tn2w^T; `rn2w` is the
+ * row-major 3x3 Rn2w, `tn2w` its translation, host pointers), then
+ *   out[R3D_METRIC_MPJPE]    = sum over frames of mean_j |pred - gt|                (loss.py:12-18,  trainer.py:386)
+ *   out[R3D_METRIC_PMPJPE]   = ... after the per-frame similarity (Procrustes) fit  (loss.py:30-69,  :393)
+ *   out[R3D_METRIC_NMPJPE]   = ... after the per-frame scale fit                    (loss.py:72-82,  :388)
+ *   out[R3D_METRIC_VELOCITY] = n_frames * mean |first difference of the error|      (loss.py:95-104, :395; NaN if n < 2)
+ *   out[R3D_METRIC_ROOT]     = sum over frames of |pred - gt| of joint 0                             (:387)
+ * i.e. the clip's contribution to each epoch_loss_* accumulator, in metres.  `out_dev` is device memory of
+ * R3D_METRIC_OUT_DOUBLES doubles: the five sums first, the rest is scratch for the workgroups' partial sums.
+ * Deterministic (fixed summation order); enqueued on `stream`, no synchronisation. */
+#define R3D_METRIC_MPJPE 0
+#define R3D_METRIC_PMPJPE 1
+#define R3D_METRIC_NMPJPE 2
+#define R3D_METRIC_VELOCITY 3
+#define R3D_METRIC_ROOT 4
+#define R3D_METRIC_COUNT 5
+#define R3D_METRIC_MAX_BLOCKS 128
+#define R3D_METRIC_OUT_DOUBLES (R3D_METRIC_COUNT * (1 + R3D_METRIC_MAX_BLOCKS))
+int r3d_clip_metrics(const float *pred_dev, const float *gt_dev, int64_t n_frames, int32_t num_joints,
+                     const double *rn2w, const double *tn2w, double *out_dev, void *stream);
+
 const char *r3d_last_error(void);
 const char *r3d_version(void);
 

@@ -19,8 +19,10 @@ R3D_INPUT_RAYS, R3D_INPUT_UV = 0, 1
 EXPORTS = (
     "r3d_create", "r3d_destroy", "r3d_num_weights", "r3d_weight_key", "r3d_weight_shape",
     "r3d_set_weight", "r3d_finalize", "r3d_workspace_bytes", "r3d_forward", "r3d_forward_pair",
-    "r3d_profile_enable", "r3d_profile_read", "r3d_last_error", "r3d_version",
+    "r3d_profile_enable", "r3d_profile_read", "r3d_clip_metrics", "r3d_last_error", "r3d_version",
 )
+METRIC_NAMES = ("mpjpe", "p_mpjpe", "n_mpjpe", "velocity", "root")     # R3D_METRIC_* order
+METRIC_OUT_DOUBLES = 5 * (1 + 128)                                      # R3D_METRIC_OUT_DOUBLES
 
 
 class Config(C.Structure):
@@ -72,6 +74,7 @@ def load():
     lib.r3d_forward_pair.argtypes = [vp, vp, C.POINTER(Input), C.c_int64, vp, vp, vp, C.c_size_t, vp]
     lib.r3d_profile_enable.argtypes = [vp, C.c_int]
     lib.r3d_profile_read.argtypes = [vp, C.POINTER(LaunchRecord), C.c_int]
+    lib.r3d_clip_metrics.argtypes = [vp, vp, C.c_int64, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp, vp]
     lib.r3d_last_error.restype = C.c_char_p
     lib.r3d_version.restype = C.c_char_p
     for name in EXPORTS:
@@ -152,6 +155,13 @@ def make_input(mode, x_ptr, window_stride, param_ptr, param_stride, cam_ptr=None
 def forward(handle: Handle, inp: Input, batch: int, out_ptr: int, ws_ptr: int, ws_bytes: int, stream: int):
     check(load().r3d_forward(handle.ptr, C.byref(inp), batch, out_ptr, ws_ptr, ws_bytes, stream),
           "r3d_forward")
+
+
+def clip_metrics(pred_ptr: int, gt_ptr: int, n_frames: int, num_joints: int, rn2w, tn2w, out_ptr: int, stream: int):
+    """r3d_clip_metrics: rn2w (3,3) / tn2w (3,) float64 array-likes on the host; the rest device pointers."""
+    r = (C.c_double * 9)(*[float(v) for row in rn2w for v in row])
+    t = (C.c_double * 3)(*[float(v) for v in tn2w])
+    check(load().r3d_clip_metrics(pred_ptr, gt_ptr, n_frames, num_joints, r, t, out_ptr, stream), "r3d_clip_metrics")
 
 
 def forward_pair(pos: Handle, trj: Handle, inp: Input, batch: int, out_ptr: int,

@@ -401,6 +401,18 @@ int r3d_debug_schedule_check(int nprob, const int *M, const int *N, const int *n
     return 0;
 }
 
+int r3d_clip_metrics(const float *pred_dev, const float *gt_dev, int64_t n_frames, int32_t num_joints,
+                     const double *rn2w, const double *tn2w, double *out_dev, void *stream) {
+    if (!pred_dev || !gt_dev || !rn2w || !tn2w || !out_dev) { r3d::set_error("r3d_clip_metrics: null pointer"); return R3D_ERR_ARG; }
+    if (n_frames < 1) { r3d::set_error("r3d_clip_metrics: n_frames must be >= 1 (got %lld)", (long long)n_frames); return R3D_ERR_ARG; }
+    if (num_joints < 1 || num_joints > 17) { r3d::set_error("r3d_clip_metrics: num_joints must be in 1..17 (got %d)", num_joints); return R3D_ERR_ARG; }
+    if (r3d::launch_clip_metrics(pred_dev, gt_dev, n_frames, num_joints, rn2w, tn2w, out_dev, (hipStream_t)stream)) {
+        r3d::set_error("r3d_clip_metrics: launch failed: %s", hipGetErrorString(hipGetLastError()));
+        return R3D_ERR_HIP;
+    }
+    return 0;
+}
+
 const char *r3d_last_error(void) { return r3d::last_error(); }
 const char *r3d_version(void) { return "ray3d_hip 0.1 (gfx950)"; }
 

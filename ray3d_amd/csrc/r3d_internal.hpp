@@ -284,4 +284,7 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // ENC_INVALID pushes the address past the buffer descriptor's bound: the load returns 0.
 constexpr int ENC_INVALID = (int)0x80000000u;
 
+int launch_clip_metrics(const float *pred, const float *gt, long long n, int J, const double *Rn2w, const double *Tn2w,
+                        double *out, hipStream_t stream);
+
 }  // namespace r3d

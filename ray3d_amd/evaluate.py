@@ -76,8 +76,30 @@ def predict_clip(lift_clip: Callable, clip: Clip, rf: int, device, flip: bool = 
     return pred
 
 
+def clip_partials_hip(pred_norm: torch.Tensor, clip: Clip, action_id: int = 0) -> torch.Tensor:
+    """clip_partials on the GPU through r3d_clip_metrics: world transform, the five error sums and the per-frame
+    Procrustes fits in one float64 kernel on the current stream - no D2H copy of the predictions."""
+    from . import _capi
+    dev = pred_norm.device
+    n = pred_norm.shape[0]
+    pred = pred_norm.reshape(n, -1, 3).contiguous().float()
+    gt = torch.from_numpy(np.ascontiguousarray(clip.gt_norm, dtype=np.float32)).to(dev, non_blocking=True).reshape(n, -1, 3)
+    assert gt.shape == pred.shape, "ground truth %s vs prediction %s" % (tuple(gt.shape), tuple(pred.shape))
+    sums = torch.empty(_capi.METRIC_OUT_DOUBLES, dtype=torch.float64, device=dev)
+    _capi.clip_metrics(pred.data_ptr(), gt.data_ptr(), n, pred.shape[1], np.asarray(clip.camera.Rn2w, dtype=np.float64),
+                       np.asarray(clip.camera.Tn2w, dtype=np.float64).reshape(3), sums.data_ptr(),
+                       torch.cuda.current_stream(dev).cuda_stream)
+    row = torch.empty(PARTIAL_COLS, dtype=torch.float64, device=dev)
+    row[:3] = torch.tensor([clip.clip_id, action_id, n], dtype=torch.float64)
+    row[3:8] = sums[:5]               # R3D_METRIC_* order == columns 3..7 (mpjpe, p-mpjpe, n-mpjpe, velocity, root)
+    return row
+
+
 def clip_partials(pred_norm: torch.Tensor, clip: Clip, action_id: int = 0) -> torch.Tensor:
-    """One PARTIAL_COLS row (float64, on pred's device): N-weighted error sums in metres."""
+    """One PARTIAL_COLS row (float64, on pred's device): N-weighted error sums in metres.  Predictions on a GPU
+    go through the HIP kernel; CPU tensors (host-logic tests with a stand-in lifter) through torch."""
+    if pred_norm.is_cuda:
+        return clip_partials_hip(pred_norm, clip, action_id)
     dev = pred_norm.device
     n = pred_norm.shape[0]
     R = torch.from_numpy(clip.camera.Rn2w.T.copy()).to(dev)

@@ -336,3 +336,71 @@ def test_bf16x3_mode_keeps_parity(monkeypatch):
         out = lifter(torch.from_numpy(xb).cuda(), torch.from_numpy(pb).cuda()).cpu().numpy()
     ref = oracle.forward(cp2, sp2, xb, pb) + oracle.forward(ct2, st2, xb, pb)
     assert np.abs(out - ref).max() <= tol_for(ref)
+
+
+# ---------------------------------------------------------------- per-clip error sums on the device
+
+def _metric_sums_hip(pred, gt, R, T):
+    from ray3d_amd import _capi
+    p = torch.from_numpy(np.ascontiguousarray(pred, dtype=np.float32)).cuda()
+    g = torch.from_numpy(np.ascontiguousarray(gt, dtype=np.float32)).cuda()
+    out = torch.full((_capi.METRIC_OUT_DOUBLES,), -1.0, dtype=torch.float64, device="cuda")
+    _capi.clip_metrics(p.data_ptr(), g.data_ptr(), p.shape[0], p.shape[1], R, T, out.data_ptr(),
+                       torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return out[:5].cpu().numpy()
+
+
+def _metric_sums_oracle(pred, gt, R, T):
+    from oracle import metrics_oracle as mo
+    pw = np.asarray(pred, np.float32).astype(np.float64) @ R.T + T.reshape(1, 1, 3)
+    gw = np.asarray(gt, np.float32).astype(np.float64) @ R.T + T.reshape(1, 1, 3)
+    n = pw.shape[0]
+    vel = n * mo.mean_velocity_error(pw, gw) if n > 1 else float("nan")
+    return np.array([n * mo.mpjpe(pw, gw), n * mo.p_mpjpe(pw, gw), n * mo.n_mpjpe(pw[:, None], gw[:, None]), vel,
+                     n * mo.mpjpe(pw[:, :1], gw[:, :1])])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,J", [(1, 17), (2, 17), (300, 17), (5000, 17), (40000, 14), (777, 15)])
+def test_clip_metrics_kernel_matches_oracle(n, J):
+    """r3d_clip_metrics vs the NumPy restatement of lib/loss/loss.py (pinned to the reference by losses.npz)."""
+    rng = np.random.default_rng(n + J)
+    gt = rng.normal(0, 0.4, (n, J, 3)).astype(np.float32) + np.array([0, 0, 1.0], np.float32)
+    pred = gt + rng.normal(0, 0.05, (n, J, 3)).astype(np.float32)
+    if n >= 300:
+        pred[7] = gt[7] * np.array([-1, 1, 1], np.float32)          # a mirrored pose: the fit must not reflect
+        pred[11] = gt[11]                                            # exact prediction: zero error, no NaN
+        gt[13, :, 2] = 1.0                                           # planar ground truth: rank-2 correlation
+        pred[13, :, 2] = 1.0
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    R, T = q * np.sign(np.linalg.det(q)), rng.normal(size=3)
+    got, want = _metric_sums_hip(pred, gt, R, T), _metric_sums_oracle(pred, gt, R, T)
+    if n == 1:
+        assert np.isnan(got[3]) and np.isnan(want[3])
+        got, want = np.delete(got, 3), np.delete(want, 3)
+    assert np.all(np.isfinite(got))
+    assert np.abs(got - want).max() <= 1e-9 * max(1.0, np.abs(want).max()), (got, want)
+    again = _metric_sums_hip(pred, gt, R, T)
+    assert np.array_equal(np.delete(again, 3) if n == 1 else again, got)      # fixed summation order
+
+
+@pytest.mark.gpu
+def test_clip_metrics_known_answers_and_errors():
+    import os
+    from conftest import GOLDEN
+    from ray3d_amd import _capi
+    z = np.load(os.path.join(GOLDEN, "losses.npz"))            # values computed by the reference's lib/loss/loss.py
+    a, b = z["pred"].reshape(-1, 17, 3), z["target"].reshape(-1, 17, 3)
+    n = a.shape[0]
+    got = _metric_sums_hip(a, b, np.eye(3), np.zeros(3))
+    # the fixture's inputs are float64; the kernel takes the model's float32 outputs
+    assert abs(got[0] / n - float(z["mpjpe"])) < 1e-6
+    assert abs(got[1] / n - float(z["p_mpjpe"])) < 1e-6
+    assert abs(got[2] / n - float(z["n_mpjpe"])) < 1e-6
+    assert abs(got[3] / n - float(z["mpjve"])) < 1e-6
+    t = torch.zeros(_capi.METRIC_OUT_DOUBLES, dtype=torch.float64, device="cuda")
+    with pytest.raises(_capi.Ray3DHipError, match="num_joints"):
+        _capi.clip_metrics(t.data_ptr(), t.data_ptr(), 4, 18, np.eye(3), np.zeros(3), t.data_ptr(), 0)
+    with pytest.raises(_capi.Ray3DHipError, match="n_frames"):
+        _capi.clip_metrics(t.data_ptr(), t.data_ptr(), 0, 17, np.eye(3), np.zeros(3), t.data_ptr(), 0)
