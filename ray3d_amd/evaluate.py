@@ -63,7 +63,8 @@ def mirror_output(pred: torch.Tensor, joints_left: Sequence[int], joints_right: 
 
 
 def predict_clip(lift_clip: Callable, clip: Clip, rf: int, device, flip: bool = False,
-                 kps_left: Sequence[int] = (), kps_right: Sequence[int] = (), causal: bool = False) -> torch.Tensor:
+                 kps_left: Sequence[int] = (), kps_right: Sequence[int] = (), causal: bool = False,
+                 joints_left: Optional[Sequence[int]] = None, joints_right: Optional[Sequence[int]] = None) -> torch.Tensor:
     """(N,1,J,3) absolute poses in the normalised frame for one clip.
     `lift_clip(padded (N+RF-1,J,F) tensor, param_row (E,) tensor) -> (N,1,J,3)`."""
     pad = (rf - 1) // 2
@@ -72,7 +73,8 @@ def predict_clip(lift_clip: Callable, clip: Clip, rf: int, device, flip: bool = 
     pred = lift_clip(padded, prow)
     if flip:
         pred_m = lift_clip(mirror_input(padded, kps_left, kps_right), prow)
-        pred = 0.5 * (pred + mirror_output(pred_m, kps_left, kps_right))
+        pred = 0.5 * (pred + mirror_output(pred_m, kps_left if joints_left is None else joints_left,
+                                           kps_right if joints_right is None else joints_right))
     return pred
 
 
@@ -162,7 +164,8 @@ def gather_partials(local_rows: torch.Tensor, counts: Sequence[int], group=None)
 
 def evaluate_clips(lift_clip: Callable, clips: Sequence[Clip], rf: int, device, flip: bool = False,
                    kps_left: Sequence[int] = (), kps_right: Sequence[int] = (),
-                   rank: int = 0, world_size: int = 1, group=None, causal: bool = False):
+                   rank: int = 0, world_size: int = 1, group=None, causal: bool = False,
+                   joints_left: Optional[Sequence[int]] = None, joints_right: Optional[Sequence[int]] = None):
     """Evaluate `clips` (sharded over `world_size` ranks when > 1; `causal`: pad as main.py:85-89 does for
     CAUSAL models).  Every rank returns
     (per_action {name: (e1,e2,e3,ev,er) mm}, action-wise average, gathered partial rows)."""
@@ -172,7 +175,7 @@ def evaluate_clips(lift_clip: Callable, clips: Sequence[Clip], rf: int, device, 
     rows = []
     for idx in shards[rank]:
         c = clips[idx]
-        pred = predict_clip(lift_clip, c, rf, device, flip, kps_left, kps_right, causal)
+        pred = predict_clip(lift_clip, c, rf, device, flip, kps_left, kps_right, causal, joints_left, joints_right)
         rows.append(clip_partials(pred, Clip(c.camera, c.rays, c.gt_norm, c.action, idx), aid[c.action]))
     local = torch.stack(rows) if rows else torch.zeros((0, PARTIAL_COLS), dtype=torch.float64, device=device)
     if world_size > 1:
@@ -182,3 +185,19 @@ def evaluate_clips(lift_clip: Callable, clips: Sequence[Clip], rf: int, device, 
     per = reduce_partials(allrows)
     named = {actions[a]: v for a, v in per.items()}
     return named, action_average(per), allrows
+
+
+def format_report(named: Dict[str, tuple], average: tuple) -> List[str]:
+    """The lines Trainer.evaluate logs (lib/train_val/trainer.py:459-477): per action, then the action-wise
+    averages rounded to 0.1 mm."""
+    labels = ("Protocol #1 Error (MPJPE):  ", "Protocol #2 Error (P-MPJPE):", "Protocol #3 Error (N-MPJPE):",
+              "Velocity    Error (MPJVE):  ", "Root        Error (MRPE):  ")
+    lines = []
+    for action, vals in named.items():
+        lines.append("----" + action + "----")
+        lines += ["%s %s mm" % (lab, v) for lab, v in zip(labels, vals)]
+        lines.append("----------")
+    heads = ("Protocol #1   (MPJPE)", "Protocol #2 (P-MPJPE)", "Protocol #3 (N-MPJPE)", "Velocity      (MPJVE)",
+             "Root           (MRPE)")
+    lines += ["%s action-wise average: %s mm" % (h, round(float(v), 1)) for h, v in zip(heads, average)]
+    return lines

@@ -369,3 +369,20 @@ def load_weight(model, pretrained: Dict[str, torch.Tensor]):
     target = _unwrap(model)
     target.load_state_dict(pretrained, strict=True)
     return model
+
+
+def load_checkpoint(path: str, pos_model, trj_model=None) -> dict:
+    """Load a checkpoint file written by the reference's Trainer (``torch.save`` of a dict holding ``model_pos`` and,
+    with a trajectory model, ``model_trj`` next to epoch / lr / optimizer state: lib/train_val/trainer.py:228-249) into
+    the given modules, as main.py:190-199 does for ``--evaluate`` - strictly (see :func:`load_weight`).  ``random_state``
+    in those files is a pickled NumPy generator state, so the file is unpickled in full: only open files you trust.
+    Returns the rest of the dict (epoch, lr, best_performance, ...)."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    if "model_pos" not in ckpt:
+        raise KeyError("%s has no 'model_pos' entry (keys: %s)" % (path, sorted(ckpt.keys())))
+    load_weight(pos_model, ckpt["model_pos"])
+    if trj_model is not None:
+        if "model_trj" not in ckpt:
+            raise KeyError("%s has no 'model_trj' entry but a trajectory model was given" % path)
+        load_weight(trj_model, ckpt["model_trj"])
+    return {k: v for k, v in ckpt.items() if k not in ("model_pos", "model_trj", "optimizer")}

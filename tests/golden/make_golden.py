@@ -15,6 +15,8 @@ What is pinned:
   3. evalcore.npz     : Trainer.evaluate_core's five metrics (with and without flip TTA) and its
      return_predictions output on synthetic clips.
   4. losses.npz       : mpjpe / n_mpjpe / p_mpjpe / mean_velocity_error known answers.
+  5. dataset.npz      : the reference's Data front end on a small synthetic archive pair: per-clip ground truth in
+     the normalised frame and ray-encoded keypoints, the left/right index lists, the H36M joint selection.
 Only numbers leave this script; no reference source text is stored.
 """
 import os
@@ -248,6 +250,59 @@ def gen_evalcore():
     np.savez_compressed(os.path.join(HERE, "evalcore.npz"), **blob)
 
 
+def gen_dataset():
+    """The reference's Data front end (lib/dataset/__init__.py) on a small synthetic archive pair in the 3DHP
+    format (plain per-camera keypoint arrays; the TS1 test camera of lib/dataset/mpii_3dhp_dataset.py), and the
+    joints its H36M class keeps of the 32-joint mocap skeleton."""
+    import copy
+    import tempfile
+    from lib.dataset import Data
+    from lib.dataset.h36m_dataset import h36m_skeleton
+    rng = np.random.default_rng(11)
+    cam_tab = dhp_camera_params["TS1"][0]
+    K = np.eye(3)
+    K[0, 0], K[1, 1] = np.array(cam_tab["focal_length"], dtype="float32")
+    K[0, 2], K[1, 2] = np.array(cam_tab["center"], dtype="float32")
+    R = np.array(cam_tab["R"], dtype="float32").astype(np.float64)
+    t = np.array(cam_tab["translation"], dtype="float32").astype(np.float64).reshape(3, 1)
+    lengths = {"Seq A 1": 31, "Seq A 2": 17, "Other": 23}
+    pos3d, pos2d = {"TS1": {}}, {"TS1": {}}
+    for act, n in lengths.items():
+        # world points in front of the camera: camera-frame box pushed back through the extrinsics
+        pc = np.stack([rng.uniform(-0.8, 0.8, (n, 17)), rng.uniform(-0.9, 0.9, (n, 17)), rng.uniform(3.0, 5.0, (n, 17))], -1)
+        pw = (pc - t.T) @ R                                     # Xw = R^T (Xc - t)
+        pos3d["TS1"][act] = pw.astype(np.float32)
+        uv = np.stack([pc[..., 0] / pc[..., 2] * K[0, 0] + K[0, 2], pc[..., 1] / pc[..., 2] * K[1, 1] + K[1, 2]], -1)
+        uv = np.concatenate([uv, uv[-1:].repeat(4, 0)], 0) + rng.normal(0, 1.0, (n + 4, 17, 2))   # 4 extra video frames
+        pos2d["TS1"][act] = [uv.astype(np.float32)]
+    meta = {"layout_name": "3dhp", "num_joints": 17, "keypoints_symmetry": [[4, 5, 6, 11, 12, 13], [1, 2, 3, 14, 15, 16]]}
+    with tempfile.TemporaryDirectory() as d:
+        p3, p2 = os.path.join(d, "d3.npz"), os.path.join(d, "d2.npz")
+        np.savez_compressed(p3, positions_3d=pos3d)
+        np.savez_compressed(p2, positions_2d=pos2d, metadata=meta)
+        data = Data({"DATASET": "3dhp", "WORLD_3D_GT_EVAL": True, "KEYPOINTS": "gt", "REMOVE_IRRELEVANT_KPTS": False,
+                     "GT_3D": p3, "GT_2D": p2, "FRAME_PATH": d, "INTRINSIC_ENCODING": False, "RAY_ENCODING": True,
+                     "DOWNSAMPLE": 1})
+        blob = dict(table_R=np.array(cam_tab["R"], dtype=np.float64), table_translation=np.array(cam_tab["translation"], dtype=np.float64),
+                    table_focal_length=np.array(cam_tab["focal_length"], dtype=np.float64),
+                    table_center=np.array(cam_tab["center"], dtype=np.float64),
+                    actions=np.array(list(lengths.keys())))
+        kl, kr = data.get_2d_kpts()
+        jl, jr = data.get_3d_joints()
+        blob.update(kps_left=np.array(kl), kps_right=np.array(kr), joints_left=np.array(jl), joints_right=np.array(jr))
+        for i, act in enumerate(lengths):
+            blob["in3d/%d" % i], blob["in2d/%d" % i] = pos3d["TS1"][act], pos2d["TS1"][act][0]
+            cams, p3d, p2d = data.fetch_via_action([("TS1", act)])
+            assert len(p3d) == 1
+            blob["gt_norm/%d" % i], blob["rays/%d" % i] = p3d[0], p2d[0]
+            c0 = cams[0][0] if isinstance(cams[0], (list, tuple)) else cams[0]
+            blob["pitch/%d" % i] = np.float64(c0.cam_pitch_rad)
+    sk = copy.deepcopy(h36m_skeleton)
+    blob["h36m_kept_17"] = np.array(sk.remove_joints([4, 5, 9, 10, 11, 16, 20, 21, 22, 23, 24, 28, 29, 30, 31]))
+    np.savez_compressed(os.path.join(HERE, "dataset.npz"), **blob)
+    print("dataset: clips", {k: v.shape for k, v in blob.items() if k.startswith("rays/")}, "kept", blob["h36m_kept_17"])
+
+
 def gen_losses():
     a = (synth.hash_uniform("loss.a", (6, 1, 17, 3), 5) * 2 - 1)
     b = a + 0.1 * (synth.hash_uniform("loss.b", (6, 1, 17, 3), 5) * 2 - 1)
@@ -262,12 +317,15 @@ def gen_losses():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1:                      # python make_golden.py <case> ...: only those model cases
-        gen_models(only=set(sys.argv[1:]))
+    if len(sys.argv) > 1:                      # python make_golden.py <case> ... | dataset: only those
+        if "dataset" in sys.argv[1:]:
+            gen_dataset()
+        gen_models(only=set(sys.argv[1:]) - {"dataset"} or {"-"})
         sys.exit(0)
     gen_cameras()
     gen_losses()
     gen_models()
     gen_evalcore()
+    gen_dataset()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("total fixture bytes: %.2f MB" % (tot / 1e6))

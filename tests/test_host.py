@@ -350,3 +350,94 @@ def test_schedule_balances_the_headline_launch():
     rc, grid, tiles, imb = _schedule_check([(256 * 27, 256, 24, 4, 0)] * 6 + [(256, 1024, 32, 4, 0)] * 2)
     assert rc == 0 and grid == 256
     assert imb < 1.08          # longest chunk within 8 % of the mean (it was 19 % with whole 6-unit tiles only)
+
+
+# ------------------------------------------------------------------ real-data front end
+
+def _dataset_fixture_archives(tmp_path):
+    z = np.load(os.path.join(GOLDEN, "dataset.npz"))
+    acts = [str(a) for a in z["actions"]]
+    pos3d = {"TS1": {a: z["in3d/%d" % i] for i, a in enumerate(acts)}}
+    pos2d = {"TS1": {a: [z["in2d/%d" % i]] for i, a in enumerate(acts)}}
+    meta = {"layout_name": "3dhp", "num_joints": 17, "keypoints_symmetry": [[4, 5, 6, 11, 12, 13], [1, 2, 3, 14, 15, 16]]}
+    p3, p2 = str(tmp_path / "d3.npz"), str(tmp_path / "d2.npz")
+    np.savez_compressed(p3, positions_3d=pos3d)
+    np.savez_compressed(p2, positions_2d=pos2d, metadata=meta)
+    table = {"TS1": [{"R": z["table_R"], "translation": z["table_translation"],
+                      "focal_length": z["table_focal_length"], "center": z["table_center"]}]}
+    return z, acts, p3, p2, table
+
+
+def test_pose_archives_load_like_the_reference_front_end(tmp_path):
+    """ray3d_amd.dataset vs lib/dataset/__init__.py (Data + fetch_via_action) on the same archive pair
+    (tests/golden/dataset.npz holds the reference's per-clip outputs)."""
+    from ray3d_amd import dataset
+    z, acts, p3, p2, table = _dataset_fixture_archives(tmp_path)
+    cams = dataset.cameras_from_tables(table)
+    pd = dataset.load_pose_data(p3, p2, cams, ["TS1"])
+    assert len(pd.clips) == len(acts)
+    for i, (a, c) in enumerate(zip(acts, pd.clips)):
+        ref_gt, ref_rays = z["gt_norm/%d" % i], z["rays/%d" % i]
+        assert c.rays.shape == ref_rays.shape and c.gt_norm.shape == ref_gt.shape      # 2D cut to the mocap length
+        assert np.array_equal(c.rays, ref_rays.astype(np.float32))                      # what trainer.py:298 feeds
+        assert np.array_equal(c.gt_norm, ref_gt.astype(np.float32))
+        assert c.action == a.split(" ")[0]
+        assert abs(c.camera.pitch - float(z["pitch/%d" % i])) < 1e-15
+    assert pd.actions == {"Seq": [0, 1], "Other": [2]}
+    assert pd.kps_left == list(z["kps_left"]) and pd.kps_right == list(z["kps_right"])
+    assert pd.joints_left == list(z["joints_left"]) and pd.joints_right == list(z["joints_right"])
+    assert list(dataset.H36M_32_TO_17) == list(z["h36m_kept_17"])
+    # filters, the 14-joint layout, and the sanity checks
+    only = dataset.load_pose_data(p3, p2, cams, ["TS1"], action_filter=["Other"], downsample=2)
+    assert len(only.clips) == 1 and only.clips[0].rays.shape[0] == 12
+    uni = dataset.load_pose_data(p3, p2, cams, ["TS1"], joints_3d=dataset.KEEP_UNIVERSAL_14_OF_17,
+                                 joints_2d=dataset.KEEP_UNIVERSAL_14_OF_17)
+    assert uni.clips[0].rays.shape[1] == 14 and (uni.kps_left, uni.kps_right) == ([4, 5, 6, 8, 9, 10], [1, 2, 3, 11, 12, 13])
+    assert (uni.joints_left, uni.joints_right) == ([4, 5, 6, 8, 9, 10], [1, 2, 3, 11, 12, 13])
+    assert np.array_equal(uni.clips[0].rays, pd.clips[0].rays[:, list(dataset.KEEP_UNIVERSAL_14_OF_17)])
+    with pytest.raises(KeyError, match="missing"):
+        dataset.load_pose_data(p3, p2, cams, ["TS2"])
+    with pytest.raises(ValueError, match="Camera count mismatch"):
+        dataset.load_pose_data(p3, p2, {"TS1": cams["TS1"] * 2}, ["TS1"])
+    short = dict(np.load(p2, allow_pickle=True))
+    k2 = short["positions_2d"].item()
+    k2["TS1"]["Other"] = [k2["TS1"]["Other"][0][:5]]
+    np.savez_compressed(str(tmp_path / "short.npz"), positions_2d=k2, metadata=short["metadata"].item())
+    with pytest.raises(ValueError, match="keypoint frames"):
+        dataset.load_pose_data(p3, str(tmp_path / "short.npz"), cams, ["TS1"])
+
+
+def test_h36m_table_conventions():
+    """Millimetre translations divided in float32, (k1,k2,p1,p2,k3) coefficient order (h36m_dataset.py:355-381)."""
+    from ray3d_amd import dataset
+    ext = {"S0": [{"R": np.eye(3), "translation": [1841.1070556640625, 4955.28466796875, 1563.4454345703125]}, {}]}
+    intr = [{"focal_length": [1145.0494384765625, 1143.7811279296875], "center": [512.54150390625, 515.4514770507812],
+             "radial_distortion": [-0.2, 0.24, -0.002], "tangential_distortion": [-0.0009, -0.0016]}, {}]
+    cam = dataset.cameras_from_tables(ext, intr, translation_divisor=1000, undistort=True)["S0"]
+    assert len(cam) == 1                                               # the entry without a translation is skipped
+    want_t = (np.array(ext["S0"][0]["translation"], dtype="float32") / 1000).astype(np.float64)
+    assert np.array_equal(cam[0].Tw2c.ravel(), want_t)
+    assert np.allclose(cam[0].dist_coeff, [-0.2, 0.24, -0.0009, -0.0016, -0.002], atol=1e-7)
+    assert cam[0].undistort and cam[0].fx == np.float32(1145.0494384765625)
+
+
+def test_checkpoint_file_in_the_trainers_format(tmp_path):
+    """A file as Trainer.train saves it (trainer.py:232-249): DataParallel-prefixed state dicts next to training state."""
+    mc = default_model_config(ARCHITECTURE="3,3")
+    fac = ray3d_amd.Model(mc, {}, is_train=False)
+    pos, trj = fac.get_pos_model(), fac.get_trj_model()
+    (cp, sp), (ct, st) = synth_states(mc)
+    as_dp = lambda st_: {"module." + k: torch.from_numpy(np.asarray(v)) for k, v in st_.items()}
+    path = str(tmp_path / "epoch_10.bin")
+    torch.save({"epoch": 10, "lr": 1e-4, "best_performance": 41.5, "random_state": np.random.RandomState(3),
+                "optimizer": {"state": {}}, "model_pos": as_dp(sp), "model_trj": as_dp(st)}, path)
+    rest = ray3d_amd.load_checkpoint(path, pos, trj)
+    assert rest["epoch"] == 10 and "optimizer" not in rest and "model_pos" not in rest
+    k = "GlobalInfo.fc_1.weight"
+    assert np.array_equal(pos.state_dict()[k].numpy(), np.asarray(sp[k]))
+    assert np.array_equal(trj.state_dict()["shrink.weight" if "shrink.weight" in st else next(iter(st))].numpy(),
+                          np.asarray(st["shrink.weight" if "shrink.weight" in st else next(iter(st))]))
+    torch.save({"epoch": 1, "model_pos": as_dp(sp)}, path)
+    with pytest.raises(KeyError, match="model_trj"):
+        ray3d_amd.load_checkpoint(path, pos, trj)
+    ray3d_amd.load_checkpoint(path, pos)
