@@ -150,8 +150,8 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
     // ---- persistent GEMM launches, one per DAG level
     Schedule *sched = schedule_get(pl, B, device_cu_count());
     if (!sched) return R3D_ERR_HIP;
-    for (size_t si = 0; si < pl->stages.size(); ++si) {
-        const auto &st = pl->stages[si];
+    for (size_t si = 0; si < sched->levels->size(); ++si) {
+        const auto &st = (*sched->levels)[si];
         const StageSchedule &ss = sched->stages[si];
         LaunchArgs la;
         memset(&la, 0, sizeof la);
@@ -161,8 +161,8 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         la.ks = ss.ks;
         int n_enc = 0;
         for (int i = 0; i < la.nprob; ++i) {
-            const ProbSpec &q = pl->probs[st[i]];
-            const Model *m = pl->m[q.model];
+            const ProbSpec &q = pl->probs[st[i] & ~STAGE_SPILL_IN];      // (a spilled tail uses the problem as it is:
+            const Model *m = pl->m[q.model];                             //  tiles carry absolute rows)
             const Layer &L = m->layers[q.layer];
             GemmProb &g = la.p[i];
             int kend = 0;
@@ -398,6 +398,65 @@ int r3d_debug_schedule_check(int nprob, const int *M, const int *N, const int *n
     for (int i = 0; i < nprob; ++i)
         for (int c : cover[i])
             if (c != 1) return -10;
+    return 0;
+}
+
+// Test hook: the whole forward's tile lists for `batch` windows on `nwg` CUs, built on the host (no device needed):
+// every 32-row x 64-column cell of every problem must be computed exactly once over all launches, a problem's
+// tiles must sit in launches that list it, and a consumer's launch must come after all of its producers' tiles.
+// Returns 0, or a negative code; *spilled = rows of the first level that run one launch late.
+int r3d_debug_plan_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg, int *launches, int *spilled) {
+    Model *a = reinterpret_cast<Model *>(pos ? pos : trj), *b = reinterpret_cast<Model *>(pos && trj ? trj : nullptr);
+    if (!a) return -1;
+    Plan *pl = plan_get(a, b);
+    if (!pl) return -2;
+    int spill_row0 = -1;
+    std::vector<int4> tiles;
+    std::vector<int> wgoff;
+    std::vector<StageSchedule> stages;
+    const std::vector<std::vector<int>> &levels = *schedule_build_host(pl, batch, nwg, spill_row0, tiles, wgoff, stages);
+    if (launches) *launches = (int)stages.size();
+    if (spilled) *spilled = 0;
+    const int np = (int)pl->probs.size();
+    std::vector<std::vector<int>> cover(np);
+    std::vector<int> last_launch(np, -1), first_launch(np, 1 << 30);
+    for (int i = 0; i < np; ++i) {
+        const ProbSpec &q = pl->probs[i];
+        const int M = (int)(batch * q.rows_per_window), N = pl->m[q.model]->layers[q.layer].N;
+        cover[i].assign((size_t)((M + 31) / 32) * ((N + 63) / 64), 0);
+    }
+    for (size_t si = 0; si < stages.size(); ++si) {
+        const StageSchedule &ss = stages[si];
+        const auto &st = levels[si];
+        if (ss.nwg < 1 || ss.nwg > 2 * nwg) return -3;
+        for (int t = 0; t < ss.ntiles; ++t) {
+            const int4 &tl = tiles[ss.tiles_off + t];
+            const int slot = tl.x & 0xff, mi = tl.x >> 8, ks = tl.w;
+            if (slot >= (int)st.size() || mi < 1) return -4;
+            const int id = st[slot] & ~STAGE_SPILL_IN;
+            const ProbSpec &q = pl->probs[id];
+            const int M = (int)(batch * q.rows_per_window), N = pl->m[q.model]->layers[q.layer].N;
+            if (tl.y % 32 || tl.y < 0 || tl.y >= M || tl.z < 0 || tl.z >= N) return -5;
+            if (id == pl->spill_prob) {
+                const bool late = (st[slot] & STAGE_SPILL_IN) != 0;
+                if (spill_row0 < 0 ? late : (late != (tl.y >= spill_row0))) return -6;
+                if (late && spilled) *spilled += std::min(mi * 32, M - tl.y);
+            }
+            const int gcols = (N + 63) / 64;
+            for (int u = tl.y / 32; u < tl.y / 32 + mi; ++u) {
+                if (u * 32 >= M) return -7;
+                for (int g = tl.z / 64; g < (tl.z + 256 / ks) / 64 && g < gcols; ++g) ++cover[id][(size_t)u * gcols + g];
+            }
+            last_launch[id] = std::max(last_launch[id], (int)si);
+            first_launch[id] = std::min(first_launch[id], (int)si);
+        }
+    }
+    for (int i = 0; i < np; ++i) {
+        for (int c : cover[i])
+            if (c != 1) return -8;
+        for (int d : pl->probs[i].deps)
+            if (last_launch[d] >= first_launch[i]) return -9;
+    }
     return 0;
 }
 

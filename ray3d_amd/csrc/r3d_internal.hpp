@@ -207,10 +207,14 @@ struct StageSchedule {
     size_t wgoff_off;
     double flops, bytes;   // algorithmic, for the launch records
     double imbalance;      // max chunk cost / mean chunk cost
+    double makespan;       // modelled cycles of the longest chunk
 };
 
 struct Schedule {
     int64_t B = 0;
+    int spill_row0 = -1;   // rows [spill_row0, M) of Plan::spill_prob run in the following launch; -1: the plain
+                           // level assignment (Plan::stages) is in use, else Plan::stages_spill
+    const std::vector<std::vector<int>> *levels = nullptr;   // the assignment this schedule was built for
     std::vector<StageSchedule> stages;
     int4 *d_tiles = nullptr;
     int *d_wgoff = nullptr;
@@ -222,6 +226,12 @@ struct Plan {
     std::vector<BufferSpec> buffers;
     std::vector<ProbSpec> probs;
     std::vector<std::vector<int>> stages;      // problem ids per launch
+    // Row spill: a second level assignment (r3d_plan.cpp) in which the last rows of problem `spill_prob` may run one
+    // launch later than the rest (entry | STAGE_SPILL_IN there), so that the launch it belongs to need not open a
+    // nearly empty extra round of tiles.  Whether it is used, and how many rows move, is decided per batch size in
+    // schedule_get (Schedule::spill_row0).  Empty when the plan has no such problem.
+    std::vector<std::vector<int>> stages_spill;
+    int spill_prob = -1;
     int64_t floats_per_window = 0;
     int emb_buf[2] = {-1, -1};
     int param_buf = -1;          // pseudo-buffer standing for r3d_input::param_dev
@@ -245,6 +255,7 @@ int model_set_weight(Model *m, const char *key, const float *host, const int64_t
 int model_finalize(Model *m);
 Plan *plan_get(Model *a, Model *b);
 constexpr int B3_MIN_ROWS = 512;          // bf16x3 tiles (opt-in) are used for problems of at least this many rows
+constexpr int STAGE_SPILL_IN = 1 << 30;   // flag on a Plan::stages entry: the spilled rows of that problem
 constexpr int GEMM_SCHED_MAX_UNITS = 6;   // widest tile of r3d_gemm_f32: 6 x 32 rows
 struct SchedProb {
     int M, N, nk;
@@ -252,6 +263,7 @@ struct SchedProb {
                      // concatenated operand with a boundary that is not a multiple of 32*KS)
     int max_units;   // per-problem cap on 32-row units per tile (0 = the launch default)
     int nk2 = 0;     // K-loop iterations of the fused further layers, in 32-row units (cost only)
+    int row0 = 0;    // first row this launch computes (a multiple of 32): rows [row0, M)
 };
 void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units, std::vector<int4> &tiles,
                     std::vector<int> &wgoff, StageSchedule &out, bool enc = false);
@@ -260,6 +272,8 @@ inline size_t frag_index(int o, int k, int nk) {
     const int nb = o >> 5, li = o & 31, kt = k >> 5, kin = k & 31, lh = kin >> 4, q = (kin & 15) >> 2, e = kin & 3;
     return ((((size_t)nb * nk + kt) * 4 + q) * 64 + (lh * 32 + li)) * 4 + e;
 }
+const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t B, int nwg, int &spill_row0, std::vector<int4> &tiles,
+                                                        std::vector<int> &wgoff, std::vector<StageSchedule> &stages);
 Schedule *schedule_get(Plan *pl, int64_t B, int nwg);   // nullptr + set_error on failure
 int device_cu_count();
 

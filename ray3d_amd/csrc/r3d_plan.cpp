@@ -18,6 +18,11 @@ namespace r3d {
 
 namespace {
 
+bool env_on(const char *name) {      // set and not "0"
+    const char *e = getenv(name);
+    return e && atoi(e) != 0;
+}
+
 struct Builder {
     Plan &p;
     int mi;             // model index inside the plan
@@ -159,7 +164,7 @@ static Plan *build_plan(const Model *a, const Model *b) {
         {
             int k0max = 0;
             for (const auto &br : m->branches) k0max = std::max(k0max, br.k0pad);
-            B.first_level_fused = m->cfg.num_levels >= 2 && m->cfg.channels <= N_ALIGN && k0max <= 256 && !getenv("R3D_NO_FIRST_FUSE");
+            B.first_level_fused = m->cfg.num_levels >= 2 && m->cfg.channels <= N_ALIGN && k0max <= 256 && !env_on("R3D_NO_FIRST_FUSE");
         }
         const int lat = m->cfg.latent, D = m->cfg.embed_dim;
         int pe = -1;
@@ -228,20 +233,50 @@ static Plan *build_plan(const Model *a, const Model *b) {
             B.fc_block("Integration", ins, 1, -1, 0, 0);
         }
     }
-    // The GlobalInfo MLP (rie.py:362) is independent of the conv pyramid and only needed by the Integration blocks.
-    // As early as possible its 32-iteration units ride in the short launches at the top of the pyramid and define
-    // their length; as LATE as possible (below) they ride in the FuseBlock launches, which have idle CUs anyway.
-    {
+    // Two level assignments are kept; schedule_get picks one per batch size by the modelled length of the launches.
+    //  * plain: every problem as early as its inputs allow, except the movable ones (below).
+    //  * spill (Plan::spill_prob): the first-level launch is made of tiles of 32 output rows of a branch, rarely a
+    //    multiple of the CU count of them: 1296 at 256 windows leave 16 tiles for a sixth round that 240 CUs sit
+    //    out.  The trajectory model's chain is four launches shorter than the pose model's, so here it sits one
+    //    launch lower and the tail of ITS first level may run next to the second pyramid level of the pose
+    //    branches, a launch with CUs to spare; the rest of its pyramid then rides wherever a launch is as long.
+    std::vector<int> asap;
+    for (const auto &q : pl->probs) asap.push_back(q.depth);
+    auto levelise = [&](bool spill, std::vector<std::vector<int>> &stages) -> bool {
         const int n = (int)pl->probs.size();
+        for (int i = 0; i < n; ++i) pl->probs[i].depth = asap[i];
+        int deepest = 0, pt = -1;
+        for (const auto &q : pl->probs) deepest = std::max(deepest, q.depth);
+        if (spill) {
+            bool pos_fused = false;
+            for (int i = 0; i < n; ++i) {
+                const ProbSpec &q = pl->probs[i];
+                if (q.layer3 >= 0 && pl->m[q.model]->cfg.kind == R3D_KIND_TRJ) pt = i;
+                pos_fused = pos_fused || (q.layer3 >= 0 && pl->m[q.model]->cfg.kind == R3D_KIND_POS);
+            }
+            if (pt < 0 || !pos_fused) return false;
+            for (auto &q : pl->probs)
+                for (int d : q.deps)
+                    if (d == pt) q.depth = std::max(q.depth, pl->probs[pt].depth + 2);
+            int grown = 0;
+            for (auto &q : pl->probs) {           // (problems are created in dependency order)
+                for (int d : q.deps) q.depth = std::max(q.depth, pl->probs[d].depth + 1);
+                grown = std::max(grown, q.depth);
+            }
+            if (grown > deepest) return false;
+        }
+        // The GlobalInfo MLP (rie.py:362) is independent of the conv pyramid and only needed by the Integration
+        // blocks.  As early as possible its 32-iteration units ride in the short launches at the top of the pyramid
+        // and define their length; as LATE as possible they ride in the FuseBlock launches, which have idle CUs
+        // anyway.  So does the trajectory model's decoder MLP ("Integration."; the body-part decoders are
+        // "Integration_<part>."), which only the final decoder kernel waits for - and, in the spill assignment, the
+        // rest of the trajectory model's pyramid.
         std::vector<std::vector<int>> users(n);
         for (int i = 0; i < n; ++i)
             for (int d : pl->probs[i].deps) users[d].push_back(i);
-        int deepest = 0;
-        for (const auto &q : pl->probs) deepest = std::max(deepest, q.depth);
-        // ... and so does the trajectory model's decoder MLP ("Integration."; the body-part decoders are
-        // "Integration_<part>."), which only the final decoder kernel waits for
         auto movable = [&](const ProbSpec &q) {
             const std::string &key = pl->m[q.model]->layers[q.layer].weight_key;
+            if (spill && pl->m[q.model]->cfg.kind == R3D_KIND_TRJ && key.rfind("LocalLayer.", 0) == 0 && q.layer3 < 0) return true;
             return (key.rfind("GlobalInfo.", 0) == 0 && key.rfind("GlobalInfo.fc_1", 0) != 0) || key.rfind("Integration.", 0) == 0;
         };
         auto iterations = [&](const ProbSpec &q) {      // K-loop iterations of one 32-row unit through the problem
@@ -269,18 +304,30 @@ static Plan *build_plan(const Model *a, const Model *b) {
                 if (level_iters[l] >= iterations(q)) { pick = l; break; }
             q.depth = pick;
         }
-    }
-    // levelise
-    int maxd = 0;
-    for (auto &q : pl->probs) maxd = std::max(maxd, q.depth);
-    pl->stages.assign(maxd + 1, {});
-    for (int i = 0; i < (int)pl->probs.size(); ++i) pl->stages[pl->probs[i].depth].push_back(i);
-    // split launches that exceed the kernarg capacity
-    std::vector<std::vector<int>> split;
-    for (auto &st : pl->stages)
-        for (size_t i = 0; i < st.size(); i += MAX_PROB)
-            split.emplace_back(st.begin() + i, st.begin() + std::min(st.size(), i + MAX_PROB));
-    pl->stages.swap(split);
+        int maxd = 0;
+        for (auto &q : pl->probs) maxd = std::max(maxd, q.depth);
+        std::vector<std::vector<int>> lv(maxd + 1);
+        for (int i = 0; i < n; ++i) lv[pl->probs[i].depth].push_back(i);
+        if (spill) lv[pl->probs[pt].depth + 1].push_back(pt | STAGE_SPILL_IN);
+        if (getenv("R3D_PLAN_DUMP"))
+            for (size_t s = 0; s < lv.size(); ++s) {
+                fprintf(stderr, "[plan%s] launch %zu:", spill ? " spill" : "", s);
+                for (int e : lv[s]) {
+                    const ProbSpec &q = pl->probs[e & ~STAGE_SPILL_IN];
+                    fprintf(stderr, " %s%s(x%d)", e & STAGE_SPILL_IN ? "+" : "", pl->m[q.model]->layers[q.layer].weight_key.c_str(), q.rows_per_window);
+                }
+                fprintf(stderr, "\n");
+            }
+        // split launches that exceed the kernarg capacity
+        stages.clear();
+        for (auto &st : lv)
+            for (size_t i = 0; i < st.size(); i += MAX_PROB)
+                stages.emplace_back(st.begin() + i, st.begin() + std::min(st.size(), i + MAX_PROB));
+        if (spill) pl->spill_prob = pt;
+        return true;
+    };
+    if (!(pl->m[0] && pl->m[1] && !env_on("R3D_NO_SPILL") && levelise(true, pl->stages_spill))) pl->stages_spill.clear();
+    levelise(false, pl->stages);
     // workspace offsets
     int64_t off = 0;
     for (auto &bf : pl->buffers) {

@@ -14,6 +14,8 @@
 // occupied (profiles/r01_v0/pmc_table.txt).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 #include "r3d_internal.hpp"
 
@@ -75,17 +77,27 @@ bool assign(const std::vector<Seg> &segs, int nbins, double T, int ksplit, Assig
     std::vector<Left> left;
     int cursor = 0;
     double cursor_cost = -1;
+    // the costliest class of units is spread evenly over the workgroups instead of filling them one by one: when a
+    // launch mixes two sizes (the trajectory model's first-level tiles are 1.4x the body branches'), the big ones
+    // must not pile up in a few chunks that the small ones then cannot level
+    long long top_units = 0;
+    const double top_c1 = segs.empty() ? 0.0 : segs.front().c1;
+    for (const Seg &s : segs)
+        if (s.c1 == top_c1) top_units += s.units;
+    const int top_cap = (int)std::max<long long>(1, (top_units + nbins - 1) / nbins);
     for (const Seg &s : segs) {          // sorted by c1, descending
         if (s.c1 != cursor_cost) { cursor = 0; cursor_cost = s.c1; }
+        const int spread = s.c1 == top_c1 && segs.back().c1 != top_c1 ? top_cap : 1 << 30;
         int u = 0;
         if (s.c1 <= T) {
             while (u < s.units) {
                 while (cursor < nbins && room[cursor] + 1e-6 < s.c1) ++cursor;
                 if (cursor == nbins) break;
-                const int take = std::min((int)std::floor((room[cursor] + 1e-6) / s.c1), s.units - u);
+                const int take = std::min(std::min((int)std::floor((room[cursor] + 1e-6) / s.c1), spread), s.units - u);
                 room[cursor] -= take * s.c1;
                 if (out) out->bins[cursor].push_back({s.prob, s.col0, 1, u, take, s.cap});
                 u += take;
+                if (take == spread) ++cursor;
             }
         }
         if (u < s.units) {
@@ -142,7 +154,7 @@ void pack(const std::vector<SchedProb> &probs, int nbins_max, int max_units, Pac
     long long total_units = 0;
     for (int i = 0; i < (int)probs.size(); ++i) {
         const SchedProb &p = probs[i];
-        const int units = (p.M + 31) / 32;
+        const int units = (std::max(p.M - p.row0, 0) + 31) / 32;
         const double c1 = unit_cycles(p.nk + p.nk2, 1);
         for (int c0 = 0; c0 < p.N; c0 += 256) {
             segs.push_back({i, c0, units, p.nk, p.max_units > 0 ? std::min(p.max_units, max_units) : max_units, p.max_ks, c1,
@@ -195,7 +207,7 @@ void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units,
             int done = 0;
             for (int k = 0; k < nt; ++k) {
                 const int sz = (r.n - done + (nt - k) - 1) / (nt - k);
-                tiles.push_back(make_int4(r.prob | (sz << 8), (r.u0 + done) * 32, r.col0, r.ks));
+                tiles.push_back(make_int4(r.prob | (sz << 8), probs[r.prob].row0 + (r.u0 + done) * 32, r.col0, r.ks));
                 done += sz;
             }
             out.ks = std::max(out.ks, r.ks);
@@ -207,16 +219,24 @@ void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units,
     out.nwg = grid;
     out.ntiles = (int)(tiles.size() - t0);
     out.imbalance = best->a.worst / std::max(best->total / grid, 1.0);
+    out.makespan = best->a.worst;
 }
 
-static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, int nwg, std::vector<int4> &tiles,
+// `spill_row0`: rows [spill_row0, M) of Plan::spill_prob belong to the launch that lists it with STAGE_SPILL_IN, the
+// rows before to its own launch (-1: all rows stay).
+static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, int nwg, int spill_row0, std::vector<int4> &tiles,
                         std::vector<int> &wgoff, StageSchedule &out) {
     std::vector<SchedProb> probs;
     double flops = 0, bytes = 0;
     for (int i = 0; i < (int)st.size(); ++i) {
-        const ProbSpec &q = pl->probs[st[i]];
+        const int id = st[i] & ~STAGE_SPILL_IN;
+        const ProbSpec &q = pl->probs[id];
         const Layer &L = pl->m[q.model]->layers[q.layer];
-        const int M = (int)(B * q.rows_per_window);
+        const int M_all = (int)(B * q.rows_per_window);
+        int M = M_all, row0 = 0;
+        if (st[i] & STAGE_SPILL_IN) row0 = spill_row0 >= 0 ? spill_row0 : M_all;
+        else if (id == pl->spill_prob && spill_row0 >= 0) M = spill_row0;
+        const double share = M_all > 0 ? (double)(M - row0) / M_all : 0.0;
         // fused-prologue tiles hold the whole encoded operand in 64 KiB of LDS: rows * (K + 4) floats
         const int enc_cap = q.enc_lut >= 0 ? std::max(1, std::min(3, (64 * 1024) / ((L.Kpad + 4) * 4 * 32))) : 0;
         // split-K sub-tiles of one iteration must come from one buffer of a concatenated operand
@@ -236,24 +256,97 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
             const Model *mm = pl->m[q.model];
             sp.max_ks = 1;
             sp.max_units = 1;
-            sp.nk2 = 2 * sp.nk + mm->layers[q.layer2].Kpad / BK + mm->layers[q.layer3].Kpad / BK;
+            // (+ the gathers of the raw input, one per pass over the tile's 96 first-layer rows: one pass when the
+            // operand tile is narrow enough to hold them all, three otherwise; ~5 iterations' time each, measured:
+            // 47 us for a body-part tile, 74 us for the trajectory model's at 2.1 GHz)
+            sp.nk2 = 2 * sp.nk + mm->layers[q.layer2].Kpad / BK + mm->layers[q.layer3].Kpad / BK + 5 * (L.Kpad <= 64 ? 1 : 3);
         } else if (q.layer2 >= 0) {                // fused pair: whole tiles of <= 128 rows, no split
             sp.max_ks = 1;
             sp.max_units = 4;
             sp.nk2 = pl->m[q.model]->layers[q.layer2].Kpad / BK;
         }
+        sp.row0 = row0;
         probs.push_back(sp);
-        flops += q.flops_per_window * (double)B;
-        bytes += 4.0 * ((double)M * L.K + (double)L.N * L.K + (double)M * L.N * (q.res_buf >= 0 ? 2.0 : 1.0));
+        flops += q.flops_per_window * (double)B * share;
+        if (M == row0) continue;
+        bytes += 4.0 * ((double)(M - row0) * L.K + (double)L.N * L.K + (double)(M - row0) * L.N * (q.res_buf >= 0 ? 2.0 : 1.0));
         if (q.layer2 >= 0) bytes += 4.0 * (double)L.N * pl->m[q.model]->layers[q.layer2].K;
-        if (q.layer3 >= 0) bytes += 4.0 * (double)L.N * L.N + 4.0 * 2.0 * (double)M * L.K;   // (three input rows per output row)
+        if (q.layer3 >= 0) bytes += 4.0 * (double)L.N * L.N + 4.0 * 2.0 * (double)(M - row0) * L.K;   // (three input rows per output row)
     }
     bool enc = false;
-    for (int id : st) enc = enc || (pl->probs[id].enc_lut >= 0 && pl->probs[id].layer3 < 0);
+    for (int e : st) enc = enc || (pl->probs[e & ~STAGE_SPILL_IN].enc_lut >= 0 && pl->probs[e & ~STAGE_SPILL_IN].layer3 < 0);
     // the fused-prologue kernel runs two workgroups per CU (one encodes while the other multiplies)
     schedule_stage(probs, enc ? 2 * nwg : nwg, GEMM_SCHED_MAX_UNITS, tiles, wgoff, out, enc);
     out.flops = flops;
     out.bytes = bytes;
+}
+
+// Host part of schedule_get: picks the level assignment and the row spill for this batch size by the modelled
+// length of the launches (sum over launches of the longest chunk), then builds every launch's tile lists.
+const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t B, int nwg, int &spill_row0, std::vector<int4> &tiles,
+                                                        std::vector<int> &wgoff, std::vector<StageSchedule> &stages) {
+    spill_row0 = -1;
+    const std::vector<std::vector<int>> *levels = &pl->stages;
+    const bool dump = getenv("R3D_PLAN_DUMP") != nullptr;
+    auto modelled = [&](const std::vector<std::vector<int>> &lv, int row0, int only_a, int only_b) {
+        double sum = 0;
+        for (int si = 0; si < (int)lv.size(); ++si) {
+            if (only_a >= 0 && si != only_a && si != only_b) continue;
+            std::vector<int4> t;
+            std::vector<int> w;
+            StageSchedule a{};
+            build_stage(pl, lv[si], B, nwg, row0, t, w, a);
+            sum += a.makespan;
+        }
+        return sum;
+    };
+    if (pl->spill_prob >= 0 && !pl->stages_spill.empty()) {
+        const auto &lv = pl->stages_spill;
+        // the launch that holds the spilling problem and the one after it
+        int s0 = -1, s1 = -1;
+        for (int si = 0; si < (int)lv.size(); ++si)
+            for (int e : lv[si]) {
+                if (e == pl->spill_prob) s0 = si;
+                if (e == (pl->spill_prob | STAGE_SPILL_IN)) s1 = si;
+            }
+        const ProbSpec &q = pl->probs[pl->spill_prob];
+        const int M_all = (int)(B * q.rows_per_window);
+        const long long own = (M_all + 31) / 32;
+        long long fl_tiles = 0;
+        for (int e : lv[std::max(s0, 0)])
+            if (!(e & STAGE_SPILL_IN) && pl->probs[e].layer3 >= 0) fl_tiles += (B * pl->probs[e].rows_per_window + 31) / 32;
+        if (s0 >= 0 && s1 >= 0 && fl_tiles > nwg) {
+            // candidates for the tiles that run late: none, the remainder of the division of the first-level tiles by
+            // the CU count, and multiples of 8 up to half a round
+            const long long rem = fl_tiles % nwg;
+            std::vector<long long> cands{0};
+            if (rem > 0 && rem <= nwg / 2) cands.push_back(rem);
+            for (long long r = 8; r <= nwg / 2; r += 8)
+                if (r != rem) cands.push_back(r);
+            double best = 0;
+            int best_row0 = M_all;
+            for (long long r : cands) {
+                if (r >= own) continue;
+                const int row0 = r ? (int)((own - r) * 32) : M_all;
+                const double cost = modelled(lv, row0, s0, s1);
+                if (r == 0 || cost < best * 0.995) { best = cost; best_row0 = row0; }
+            }
+            if (best_row0 < M_all) {
+                const double c_spill = modelled(lv, best_row0, -1, -1), c_plain = modelled(pl->stages, -1, -1, -1);
+                if (dump) fprintf(stderr, "[plan] B=%lld: %d rows late: modelled %.0f cycles, plain %.0f\n", (long long)B, M_all - best_row0, c_spill, c_plain);
+                if (c_spill < c_plain * 0.99) {      // (measured: modelled gains under 1 % do not materialise)
+                    levels = &lv;
+                    spill_row0 = best_row0;
+                }
+            }
+        }
+    }
+    for (const auto &st : *levels) {
+        StageSchedule ss{};
+        build_stage(pl, st, B, nwg, spill_row0, tiles, wgoff, ss);
+        stages.push_back(ss);
+    }
+    return levels;
 }
 
 Schedule *schedule_get(Plan *pl, int64_t B, int nwg) {
@@ -272,11 +365,7 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg) {
     s->B = B;
     std::vector<int4> tiles;
     std::vector<int> wgoff;
-    for (const auto &st : pl->stages) {
-        StageSchedule ss{};
-        build_stage(pl, st, B, nwg, tiles, wgoff, ss);
-        s->stages.push_back(ss);
-    }
+    s->levels = schedule_build_host(pl, B, nwg, s->spill_row0, tiles, wgoff, s->stages);
     hipError_t e;
     if ((e = hipMalloc((void **)&s->d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(int4))) != hipSuccess ||
         (e = hipMalloc((void **)&s->d_wgoff, std::max<size_t>(wgoff.size(), 1) * sizeof(int))) != hipSuccess ||

@@ -441,3 +441,36 @@ def test_checkpoint_file_in_the_trainers_format(tmp_path):
     with pytest.raises(KeyError, match="model_trj"):
         ray3d_amd.load_checkpoint(path, pos, trj)
     ray3d_amd.load_checkpoint(path, pos)
+
+
+def _plan_check(mc, batches, nwg=256):
+    """Whole-forward tile lists built on the host (r3d_debug_plan_check): every 32 x 64 cell of every problem once,
+    producers' tiles in earlier launches than their consumers', spilled rows only in the launch that lists them."""
+    lib = _capi.load()
+    fn = lib.r3d_debug_plan_check
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    fn.restype = ctypes.c_int
+    hp, ht = _capi.Handle(config_from_dicts(mc, "pos")), _capi.Handle(config_from_dicts(mc, "trj"))
+    out = []
+    for B in batches:
+        n, sp = ctypes.c_int(), ctypes.c_int()
+        rc = fn(hp.ptr, ht.ptr, B, nwg, ctypes.byref(n), ctypes.byref(sp))
+        assert rc == 0, (B, rc)
+        out.append((n.value, sp.value))
+    hp.close()
+    ht.close()
+    return out
+
+
+def test_plan_tile_lists_cover_every_problem_once(monkeypatch):
+    mc = default_model_config(ARCHITECTURE="3,3,3,3,3")
+    res = _plan_check(mc, [1, 2, 31, 100, 255, 256, 257, 600, 1024, 2048])
+    assert all(n == 13 for n, _ in res)
+    assert dict(zip([1, 2, 31, 100, 255, 256, 257, 600, 1024, 2048], [s for _, s in res]))[256] == 512
+    # 1296 equal-row tiles on 256 CUs: the 16 that would open a sixth round run with the next launch
+    for arch in ("3,3,3", "3,3", "3"):
+        _plan_check(default_model_config(ARCHITECTURE=arch), [1, 64, 256, 1000, 4096])
+    _plan_check(mc, [256, 1000], nwg=64)
+    _plan_check(default_model_config(ARCHITECTURE="3,3,3,3", CHANNELS=512), [3, 256])
+    monkeypatch.setenv("R3D_NO_SPILL", "1")
+    assert all(s == 0 for _, s in _plan_check(mc, [100, 256, 1024]))
