@@ -5,7 +5,9 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ray3d_amd
-from ray3d_amd import synth
+from ray3d_amd import synth, _capi
+if os.environ.get("R3D_LIB_OVERRIDE"):          # A/B against another build of the library
+    _capi.LIB_PATH = os.path.abspath(os.environ["R3D_LIB_OVERRIDE"])
 from ray3d_amd.spec import config_from_dicts
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
