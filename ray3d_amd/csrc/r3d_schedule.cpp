@@ -169,10 +169,18 @@ void pack(const std::vector<SchedProb> &probs, int nbins_max, int max_units, Pac
     // split-K pieces of 128 and of 64 columns; wider pieces win ties
     out.ks = 0;
     for (int ksplit = 2; ksplit <= 4; ksplit *= 2) {
-        double lo = std::max(total / nbins, biggest_fixed), hi = std::max(total, lo) + 1.0;
-        for (const Seg &s : segs) hi = std::max(hi, s.c1 * s.units + 1.0);
-        if (assign(segs, nbins, lo, ksplit, nullptr)) hi = lo;
-        for (int it = 0; it < 40 && hi - lo > 16.0; ++it) {
+        double lo = std::max(total / nbins, biggest_fixed), top = std::max(total, lo) + 1.0;
+        for (const Seg &s : segs) top = std::max(top, s.c1 * s.units + 1.0);
+        // gallop up from the ideal budget (a feasible one is rarely more than a unit above it), then bisect
+        double hi = lo;
+        if (!assign(segs, nbins, lo, ksplit, nullptr)) {
+            double step = 0.03 * lo + 1.0;
+            for (hi = std::min(lo + step, top); hi < top && !assign(segs, nbins, hi, ksplit, nullptr); hi = std::min(hi + step, top)) {
+                lo = hi;
+                step *= 2.0;
+            }
+        }
+        for (int it = 0; it < 40 && hi - lo > 0.001 * hi; ++it) {
             const double mid = 0.5 * (lo + hi);
             if (assign(segs, nbins, mid, ksplit, nullptr)) hi = mid; else lo = mid;
         }
@@ -288,18 +296,18 @@ const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t
     spill_row0 = -1;
     const std::vector<std::vector<int>> *levels = &pl->stages;
     const bool dump = getenv("R3D_PLAN_DUMP") != nullptr;
-    auto modelled = [&](const std::vector<std::vector<int>> &lv, int row0, int only_a, int only_b) {
+    auto build_all = [&](const std::vector<std::vector<int>> &lv, int row0, std::vector<int4> &t, std::vector<int> &w,
+                         std::vector<StageSchedule> &ss) {
         double sum = 0;
-        for (int si = 0; si < (int)lv.size(); ++si) {
-            if (only_a >= 0 && si != only_a && si != only_b) continue;
-            std::vector<int4> t;
-            std::vector<int> w;
+        for (const auto &st : lv) {
             StageSchedule a{};
-            build_stage(pl, lv[si], B, nwg, row0, t, w, a);
+            build_stage(pl, st, B, nwg, row0, t, w, a);
+            ss.push_back(a);
             sum += a.makespan;
         }
         return sum;
     };
+    const double c_plain = build_all(pl->stages, -1, tiles, wgoff, stages);
     if (pl->spill_prob >= 0 && !pl->stages_spill.empty()) {
         const auto &lv = pl->stages_spill;
         // the launch that holds the spilling problem and the one after it
@@ -317,34 +325,40 @@ const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t
             if (!(e & STAGE_SPILL_IN) && pl->probs[e].layer3 >= 0) fl_tiles += (B * pl->probs[e].rows_per_window + 31) / 32;
         if (s0 >= 0 && s1 >= 0 && fl_tiles > nwg) {
             // candidates for the tiles that run late: none, the remainder of the division of the first-level tiles by
-            // the CU count, and multiples of 8 up to half a round
+            // the CU count, and multiples of 32 up to half a round
             const long long rem = fl_tiles % nwg;
             std::vector<long long> cands{0};
             if (rem > 0 && rem <= nwg / 2) cands.push_back(rem);
-            for (long long r = 8; r <= nwg / 2; r += 8)
+            for (long long r = 32; r <= nwg / 2; r += 32)
                 if (r != rem) cands.push_back(r);
             double best = 0;
             int best_row0 = M_all;
             for (long long r : cands) {
                 if (r >= own) continue;
                 const int row0 = r ? (int)((own - r) * 32) : M_all;
-                const double cost = modelled(lv, row0, s0, s1);
+                std::vector<int4> t;
+                std::vector<int> w;
+                StageSchedule a{}, b{};
+                build_stage(pl, lv[s0], B, nwg, row0, t, w, a);
+                build_stage(pl, lv[s1], B, nwg, row0, t, w, b);
+                const double cost = a.makespan + b.makespan;
                 if (r == 0 || cost < best * 0.995) { best = cost; best_row0 = row0; }
             }
             if (best_row0 < M_all) {
-                const double c_spill = modelled(lv, best_row0, -1, -1), c_plain = modelled(pl->stages, -1, -1, -1);
+                std::vector<int4> t;
+                std::vector<int> w;
+                std::vector<StageSchedule> ss;
+                const double c_spill = build_all(lv, best_row0, t, w, ss);
                 if (dump) fprintf(stderr, "[plan] B=%lld: %d rows late: modelled %.0f cycles, plain %.0f\n", (long long)B, M_all - best_row0, c_spill, c_plain);
                 if (c_spill < c_plain * 0.99) {      // (measured: modelled gains under 1 % do not materialise)
                     levels = &lv;
                     spill_row0 = best_row0;
+                    tiles.swap(t);
+                    wgoff.swap(w);
+                    stages.swap(ss);
                 }
             }
         }
-    }
-    for (const auto &st : *levels) {
-        StageSchedule ss{};
-        build_stage(pl, st, B, nwg, spill_row0, tiles, wgoff, ss);
-        stages.push_back(ss);
     }
     return levels;
 }
@@ -353,8 +367,8 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg) {
     auto it = pl->schedules.find(B);
     if (it != pl->schedules.end()) return it->second;
     // bound the cache: evict the oldest batch size (the caller synchronises nothing here; a schedule
-    // is only freed after 16 newer batch sizes were used, by which time its launches have long retired)
-    if (pl->schedule_lru.size() >= 16) {
+    // is only freed after 64 newer batch sizes were used, by which time its launches have long retired)
+    if (pl->schedule_lru.size() >= 64) {
         const int64_t old = pl->schedule_lru.front();
         pl->schedule_lru.erase(pl->schedule_lru.begin());
         (void)hipDeviceSynchronize();

@@ -317,10 +317,17 @@ class Ray3DLifter(nn.Module):
             cur.wait_stream(s)
         return out
 
+    CLIP_CHUNK = 2048      # windows per forward in clip mode
+    CLIP_ROUND = 128       # the last chunk is rounded up to a multiple of this many windows
+
     def forward_clip(self, clip: torch.Tensor, param_row: Optional[torch.Tensor] = None):
         """clip (N + RF - 1, J, F): an edge-padded sequence; window i = frames [i, i+RF) is gathered
-        in the prologue kernel instead of materialising lib/train_val/trainer.py:47-58's copy.
-        param_row (E,) is broadcast to every window (trainer.py:324).  Returns (N,1,J,3)."""
+        in the kernels instead of materialising lib/train_val/trainer.py:47-58's copy.
+        param_row (E,) is broadcast to every window (trainer.py:324).  Returns (N,1,J,3).
+
+        The library keeps one tile schedule per batch size, and every clip has its own length: the windows are
+        lifted CLIP_CHUNK at a time and the last chunk is rounded up to a multiple of CLIP_ROUND (over repeated last
+        frames; the surplus poses are cut off), so that a whole evaluation uses a handful of batch sizes."""
         rf = self.receptive_field()
         assert clip.dim() == 3 and clip.shape[1] == self.pos.num_joints_in and clip.shape[2] == self.pos.in_features
         n = clip.shape[0] - rf + 1
@@ -329,7 +336,20 @@ class Ray3DLifter(nn.Module):
         clip = clip.detach().to(torch.float32).contiguous()
         p = param_row.detach().to(clip.device, torch.float32).contiguous().view(-1) \
             if self.pos.camera_embedding else None
-        return self._run(_capi.R3D_INPUT_RAYS, clip, 1, n, p, 0)
+        if n <= self.CLIP_ROUND:
+            return self._run(_capi.R3D_INPUT_RAYS, clip, 1, n, p, 0)
+        sizes = [self.CLIP_CHUNK] * (n // self.CLIP_CHUNK)
+        if n % self.CLIP_CHUNK:
+            sizes.append(-(-(n % self.CLIP_CHUNK) // self.CLIP_ROUND) * self.CLIP_ROUND)
+        total = sum(sizes)
+        if total > n:
+            clip = torch.cat([clip, clip[-1:].expand(total - n, -1, -1)], dim=0)
+        out = torch.empty((total, 1, self.pos.num_joints_in, 3), dtype=torch.float32, device=clip.device)
+        start = 0
+        for b in sizes:
+            self._run(_capi.R3D_INPUT_RAYS, clip[start:], 1, b, p, 0, out=out[start:start + b])
+            start += b
+        return out[:n]
 
     def forward_uv(self, uv: torch.Tensor, cam_rows: torch.Tensor, param: Optional[torch.Tensor] = None,
                    window_stride: Optional[int] = None):

@@ -90,10 +90,18 @@ def test_forward_clip_equals_materialised_windows():
     windows = np.stack([clip[i:i + rf] for i in range(n)])
     prow = np.array([1.5, 0.2], np.float32)
     with torch.no_grad():
+        lifter.CLIP_ROUND = 256                                   # one forward of exactly n windows
         a = lifter.forward_clip(torch.from_numpy(clip).cuda(), torch.from_numpy(prow).cuda()).cpu().numpy()
         b = lifter(torch.from_numpy(windows).cuda(), torch.from_numpy(np.tile(prow, (n, 1))).cuda()).cpu().numpy()
-    assert a.shape == (n, 1, 17, 3)
-    assert np.array_equal(a, b)        # same arithmetic, same order: bit-identical
+        assert a.shape == (n, 1, 17, 3)
+        assert np.array_equal(a, b)        # same arithmetic, same order: bit-identical
+        # chunked: 64 windows per forward, the last chunk rounded up to a multiple of 32 over repeated last frames
+        lifter.CLIP_CHUNK, lifter.CLIP_ROUND = 64, 32
+        c = lifter.forward_clip(torch.from_numpy(clip).cuda(), torch.from_numpy(prow).cuda())
+        assert c.shape == (n, 1, 17, 3) and c.is_contiguous()
+        # other batch sizes, other split-K tiles: last-bit differences on outputs of several metres
+        assert np.abs(c.cpu().numpy() - b).max() <= 1e-5 * max(1.0, np.abs(b).max())
+        c += 1.0                                                   # caller-owned and writable (trainer.py:353)
 
 
 def test_forward_uv_matches_host_ray_encoding():
