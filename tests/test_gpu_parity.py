@@ -200,6 +200,42 @@ def test_large_batch_1024():
     assert (big - parts).abs().max().item() <= 6e-5
 
 
+def test_universal_14_joint_batch_4096():
+    """BASELINE configs[4]: 14-joint layout (quirk Q2's permuted output order), RF 9, 4096 windows per step with a
+    different synthetic camera per window: oracle agreement on a sample, equal to eight 512-window calls."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    from oracle import oracle
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3", NUM_KPTS=14)
+    pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    B = 4096
+    x = synth.synth_rays(B, cp, seed=51)
+    p = synth.synth_param(B, seed=52)                              # per-window [height, pitch]
+    xd, pd = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    with torch.no_grad():
+        big = lifter(xd, pd)
+        parts = torch.cat([lifter(xd[i:i + 512].contiguous(), pd[i:i + 512].contiguous()) for i in range(0, B, 512)])
+    assert big.shape == (B, 1, 14, 3) and torch.isfinite(big).all()
+    assert (big - parts).abs().max().item() <= 6e-5
+    idx = [0, 1, 2047, 4095]
+    ref = oracle.forward(cp, sp, x[idx], p[idx]) + oracle.forward(ct, st, x[idx], p[idx])
+    assert np.abs(big[idx].cpu().numpy() - ref).max() <= tol_for(ref)
+
+
+def test_empty_batch_is_rejected():
+    """The reference's forward fails on an empty batch (BatchNorm/Conv on zero rows is fine in torch, but main.py never
+    produces one); the library names the problem instead of launching empty grids."""
+    import ray3d_amd
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3")
+    pos, trj, _, _ = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    x = torch.zeros((0, 9, 17, 3), device="cuda")
+    p = torch.zeros((0, 2), device="cuda")
+    with pytest.raises((RuntimeError, AssertionError)):
+        lifter(x, p)
+
+
 def test_weight_update_is_picked_up():
     import ray3d_amd
     from ray3d_amd import synth
