@@ -200,9 +200,8 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
                 g.res_tap = 1 + m->cfg.causal;
             }
             g.w = m->d_arena + L.w_off;
-            // (below B3_MIN_ROWS rows the tiles are single units, whose bound is the weight stream, not the matrix rate)
-            if (L.bf3 && q.layer2 < 0 && q.enc_lut < 0 && B * q.rows_per_window >= B3_MIN_ROWS)
-                g.wb3 = reinterpret_cast<const unsigned short *>(m->d_arena + L.wb3_off);
+            if (L.bf3 && q.layer2 < 0 && q.enc_lut < 0)
+                g.wb3 = m->d_arena + L.wb3_off;
             g.bias = m->d_arena + L.b_off;
             g.res = q.res_buf >= 0 ? buf_ptr(q.res_buf) + q.res_col : nullptr;
             g.ldr = q.res_ld;

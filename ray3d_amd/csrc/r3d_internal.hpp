@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -39,8 +40,8 @@ struct GemmProb {
     const float *bias2;
     int K2;
     float slope2;
-    // --- fp32 on the bf16 matrix cores (wb3 != nullptr): the same weights split into three bf16 terms ---
-    const unsigned short *wb3;
+    // --- fp32 on the bf16 matrix cores (wb3 != nullptr): the same fp32 weights in bf16-MFMA operand order ---
+    const float *wb3;
     // --- first level of the pyramid in one tile (w3 != nullptr; lut != nullptr): w/bias = expand_conv on the gathered
     // input (three rows per output row), w2/bias2 = the level's 3-tap convolution, w3/bias3 = its 1x1 convolution;
     // the residual is the centre one of the three expand_conv rows.  M counts OUTPUT rows. ---
@@ -129,8 +130,8 @@ struct Layer {
     std::vector<int> colmap_neg;   // first layers: column the same weight is SUBTRACTED from (-1: none)
     bool frag;                // packed in MFMA fragment order (GEMM layers) or row-major [N][Kpad] (decoder tail)
     size_t w_off, b_off;      // offsets (floats) into the packed arena
-    bool bf3 = false;         // also packed as three bf16 terms for gemm_tile_b3 (the FCBlocks' 1024-wide Linears)
-    size_t wb3_off = 0;       // offset (floats) of those planes in the arena: Npad * Kpad * 3 bf16
+    bool bf3 = false;         // also packed in bf16-MFMA operand order for gemm_tile_b3 (the FCBlocks' 1024-wide Linears)
+    size_t wb3_off = 0;       // offset (floats) of that copy in the arena: Npad * Kpad floats
 };
 
 struct Model {
@@ -254,7 +255,6 @@ Model *model_create(const r3d_config &cfg);
 int model_set_weight(Model *m, const char *key, const float *host, const int64_t *shape, int rank);
 int model_finalize(Model *m);
 Plan *plan_get(Model *a, Model *b);
-constexpr int B3_MIN_ROWS = 512;          // bf16x3 tiles (opt-in) are used for problems of at least this many rows
 constexpr int STAGE_SPILL_IN = 1 << 30;   // flag on a Plan::stages entry: the spilled rows of that problem
 constexpr int GEMM_SCHED_MAX_UNITS = 6;   // widest tile of r3d_gemm_f32: 6 x 32 rows
 struct SchedProb {

@@ -475,10 +475,13 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
 // bf16 rounding of what the previous ones left: 8 + 8 + 8 mantissa bits), and the six products a0b0, a0b1, a1b0,
 // a0b2, a1b1, a2b0 are accumulated in fp32, smallest first; the three dropped products are below 2^-24 of the
 // leading one.  Measured (tools/bf16x3_probe.cpp): the same error against float64 as an fp32 dot product.
-// Weights are split and packed on the host (r3d_model.cpp: [32-col block][K tile][k16 half][term][lane][8]);
-// activations are split when their fp32 staging registers are written to the LDS ring (a few VALU instructions per
-// thread and K tile), which then holds three bf16 planes.  Used for the M = B layers (the FCBlocks' 1024-wide
-// Linears), whose 32-row tiles are bound by the fp32 matrix rate; opt-in (r3d_api.cpp, R3D_BF16X3).
+// Weights stay fp32 in memory, packed so that a lane's eight consecutive k of a 16-deep MFMA step are two b128
+// loads (r3d_model.cpp: [32-col block][K tile][k16 half][4-float group][lane][4]) and are split in registers by the
+// wavefront that owns the column block - each weight is split once per tile, 5.5 VALU instructions per value, hidden
+// behind the matrix work - so the weight stream is 4 bytes per value, not the 6 of pre-split planes: a 32-row tile
+// is bound by that stream.  Activations are split when their fp32 staging registers are written to the LDS ring
+// (a few VALU instructions per thread and K tile), which then holds three bf16 planes.  Used for the FCBlocks'
+// 1024-wide Linears; opt-in (r3d_api.cpp, R3D_BF16X3).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -490,6 +493,25 @@ __device__ __forceinline__ unsigned b3_pack(float a, float b) {
 }
 __device__ __forceinline__ float b3_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float b3_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// eight fp32 values -> their three bf16 terms, packed as MFMA operands
+__device__ __forceinline__ void b3_split8(const f32x4 &a, const f32x4 &b, bf16x8 (&pl)[3]) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    u32x4 p0, p1, p2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned h = b3_pack(x[2 * i], x[2 * i + 1]);
+        const float r0 = x[2 * i] - b3_lo(h), r1 = x[2 * i + 1] - b3_hi(h);
+        const unsigned m = b3_pack(r0, r1);
+        p0[i] = h;
+        p1[i] = m;
+        p2[i] = b3_pack(r0 - b3_lo(m), r1 - b3_hi(m));
+    }
+    pl[0] = __builtin_bit_cast(bf16x8, p0);
+    pl[1] = __builtin_bit_cast(bf16x8, p1);
+    pl[2] = __builtin_bit_cast(bf16x8, p2);
+}
 
 template <int MI>
 __device__ __forceinline__ void gemm_tile_b3(ProbRef P, const int row0, const int col0, float *smem, long long *dbg) {
@@ -556,20 +578,20 @@ __device__ __forceinline__ void gemm_tile_b3(ProbRef P, const int row0, const in
             *reinterpret_cast<uint2 *>(d + 2 * PLANE) = make_uint2(l0, l1);
         }
     };
-    // ---- W fragments: three pre-split planes, [(n/32)][K tile][k16 half][term][lane][8 bf16]
+    // ---- W fragments: fp32, [(n/32)][K tile][k16 half][4-float group][lane][4]
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned short *>(P.wb3 + ((size_t)((col0 >> 5) + wave_u) * nk) * 3072), 0, nk * 6144, 0x00020000);
+        const_cast<float *>(P.wb3 + ((size_t)((col0 >> 5) + wave_u) * nk) * 1024), 0, nk * 4096, 0x00020000);
     const int w_voff = lane * 16;
-    struct WFrag { bf16x8 f[2][3]; };
+    struct WFrag { f32x4 f[2][2]; };
     WFrag wa, wb, wc;                        // three sets rotating: weights run two K tiles ahead (an iteration of
                                              // a 32-row tile is shorter than an L2 miss)
     auto load_w = [&](int kt, WFrag &dst) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                dst.f[h][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff + (h * 3 + p) * 1024, kt * 6144, 0));
+            for (int j = 0; j < 2; ++j)
+                dst.f[h][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff + (h * 2 + j) * 1024, kt * 4096, 0));
     };
     f32x16 acc[MI];
 #pragma unroll
@@ -598,6 +620,8 @@ __device__ __forceinline__ void gemm_tile_b3(ProbRef P, const int row0, const in
     __syncthreads();
     R3D_TSTAMP(1);
     int st_cur = 0;
+    // (pinning the split's VALU instructions between the MFMAs of the previous 16-deep step with
+    // sched_group_barrier is no faster than what the scheduler does by itself: measured)
     auto k_tile = [&](int kt, const WFrag &w_use, WFrag &w_load, Staged &stg) {
         const int st_next = st_cur == 2 ? 0 : st_cur + 1, st_next2 = st_next == 2 ? 0 : st_next + 1;
         commit_a(st_next2, stg);                 // tile kt+2
@@ -607,7 +631,8 @@ __device__ __forceinline__ void gemm_tile_b3(ProbRef P, const int row0, const in
         const float *s = smem + st_cur * SFB + a_frag;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            bf16x8 av[MI][3];
+            bf16x8 av[MI][3], wp[3];
+            b3_split8(w_use.f[h][0], w_use.f[h][1], wp);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -615,12 +640,12 @@ __device__ __forceinline__ void gemm_tile_b3(ProbRef P, const int row0, const in
                     av[mi][p] = *reinterpret_cast<const bf16x8 *>(s + p * PLANE + mi * 32 * B3_LD + h * 8);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][2], w_use.f[h][0], acc[mi], 0, 0, 0);
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][1], w_use.f[h][1], acc[mi], 0, 0, 0);
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][0], w_use.f[h][2], acc[mi], 0, 0, 0);
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][1], w_use.f[h][0], acc[mi], 0, 0, 0);
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][0], w_use.f[h][1], acc[mi], 0, 0, 0);
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][0], w_use.f[h][0], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][2], wp[0], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][1], wp[1], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][0], wp[2], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][1], wp[0], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][0], wp[1], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][0], wp[0], acc[mi], 0, 0, 0);
             }
         }
         __syncthreads();

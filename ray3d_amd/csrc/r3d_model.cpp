@@ -321,7 +321,7 @@ int model_finalize(Model *m) {
         if (L.bf3) {
             off = (off + 3) / 4 * 4;                       // 16-byte aligned planes
             L.wb3_off = off;
-            off += (size_t)L.Npad * L.Kpad * 3 / 2;
+            off += (size_t)L.Npad * L.Kpad;
         }
     }
     m->arena.assign(off, 0.0f);
@@ -360,26 +360,16 @@ int model_finalize(Model *m) {
         float *bd = m->arena.data() + L.b_off;
         for (int o = 0; o < L.N; ++o) bd[o] = (float)t[o];
         if (L.bf3) {
-            // the same folded weights as three bf16 terms, w = w0 + w1 + w2 exactly (each term the bf16 rounding of
-            // what the previous ones left), in v_mfma_f32_32x32x16_bf16 B-operand order:
-            // [32-col block][K tile][k16 half][term][lane][8], lane l holding column l % 32, k = 8 * (l / 32) + e
-            auto bf16_rne = [](float x) {
-                uint32_t u; memcpy(&u, &x, 4);
-                return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-            };
-            auto bf16_f = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
-            uint16_t *pl16 = reinterpret_cast<uint16_t *>(m->arena.data() + L.wb3_off);
+            // the same folded weights in v_mfma_f32_32x32x16_bf16 B-operand order (the kernel splits them into three
+            // bf16 terms in registers): [32-col block][K tile][k16 half][4-float group][lane][4], lane l holding
+            // column l % 32 and k = 8 * (l / 32) + 4 * group + e of the half
+            float *pk = m->arena.data() + L.wb3_off;
             for (int o = 0; o < L.N; ++o)
                 for (int k = 0; k < L.K; ++k) {
                     const float v = (float)((double)w[(size_t)o * L.cin + k] * s[o]);
-                    uint16_t tr[3];
-                    tr[0] = bf16_rne(v);
-                    const float r1 = v - bf16_f(tr[0]);
-                    tr[1] = bf16_rne(r1);
-                    tr[2] = bf16_rne(r1 - bf16_f(tr[1]));
-                    const int nb = o >> 5, kt = k >> 5, kin = k & 31, h = kin >> 4, lane = ((kin & 15) >> 3) * 32 + (o & 31), e = kin & 7;
-                    for (int p3 = 0; p3 < 3; ++p3)
-                        pl16[((((size_t)(nb * nk + kt) * 2 + h) * 3 + p3) * 64 + lane) * 8 + e] = tr[p3];
+                    const int nb = o >> 5, kt = k >> 5, kin = k & 31, h = kin >> 4, kk = kin & 15;
+                    const int lane = (kk >> 3) * 32 + (o & 31), j = (kk & 7) >> 2, e = kk & 3;
+                    pk[((((size_t)(nb * nk + kt) * 2 + h) * 2 + j) * 64 + lane) * 4 + e] = v;
                 }
         }
     }

@@ -255,7 +255,7 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
         }
         SchedProb sp{M, L.N, L.Kpad / BK, max_ks, enc_cap};
         if (q.nseg == 1 && q.seg[0].width < L.Kpad) sp.max_ks = 1;   // an operand narrower than its padded K: one bounded descriptor
-        if (L.bf3 && q.layer2 < 0 && q.enc_lut < 0 && M >= B3_MIN_ROWS) {   // bf16-matrix-core tiles: whole tiles of <= 128 rows, ~1.5x the iteration rate
+        if (L.bf3 && q.layer2 < 0 && q.enc_lut < 0) {   // bf16-matrix-core tiles: whole tiles of <= 128 rows, ~1.5x the iteration rate
             sp.max_ks = 1;
             sp.max_units = 4;
             sp.nk = (sp.nk * 2 + 2) / 3;

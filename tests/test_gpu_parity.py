@@ -369,12 +369,18 @@ def test_bf16x3_mode_keeps_parity(monkeypatch):
     from ray3d_amd import synth
     from oracle import oracle
     monkeypatch.setenv("R3D_BF16X3", "1")
-    # (the mode applies to problems of >= 512 rows, i.e. batches of >= 512 windows in these layers: the fixtures'
-    # 4-8 windows would not exercise it, hence the oracle)
+    # a reference fixture (outputs of the reference's PyTorch-CPU forward) ...
+    z, mc = load_model_fixture("j17_rf27_s3")
+    pos, trj, _, _ = build_modules(mc)
+    with torch.no_grad():
+        got = ray3d_amd.Ray3DLifter(pos, trj).eval()(torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["param"]).cuda())
+    want = z["out_pos"] + z["out_trj"]
+    assert np.abs(got.cpu().numpy() - want).max() <= tol_for(want)
+    # ... and a batch with multi-unit tiles against the oracle
     mc2 = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
     pos2, trj2, (cp2, sp2), (ct2, st2) = build_modules(mc2)
     lifter = ray3d_amd.Ray3DLifter(pos2, trj2).eval()
-    xb = synth.synth_rays(600, cp2, seed=41)          # >= B3_MIN_ROWS (512) rows: the mode is active
+    xb = synth.synth_rays(600, cp2, seed=41)
     pb = synth.synth_param(600, seed=42)
     with torch.no_grad():
         out = lifter(torch.from_numpy(xb).cuda(), torch.from_numpy(pb).cuda()).cpu().numpy()
