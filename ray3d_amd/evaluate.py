@@ -5,7 +5,7 @@ Reproduces the behaviour of ``Trainer.evaluate_core`` / ``Trainer.evaluate``
 
 * a clip is edge-padded by (RF-1)//2 frames per side (lib/dataloader/generators.py:213-216) and
   window i covers padded frames [i, i+RF) (trainer.py:47-58) - the windows are gathered inside
-  the prologue kernel (`Ray3DLifter.forward_clip`), not materialised;
+  the first-layer tiles (`Ray3DLifter.forward_clip`), not materialised;
 * the camera row [height, pitch] is shared by all windows of the clip (trainer.py:297,324);
 * prediction = pos + trj, optionally averaged with the mirrored pass (trainer.py:299-302,338-353);
 * prediction and ground truth go to world coordinates in float64 (trainer.py:355-364) and the five
