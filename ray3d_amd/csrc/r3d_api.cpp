@@ -230,7 +230,33 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         if ((n_enc != 0) != (ss.kind == STAGE_ENC)) { set_error("internal: schedule and plan disagree on the launch kind"); return R3D_ERR_STATE; }
         const char *kname = ss.kind == STAGE_ENC ? "r3d_gemm_enc_f32" : "r3d_gemm_f32";
         if ((e = rec.begin(kname, stage_no, ss.nwg, ss.flops, ss.bytes)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+#ifdef R3D_TIMING
+        // development build only (tools/build_probe.sh): phase stamps of the first tiles of launch $R3D_TIMING_STAGE
+        static long long *timing_buf = nullptr;
+        const char *tstage = getenv("R3D_TIMING_STAGE");
+        const bool timed = tstage && atoi(tstage) == (int)si;
+        if (timed) {
+            if (!timing_buf) (void)hipMalloc((void **)&timing_buf, (1024 + 4 * 1024) * 8 + 65536);
+            (void)hipMemsetAsync(timing_buf, 0, (1024 + 4 * 1024) * 8 + 65536, stream);
+            la.dbg = timing_buf;
+        }
+#endif
         if ((e = launch_gemm_stage(la, ss.nwg, ss.kind, stream)) != hipSuccess) return hip_fail(e, "launch r3d_gemm_f32");
+#ifdef R3D_TIMING
+        if (timed) {
+            (void)hipStreamSynchronize(stream);
+            std::vector<long long> ht(16 * 64);
+            (void)hipMemcpy(ht.data(), timing_buf + 6144, ht.size() * 8, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[timing] launch %zu: wg tile | phase lengths in us (100 MHz wall clock)\n", si);
+            for (int w = 0; w < 16 && w < ss.nwg; ++w)
+                for (int t = 0; t < 8; ++t) {
+                    const long long *q = &ht[w * 64 + t * 8];
+                    if (!q[0]) continue;
+                    fprintf(stderr, "  wg %2d tile %d: %6.2f %6.2f %6.2f %6.2f | total %6.2f\n", w, t, (q[1] - q[0]) / 100.0,
+                            (q[2] - q[1]) / 100.0, (q[3] - q[2]) / 100.0, (q[4] - q[3]) / 100.0, (q[4] - q[0]) / 100.0);
+                }
+        }
+#endif
         if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
         ++stage_no;
     }

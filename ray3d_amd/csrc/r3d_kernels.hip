@@ -9,11 +9,11 @@
 //                                          BatchNorm folded; split-K variants for the small launches;
 //                        gemm_tile<PAIR>   a pyramid level's 3-tap and 1x1 convolutions (rie.py:94-97), the
 //                                          intermediate tile staying in LDS;
-//                        first_level_tile  expand_conv on the gathered input (window gather,
+//                        first_level_run   expand_conv on the gathered input (window gather,
 //                                          lib/train_val/trainer.py:47-58; body-part grouping and the
 //                                          positional / temporal differences of rie.py:290-357 folded into the
 //                                          weights) + the first pyramid level, for 32 output rows.
-//  r3d_gemm_enc_f32    fallback for configurations first_level_tile does not cover (one-level architectures,
+//  r3d_gemm_enc_f32    fallback for configurations first_level_run does not cover (one-level architectures,
 //                      more than 256 channels): expand_conv / GlobalInfo.fc_1 with the gather fused.
 //  r3d_decode_f32      last Linear of the decoders + joint reassembly (rie.py:409-432) + trajectory
 //                      add (lib/train_val/trainer.py:353).
@@ -805,7 +805,7 @@ __device__ __forceinline__ void enc_tile(ProbRef P, const int row0, const int co
 
 // ------------------------------------------------------------------------------------ first level in one tile
 //
-// first_level_tile: expand_conv (on the gathered input), the level-1 3-tap convolution and its 1x1 convolution
+// first_level_run: expand_conv (on the gathered input), the level-1 3-tap convolution and its 1x1 convolution
 // for 32 output rows, without the 96 x C intermediate ever leaving the CU (lib/model/rie.py:85-97 up to the end of
 // the first loop iteration).  As separate launches the expand_conv output - the largest activation of the network,
 // 127 MB at B = 256 - was written by a launch that did little else than write it, and read back by the next.
@@ -822,10 +822,15 @@ constexpr int FL_LUT_OFF = FL_H0_FLOATS + FL_R2_FLOATS;
 constexpr int FL_LUT_INTS = 320;                           // K0 + K0/4, K0 <= 256
 static_assert((FL_LUT_OFF + FL_LUT_INTS) * 4 <= GEMM_LDS_BYTES, "the fused first level fits the GEMM kernel's LDS allocation");
 
+// A workgroup's consecutive tiles of one problem are handled as a run: the raw values of the NEXT tile's first
+// gather pass are requested while this tile's 3-tap loop runs and wait in registers until the gather region is free
+// again (phase stamps: a body-part tile spent 9.8 us in the expand phase for 2.9 us of MFMA work, most of it the
+// latency of the scattered loads).
 template <int MI0>   // expand_conv rows per pass / 32: 3 (K0 <= 64) or 1
-__device__ __forceinline__ void first_level_tile(ProbRef P, const int row0, const bool new_prob, float *smem, long long *dbg) {
-    R3D_TSTAMP(0);
+__device__ __forceinline__ void first_level_run(ProbRef P, const int4 *tile_list, const int ntiles, const bool new_prob, float *smem,
+                                                long long *dbg_base) {
     constexpr int R0 = MI0 * 32, NA = (R0 + 63) / 64;
+    constexpr int NQ = MI0 == 3 ? 2 : 8;                     // K tiles of one gather pass (K0 <= 64 / K0 <= 256)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6;
@@ -853,11 +858,9 @@ __device__ __forceinline__ void first_level_tile(ProbRef P, const int row0, cons
     __amdgpu_buffer_rsrc_t w0rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(P.w + ((size_t)wave_u * nk0) * 1024), 0, nk0 * 4096, 0x00020000);
     const float bias0 = gload1(P.bias + wave * 32 + li), slope0 = P.slope;
-#pragma unroll 1
-    for (int pass = 0; pass < 3 / MI0; ++pass) {
-        const int prow0 = 3 * row0 + pass * R0;               // first expand_conv row of the pass
-        unsigned b_first[NA], b_cur[NA];
-        bool on[NA];
+    unsigned b_first[NA], b_cur[NA];
+    bool on[NA];
+    auto row_bases = [&](int prow0) {                        // prow0: first expand_conv row of a pass
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int vr = srow + 64 * i;
@@ -869,31 +872,61 @@ __device__ __forceinline__ void first_level_tile(ProbRef P, const int row0, cons
             b_first[i] = (wbase + (unsigned)(t3 * 3 * P.enc_jf)) * 4;
             b_cur[i] = (wbase + (unsigned)P.enc_cur) * 4;
         }
-        struct Raw { f32x4 a[NA]; };
-        auto issue = [&](int kt, Raw &r) {
-            const int k = kt * BK + a_kq;
-            const int4 o1 = *reinterpret_cast<const int4 *>(lut1 + k);
-            const bool cur = lutk[k >> 2] != 0;
-            const int c1[4] = {o1.x, o1.y, o1.z, o1.w};
+    };
+    struct Raw { f32x4 a[NA]; };
+    auto issue = [&](int kt, Raw &r) {
+        const int k = kt * BK + a_kq;
+        const int4 o1 = *reinterpret_cast<const int4 *>(lut1 + k);
+        const bool cur = lutk[k >> 2] != 0;
+        const int c1[4] = {o1.x, o1.y, o1.z, o1.w};
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                if (!on[i]) continue;
-                const unsigned b = cur ? b_cur[i] : b_first[i];
+        for (int i = 0; i < NA; ++i) {
+            if (!on[i]) continue;
+            const unsigned b = cur ? b_cur[i] : b_first[i];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    r.a[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, b + (unsigned)c1[e], 0, 0));
-            }
-        };
-        auto commit = [&](int kt, const Raw &r) {
+            for (int e = 0; e < 4; ++e)
+                r.a[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, b + (unsigned)c1[e], 0, 0));
+        }
+    };
+    auto commit = [&](int kt, const Raw &r) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                if (!on[i]) continue;
-                *reinterpret_cast<f32x4 *>(r2 + (srow + 64 * i) * ldt + kt * BK + a_kq) = r.a[i];
-            }
-        };
-        load_frag(w0rsrc, 0, rb);
-        load_frag(w0rsrc, 1 < nk0 - 1 ? 1 : nk0 - 1, rbn);
-        {
+        for (int i = 0; i < NA; ++i) {
+            if (!on[i]) continue;
+            *reinterpret_cast<f32x4 *>(r2 + (srow + 64 * i) * ldt + kt * BK + a_kq) = r.a[i];
+        }
+    };
+    Raw gq[NQ];                                              // the first pass of the coming tile
+    auto issue_first_pass = [&](int tile_row0) {
+        row_bases(3 * tile_row0);
+#pragma unroll
+        for (int kt = 0; kt < NQ; ++kt)
+            if (kt < nk0) issue(kt, gq[kt]);
+    };
+    issue_first_pass(__builtin_amdgcn_readfirstlane(tile_list[0].y));
+#pragma unroll 1
+  for (int ti = 0; ti < ntiles; ++ti) {
+    const int row0 = __builtin_amdgcn_readfirstlane(tile_list[ti].y);
+    const int next_row0 = ti + 1 < ntiles ? __builtin_amdgcn_readfirstlane(tile_list[ti + 1].y) : -1;
+#ifdef R3D_TIMING
+    long long *dbg = dbg_base && ti < 8 ? dbg_base + ti * 8 : nullptr;
+#else
+    long long *dbg = nullptr;
+    (void)dbg;
+#endif
+    R3D_TSTAMP(0);
+#pragma unroll 1
+    for (int pass = 0; pass < 3 / MI0; ++pass) {
+        if (pass > 0 || ti == 0) {                           // (a later tile's first fragments were requested before
+            load_frag(w0rsrc, 0, rb);                        //  the previous tile's epilogue)
+            load_frag(w0rsrc, 1 < nk0 - 1 ? 1 : nk0 - 1, rbn);
+        }
+        if (pass == 0) {
+            // (b_first / b_cur / on describe this tile's rows: set when its loads were issued)
+#pragma unroll
+            for (int kt = 0; kt < NQ; ++kt)
+                if (kt < nk0) commit(kt, gq[kt]);
+        } else {
+            row_bases(3 * row0 + pass * R0);
             Raw g0, g1;
             issue(0, g0);
             int kt = 0;
@@ -906,6 +939,9 @@ __device__ __forceinline__ void first_level_tile(ProbRef P, const int row0, cons
             if (kt < nk0) commit(kt, g0);
         }
         __syncthreads();
+        // the next tile's raw values: requested behind this tile's last gather, in front of its matrix work, so that
+        // no weight load queues behind them for long (loads return in order); consumed after this tile's epilogue
+        if (pass + 1 == 3 / MI0 && next_row0 >= 0) issue_first_pass(next_row0);
         f32x16 acc0[MI0];
 #pragma unroll
         for (int mi = 0; mi < MI0; ++mi)
@@ -1029,6 +1065,10 @@ __device__ __forceinline__ void first_level_tile(ProbRef P, const int row0, cons
         }
     }
     R3D_TSTAMP(3);
+    if (next_row0 >= 0) {
+        load_frag(w0rsrc, 0, rb);
+        load_frag(w0rsrc, 1 < nk0 - 1 ? 1 : nk0 - 1, rbn);
+    }
     // ---- epilogue: + centre (causal: last) expand_conv row (still in H0), rows transposed through the second region
     {
         const float bias2 = gload1(P.bias3 + wave * 32 + li), slope2 = P.slope3;
@@ -1061,6 +1101,7 @@ __device__ __forceinline__ void first_level_tile(ProbRef P, const int row0, cons
         __syncthreads();
     }
     R3D_TSTAMP(4);
+  }
 }
 
 template <bool ENC>
@@ -1105,9 +1146,17 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                 default: enc_tile<3>(P, row0, col0, new_prob, smem, dbg); break;
             }
         } else {
-            if (P.w3 != nullptr) {       // first level of the pyramid, fused (32 output rows per tile)
-                if (P.K <= 64) first_level_tile<3>(P, row0, new_prob, smem, dbg);
-                else first_level_tile<1>(P, row0, new_prob, smem, dbg);
+            if (P.w3 != nullptr) {       // first level of the pyramid, fused (32 output rows per tile): this
+                int n = 1;               // workgroup's consecutive tiles of the problem as one run
+                while (t + n < t1 && __builtin_amdgcn_readfirstlane(args->tiles[t + n].x & 0xff) == pi) ++n;
+#ifdef R3D_TIMING
+                long long *run_dbg = dbg_base && t - t0 < 8 ? dbg_base + (t - t0) * 8 : nullptr;
+#else
+                long long *run_dbg = nullptr;
+#endif
+                if (P.K <= 64) first_level_run<3>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                else first_level_run<1>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                t += n - 1;
                 continue;
             }
             if (P.wb3 != nullptr) {      // fp32 on the bf16 matrix cores (whole tiles of <= 128 rows)
