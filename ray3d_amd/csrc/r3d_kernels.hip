@@ -896,13 +896,13 @@ __device__ __forceinline__ void first_level_run(ProbRef P, const int4 *tile_list
         }
     };
     Raw gq[NQ];                                              // the first pass of the coming tile
-    auto issue_first_pass = [&](int tile_row0) {
-        row_bases(3 * tile_row0);
+    auto issue_pass = [&](int prow0) {
+        row_bases(prow0);
 #pragma unroll
         for (int kt = 0; kt < NQ; ++kt)
             if (kt < nk0) issue(kt, gq[kt]);
     };
-    issue_first_pass(__builtin_amdgcn_readfirstlane(tile_list[0].y));
+    issue_pass(3 * __builtin_amdgcn_readfirstlane(tile_list[0].y));
 #pragma unroll 1
   for (int ti = 0; ti < ntiles; ++ti) {
     const int row0 = __builtin_amdgcn_readfirstlane(tile_list[ti].y);
@@ -920,28 +920,15 @@ __device__ __forceinline__ void first_level_run(ProbRef P, const int4 *tile_list
             load_frag(w0rsrc, 0, rb);                        //  the previous tile's epilogue)
             load_frag(w0rsrc, 1 < nk0 - 1 ? 1 : nk0 - 1, rbn);
         }
-        if (pass == 0) {
-            // (b_first / b_cur / on describe this tile's rows: set when its loads were issued)
+        // (this pass's raw values are in registers: requested one pass - or one tile - ago)
 #pragma unroll
-            for (int kt = 0; kt < NQ; ++kt)
-                if (kt < nk0) commit(kt, gq[kt]);
-        } else {
-            row_bases(3 * row0 + pass * R0);
-            Raw g0, g1;
-            issue(0, g0);
-            int kt = 0;
-            for (; kt + 1 < nk0; kt += 2) {
-                issue(kt + 1, g1);
-                commit(kt, g0);
-                if (kt + 2 < nk0) issue(kt + 2, g0);
-                commit(kt + 1, g1);
-            }
-            if (kt < nk0) commit(kt, g0);
-        }
+        for (int kt = 0; kt < NQ; ++kt)
+            if (kt < nk0) commit(kt, gq[kt]);
         __syncthreads();
-        // the next tile's raw values: requested behind this tile's last gather, in front of its matrix work, so that
-        // no weight load queues behind them for long (loads return in order); consumed after this tile's epilogue
-        if (pass + 1 == 3 / MI0 && next_row0 >= 0) issue_first_pass(next_row0);
+        // the next pass's / the next tile's raw values: requested in front of this pass's matrix work, so that no
+        // weight load queues behind them for long (loads return in order); consumed once the gather region is free
+        if (pass + 1 < 3 / MI0) issue_pass(3 * row0 + (pass + 1) * R0);
+        else if (next_row0 >= 0) issue_pass(3 * next_row0);
         f32x16 acc0[MI0];
 #pragma unroll
         for (int mi = 0; mi < MI0; ++mi)
