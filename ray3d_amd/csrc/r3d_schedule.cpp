@@ -264,10 +264,10 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
             const Model *mm = pl->m[q.model];
             sp.max_ks = 1;
             sp.max_units = 1;
-            // (+ the gathers of the raw input, one per pass over the tile's 96 first-layer rows: one pass when the
-            // operand tile is narrow enough to hold them all, three otherwise; ~5 iterations' time each, measured:
-            // 47 us for a body-part tile, 74 us for the trajectory model's at 2.1 GHz)
-            sp.nk2 = 2 * sp.nk + mm->layers[q.layer2].Kpad / BK + mm->layers[q.layer3].Kpad / BK + 5 * (L.Kpad <= 64 ? 1 : 3);
+            // (+ the gather passes over the tile's 96 first-layer rows and the phase changes: one pass when the operand
+            // tile is narrow enough to hold all rows, three otherwise; 5 / 12 iterations' time by the phase stamps:
+            // 45.5 us for a body-part tile, 67.5 us for the trajectory model's at 2.1 GHz)
+            sp.nk2 = 2 * sp.nk + mm->layers[q.layer2].Kpad / BK + mm->layers[q.layer3].Kpad / BK + (L.Kpad <= 64 ? 5 : 12);
         } else if (q.layer2 >= 0) {                // fused pair: whole tiles of <= 128 rows, no split
             sp.max_ks = 1;
             sp.max_units = 4;
