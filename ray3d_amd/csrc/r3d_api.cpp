@@ -247,6 +247,16 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             (void)hipStreamSynchronize(stream);
             std::vector<long long> ht(16 * 64);
             (void)hipMemcpy(ht.data(), timing_buf + 6144, ht.size() * 8, hipMemcpyDeviceToHost);
+            std::vector<long long> hw(4 * 1024);
+            (void)hipMemcpy(hw.data(), timing_buf + 1024, hw.size() * 8, hipMemcpyDeviceToHost);
+            long long w0 = 1LL << 62, w1 = 0, s1 = 0, e0 = 1LL << 62;
+            for (int w = 0; w < ss.nwg && w < 1024; ++w) {
+                w0 = std::min(w0, hw[w * 4 + 2]); s1 = std::max(s1, hw[w * 4 + 2]);
+                w1 = std::max(w1, hw[w * 4 + 3]); e0 = std::min(e0, hw[w * 4 + 3]);
+            }
+            fprintf(stderr, "[timing] launch %zu: first workgroup start -> last end %.2f us; starts spread over %.2f us, ends over %.2f us; "
+                    "wg 0: start -> first tile entry %.2f us\n", si, (w1 - w0) / 100.0, (s1 - w0) / 100.0, (w1 - e0) / 100.0,
+                    (ht[0] - hw[2]) / 100.0);
             fprintf(stderr, "[timing] launch %zu: wg tile | phase lengths in us (100 MHz wall clock)\n", si);
             for (int w = 0; w < 16 && w < ss.nwg; ++w)
                 for (int t = 0; t < 8; ++t) {
