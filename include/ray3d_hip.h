@@ -119,7 +119,9 @@ int r3d_forward_pair(r3d_model *pos, r3d_model *trj, const r3d_input *in, int64_
 /* ---- instrumentation (bench.py / tests) ---- */
 
 /* When enabled, the next forward brackets every kernel launch with hipEvents on the launch
- * stream; r3d_profile_read then synchronises and returns per-launch records. */
+ * stream; r3d_profile_read then synchronises and returns per-launch records.  The first record
+ * ("r3d_event_pair", stage -1) is an empty bracket: the cost of the two event records themselves,
+ * which every other record's `ms` includes. */
 typedef struct {
     char kernel[48];  /* kernel family name as rocprofv3 shows it (prefix)                  */
     int32_t stage;    /* position in the launch sequence                                     */

@@ -122,6 +122,9 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
     Recorder rec{a, stream};
     hipError_t e;
     int stage_no = 0;
+    // profiling: an empty bracket first - what two event records cost by themselves on this stream (stage -1)
+    if ((e = rec.begin("r3d_event_pair", -1, 0, 0.0, 0.0)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+    if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
 
     // ---- pointwise prologue: uv -> rays (UV mode), camera embeddings
     const float *x_rays = in->x_dev;
