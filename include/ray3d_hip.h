@@ -9,8 +9,14 @@
  * Conventions: plain C, int status codes (0 = ok, <0 = error, text via r3d_last_error()),
  * no exceptions cross the boundary.  All *_dev pointers are device (HBM) pointers owned by the
  * caller; the library owns only its packed weights.  A handle is bound to the HIP device that
- * was current at r3d_finalize(); it is not thread-safe, different handles are independent.
+ * was current at r3d_finalize().  Threading: a handle - and a (pos, trj) pair used together - must
+ * be driven by one thread at a time (its launch plans, per-batch-size tile schedules and profiling
+ * records are unguarded caches); different handles are independent and may be used concurrently
+ * (the registry that maps handle pairs to plans is mutex-guarded, r3d_last_error() is thread-local).
  * Every call enqueues on the given hipStream_t (passed as void*) and returns without syncing.
+ * The first forward of a new batch size builds and uploads a tile schedule (hipMalloc + blocking
+ * hipMemcpy): call r3d_prepare() for that size beforehand when the forward is to be captured into
+ * a hipGraph or must not stall.
  */
 #ifndef RAY3D_HIP_H
 #define RAY3D_HIP_H
@@ -104,6 +110,11 @@ typedef struct {
 /* Bytes of scratch HBM a forward of B windows needs (either model may be NULL). */
 size_t r3d_workspace_bytes(const r3d_model *pos, const r3d_model *trj, int64_t B);
 
+/* Everything a forward of B windows needs besides its arguments - the launch plan of the pair and the tile schedule
+ * of this batch size, uploaded - so that the forward itself only enqueues kernels (hipGraph capture, latency).
+ * Either model may be NULL.  The library keeps the schedules of the 64 most recently used batch sizes per pair. */
+int r3d_prepare(r3d_model *pos, r3d_model *trj, int64_t B);
+
 /* One network, exactly the reference module's forward:
  *   pos: out_dev (B,1,J,3)   lib/model/rie.py:284-434
  *   trj: out_dev (B,1,1,3)   lib/model/rie.py:518-559 */
@@ -159,6 +170,21 @@ int r3d_clip_metrics(const float *pred_dev, const float *gt_dev, int64_t n_frame
 
 const char *r3d_last_error(void);
 const char *r3d_version(void);
+
+/* ---- test hooks (tests/test_host.py; host only, no device needed) ---- */
+
+/* Builds the static tile schedule of ONE launch for `nprob` GEMM problems (rows M[i], columns N[i], nk[i] K tiles of
+ * 32, largest split-K factor max_ks[i], cap on 32-row units per tile max_units[i]) on `nwg` workgroups and verifies
+ * that the tiles cover every (32-row unit, 64-column granule) exactly once within the kernel's tile-shape rules.
+ * Returns 0, or a negative code naming the first violated rule. */
+int r3d_debug_schedule_check(int nprob, const int *M, const int *N, const int *nk, const int *max_ks,
+                             const int *max_units, int nwg, int enc, int *out_grid, int *out_tiles,
+                             double *out_imbalance);
+
+/* The whole forward's tile lists for `batch` windows on `nwg` CUs: every cell of every problem computed exactly once
+ * over all launches, every consumer's launch after all of its producers' tiles.  *spilled = first-level rows that
+ * run one launch late (row spill).  Returns 0 or a negative code. */
+int r3d_debug_plan_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg, int *launches, int *spilled);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,7 @@ EXPORTS = (
     "r3d_create", "r3d_destroy", "r3d_num_weights", "r3d_weight_key", "r3d_weight_shape",
     "r3d_set_weight", "r3d_finalize", "r3d_workspace_bytes", "r3d_forward", "r3d_forward_pair",
     "r3d_profile_enable", "r3d_profile_read", "r3d_clip_metrics", "r3d_last_error", "r3d_version",
+    "r3d_prepare", "r3d_debug_schedule_check", "r3d_debug_plan_check",
 )
 METRIC_NAMES = ("mpjpe", "p_mpjpe", "n_mpjpe", "velocity", "root")     # R3D_METRIC_* order
 METRIC_OUT_DOUBLES = 5 * (1 + 128)                                      # R3D_METRIC_OUT_DOUBLES
@@ -72,6 +73,7 @@ def load():
     lib.r3d_workspace_bytes.restype = C.c_size_t
     lib.r3d_forward.argtypes = [vp, C.POINTER(Input), C.c_int64, vp, vp, C.c_size_t, vp]
     lib.r3d_forward_pair.argtypes = [vp, vp, C.POINTER(Input), C.c_int64, vp, vp, vp, C.c_size_t, vp]
+    lib.r3d_prepare.argtypes = [vp, vp, C.c_int64]
     lib.r3d_profile_enable.argtypes = [vp, C.c_int]
     lib.r3d_profile_read.argtypes = [vp, C.POINTER(LaunchRecord), C.c_int]
     lib.r3d_clip_metrics.argtypes = [vp, vp, C.c_int64, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp, vp]
@@ -146,6 +148,11 @@ class Handle:
 
 def workspace_bytes(pos: Optional[Handle], trj: Optional[Handle], batch: int) -> int:
     return int(load().r3d_workspace_bytes(pos.ptr if pos else None, trj.ptr if trj else None, batch))
+
+
+def prepare(pos: Optional[Handle], trj: Optional[Handle], batch: int):
+    """r3d_prepare: plan + tile schedule of this batch size, uploaded (outside of any stream capture)."""
+    check(load().r3d_prepare(pos.ptr if pos else None, trj.ptr if trj else None, batch), "r3d_prepare")
 
 
 def make_input(mode, x_ptr, window_stride, param_ptr, param_stride, cam_ptr=None, cam_stride=0) -> Input:

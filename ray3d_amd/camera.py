@@ -4,7 +4,7 @@ Counterpart of the parts of ``CameraInfoPacket`` that sit on the lifting path
 (lib/camera/camera.py:210-277 constructor, :308-316 pitch, :325-345 normalised frame,
 :390-410 world<->normalised, :423-471 uv -> ray).  Everything per-camera is a handful of float64
 numbers computed once on the host; everything per-keypoint happens on the GPU
-(`Ray3DLifter.forward_uv`, kernel r3d_encode_f32), fed by :meth:`Camera.cam_row`.
+(`Ray3DLifter.forward_uv`: the first-level gather of r3d_gemm_f32 encodes the rays it stages), fed by :meth:`Camera.cam_row`.
 
 "Normalised" follows the reference's meaning: the camera frame rotated about its
 x axis by the camera pitch and shifted by the camera height - NOT unit-length rays.

@@ -362,6 +362,16 @@ size_t r3d_workspace_bytes(const r3d_model *pos, const r3d_model *trj, int64_t B
     return workspace_need(plan_get(a, b), B, a->RF, a->RF, a->cfg.num_joints);
 }
 
+int r3d_prepare(r3d_model *pos, r3d_model *trj, int64_t B) {
+    Model *p = reinterpret_cast<Model *>(pos), *t = reinterpret_cast<Model *>(trj);
+    Model *a = p ? p : t, *b = p ? t : nullptr;
+    if (!a || B <= 0) { set_error("r3d_prepare: no model given or B <= 0"); return R3D_ERR_ARG; }
+    for (Model *m : {a, b})
+        if (m && (!m->finalized || m->dirty)) { set_error("r3d_prepare called before r3d_finalize (or weights changed since)"); return R3D_ERR_STATE; }
+    if (b && !same_input_shape(a, b)) { set_error("pos and trj models disagree on J / F / levels / extrinsic_dim"); return R3D_ERR_ARG; }
+    return schedule_get(plan_get(a, b), B, device_cu_count()) ? R3D_OK : R3D_ERR_HIP;
+}
+
 int r3d_forward(r3d_model *m, const r3d_input *in, int64_t B, float *out_dev, void *ws, size_t ws_bytes, void *stream) {
     Model *mm = reinterpret_cast<Model *>(m);
     if (!mm) { set_error("r3d_forward: null model"); return R3D_ERR_ARG; }
@@ -400,7 +410,7 @@ int r3d_profile_read(r3d_model *m, r3d_launch_record *records, int capacity) {
     return n;
 }
 
-// Test hook (not part of include/ray3d_hip.h): build the static schedule of one launch on the host and verify
+// Test hook: build the static schedule of one launch on the host and verify
 // that its tiles cover every (32-row unit, 64-column granule) of every problem exactly once within the
 // kernel's tile-shape limits.  Returns 0 or a negative code naming the first violated rule.
 int r3d_debug_schedule_check(int nprob, const int *M, const int *N, const int *nk, const int *max_ks, const int *max_units,

@@ -168,8 +168,9 @@ struct Model {
     };
     std::vector<Rec> recs;
     int nrec = 0;
-    // cached plans keyed by the partner model (nullptr for single)
-    std::map<const Model *, struct Plan *> plans;
+    // Launch plans live in a registry keyed by the (never reused) ids of the models they join - r3d_plan.cpp;
+    // a model's destructor drops every plan that names it, so no plan outlives a partner.
+    uint64_t id = 0;
     ~Model();
 };
 
@@ -255,6 +256,7 @@ Model *model_create(const r3d_config &cfg);
 int model_set_weight(Model *m, const char *key, const float *host, const int64_t *shape, int rank);
 int model_finalize(Model *m);
 Plan *plan_get(Model *a, Model *b);
+void plans_drop(const Model *m);   // delete every cached plan (and its schedules) that names `m`
 constexpr int STAGE_SPILL_IN = 1 << 30;   // flag on a Plan::stages entry: the spilled rows of that problem
 constexpr int GEMM_SCHED_MAX_UNITS = 6;   // widest tile of r3d_gemm_f32: 6 x 32 rows
 struct SchedProb {

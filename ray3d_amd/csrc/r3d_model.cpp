@@ -4,6 +4,7 @@
 // Reference constructors this mirrors: lib/model/rie.py:13-63 (TemporalBlock), :108-120 (Linear),
 // :138-157 (FCBlock), :178-253 (RIEModel), :443-494 (RIETrajectoryModel),
 // lib/model/embedding.py:4-13 (Embedding).  Eval-mode BatchNorm1d: y = (x-mean)/sqrt(var+1e-5)*g+b.
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -119,7 +120,7 @@ struct Grammar {
 }  // namespace
 
 Model::~Model() {
-    for (auto &kv : plans) delete kv.second;
+    plans_drop(this);
     if (d_arena) (void)hipFree(d_arena);
     if (d_iarena) (void)hipFree(d_iarena);
     for (auto &r : recs) {
@@ -147,6 +148,8 @@ Model *model_create(const r3d_config &cfg) {
     if (cfg.causal != 0 && cfg.causal != 1) { set_error("causal must be 0 or 1 (got %d)", cfg.causal); return nullptr; }
 
     Model *m = new Model();
+    static std::atomic<uint64_t> next_id{1};
+    m->id = next_id.fetch_add(1);
     m->cfg = cfg;
     {
         const char *e = getenv("R3D_BF16X3");
@@ -380,14 +383,16 @@ int model_finalize(Model *m) {
     if (m->d_arena && m->device != dev) {
         (void)hipFree(m->d_arena); (void)hipFree(m->d_iarena);
         m->d_arena = nullptr; m->d_iarena = nullptr;
-        for (auto &kv : m->plans) delete kv.second;
-        m->plans.clear();
+        plans_drop(m);
     }
     m->device = dev;
     if (!m->d_arena) {
         if ((e = hipMalloc((void **)&m->d_arena, m->arena.size() * sizeof(float))) != hipSuccess) return hip_fail(e, "hipMalloc(weights)");
         if ((e = hipMalloc((void **)&m->d_iarena, m->iarena.size() * sizeof(int))) != hipSuccess) return hip_fail(e, "hipMalloc(luts)");
     }
+    // a re-finalisation overwrites weights that forwards in flight on any stream may still be reading (a blocking
+    // hipMemcpy only orders against the null stream)
+    if (m->finalized && (e = hipDeviceSynchronize()) != hipSuccess) return hip_fail(e, "hipDeviceSynchronize");
     if ((e = hipMemcpy(m->d_arena, m->arena.data(), m->arena.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "hipMemcpy(weights)");
     if ((e = hipMemcpy(m->d_iarena, m->iarena.data(), m->iarena.size() * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "hipMemcpy(luts)");
     m->finalized = true;

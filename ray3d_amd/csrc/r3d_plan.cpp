@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 
 #include "r3d_internal.hpp"
 
@@ -338,12 +339,32 @@ static Plan *build_plan(const Model *a, const Model *b) {
     return pl;
 }
 
+// Plans are cached per pair of model ids.  Ids are unique for the life of the process (a pointer is not: a model
+// freed and another allocated at its address must not inherit the plan, whose layer indices and K paddings belong to
+// the old configuration), and a model's destructor / re-finalisation on another device drops every plan naming it.
+static std::mutex g_plans_mutex;
+static std::map<std::pair<uint64_t, uint64_t>, Plan *> g_plans;
+
 Plan *plan_get(Model *a, Model *b) {
-    auto it = a->plans.find(b);
-    if (it != a->plans.end()) return it->second;
+    std::lock_guard<std::mutex> lock(g_plans_mutex);
+    const auto key = std::make_pair(a->id, b ? b->id : (uint64_t)0);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) return it->second;
     Plan *p = build_plan(a, b);
-    a->plans[b] = p;
+    g_plans[key] = p;
     return p;
+}
+
+void plans_drop(const Model *m) {
+    std::lock_guard<std::mutex> lock(g_plans_mutex);
+    for (auto it = g_plans.begin(); it != g_plans.end();) {
+        if (it->first.first == m->id || it->first.second == m->id) {
+            delete it->second;
+            it = g_plans.erase(it);
+        } else {
+            ++it;
+        }
+    }
 }
 
 }  // namespace r3d

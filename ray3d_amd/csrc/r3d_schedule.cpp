@@ -365,9 +365,14 @@ const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t
 
 Schedule *schedule_get(Plan *pl, int64_t B, int nwg) {
     auto it = pl->schedules.find(B);
-    if (it != pl->schedules.end()) return it->second;
-    // bound the cache: evict the oldest batch size (the caller synchronises nothing here; a schedule
-    // is only freed after 64 newer batch sizes were used, by which time its launches have long retired)
+    if (it != pl->schedules.end()) {
+        // least recently USED goes first: a hit moves the size to the back of the queue
+        auto pos = std::find(pl->schedule_lru.begin(), pl->schedule_lru.end(), B);
+        if (pos != pl->schedule_lru.end() && pos + 1 != pl->schedule_lru.end()) std::rotate(pos, pos + 1, pl->schedule_lru.end());
+        return it->second;
+    }
+    // bound the cache at 64 batch sizes: the least recently used one goes; its launches may still be in flight on
+    // any stream, hence the device-wide synchronisation before its tile lists are freed
     if (pl->schedule_lru.size() >= 64) {
         const int64_t old = pl->schedule_lru.front();
         pl->schedule_lru.erase(pl->schedule_lru.begin());

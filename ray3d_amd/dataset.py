@@ -93,8 +93,11 @@ def load_pose_data(path_3d: str, path_2d: str, cameras: Mapping[str, Sequence[Ca
     ``Trainer.evaluate`` walks (lib/train_val/trainer.py:407-460), grouped by ``action.split(' ')[0]`` (:417).
 
     ``joints_3d`` / ``joints_2d`` select joints from the archives (``H36M_32_TO_17`` for the 32-joint H36M mocap file,
-    ``KEEP_UNIVERSAL_14_OF_17`` for the cross-dataset 14-joint layout); ``action_filter`` keeps actions that start
-    with one of the given names (main.py's ``ACTIONS``); ``downsample`` is ``DOWNSAMPLE`` (:298-311);
+    ``KEEP_UNIVERSAL_14_OF_17`` for the cross-dataset 14-joint layout); ``action_filter`` is main.py's ``ACTIONS`` list used the way
+    ``Trainer.evaluate`` uses it (:412-417): its entries are EXACT action keys looked up for every test subject
+    ('Walking' selects the sequence called 'Walking', not 'Walking 1' or 'WalkingDog'; a key a subject lacks raises
+    ``KeyError`` as the reference's ``fetch_via_action`` would); ``downsample`` is ``DOWNSAMPLE`` as
+    ``fetch_via_action`` applies it (lib/dataset/__init__.py:342-348);
     ``joints_symmetry`` = the skeleton's (joints_left, joints_right) when it is neither the 17- nor the 14-joint one.
     Raises on what ``sanity_check`` (:205-231) asserts: missing subject/action, fewer 2D frames than mocap frames,
     camera-count mismatch."""
@@ -118,9 +121,15 @@ def load_pose_data(path_3d: str, path_2d: str, cameras: Mapping[str, Sequence[Ca
             raise KeyError("Subject %s is missing from the 2D detections dataset" % subject)
         if subject not in cameras:
             raise KeyError("no cameras given for subject %r" % subject)
-        for action, pos3d in a3[subject].items():
-            if action_filter is not None and not any(action.startswith(a) for a in action_filter):
-                continue
+        if action_filter is not None:
+            for a in action_filter:
+                if a not in a3[subject]:
+                    raise KeyError("action %r (ACTIONS) is not a sequence of subject %r: the filter's entries are exact "
+                                   "action keys (lib/train_val/trainer.py:412-417)" % (a, subject))
+            wanted = [(a, a3[subject][a]) for a in action_filter]
+        else:
+            wanted = list(a3[subject].items())
+        for action, pos3d in wanted:
             if action not in a2[subject]:
                 raise KeyError("Action %s of subject %s is missing from the 2D detections dataset" % (action, subject))
             views = a2[subject][action]

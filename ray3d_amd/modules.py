@@ -319,7 +319,25 @@ class Ray3DLifter(nn.Module):
         return out
 
     CLIP_CHUNK = 2048      # windows per forward in clip mode
-    CLIP_ROUND = 128       # the last chunk is rounded up to a multiple of this many windows
+    CLIP_ROUND = 128       # the last chunk is rounded up to a multiple of this many windows (0: exact sizes)
+
+    def clip_batch_sizes(self, n: int):
+        """Batch sizes of the forwards that lift an n-window clip: CLIP_CHUNK at a time, the rest rounded up to a
+        multiple of CLIP_ROUND - to 32 or 64 when it is that short - so that clips of any lengths share a handful of
+        tile schedules (the library builds and uploads one per batch size).  CLIP_ROUND = 0 lifts exact sizes."""
+        sizes = [self.CLIP_CHUNK] * (n // self.CLIP_CHUNK)
+        r = n % self.CLIP_CHUNK
+        if r:
+            if self.CLIP_ROUND <= 0:
+                sizes.append(r)
+            else:
+                up = -(-r // self.CLIP_ROUND) * self.CLIP_ROUND
+                for small in (32, 64):
+                    if r <= small < up:
+                        up = small
+                        break
+                sizes.append(up)
+        return sizes
 
     def forward_clip(self, clip: torch.Tensor, param_row: Optional[torch.Tensor] = None):
         """clip (N + RF - 1, J, F): an edge-padded sequence; window i = frames [i, i+RF) is gathered
@@ -327,8 +345,8 @@ class Ray3DLifter(nn.Module):
         param_row (E,) is broadcast to every window (trainer.py:324).  Returns (N,1,J,3).
 
         The library keeps one tile schedule per batch size, and every clip has its own length: the windows are
-        lifted CLIP_CHUNK at a time and the last chunk is rounded up to a multiple of CLIP_ROUND (over repeated last
-        frames; the surplus poses are cut off), so that a whole evaluation uses a handful of batch sizes."""
+        lifted in the batch sizes of :meth:`clip_batch_sizes` (the surplus windows slide over repeated last frames
+        and their poses are cut off), so that a whole evaluation uses a handful of batch sizes."""
         rf = self.receptive_field()
         assert clip.dim() == 3 and clip.shape[1] == self.pos.num_joints_in and clip.shape[2] == self.pos.in_features
         n = clip.shape[0] - rf + 1
@@ -337,12 +355,10 @@ class Ray3DLifter(nn.Module):
         clip = clip.detach().to(torch.float32).contiguous()
         p = param_row.detach().to(clip.device, torch.float32).contiguous().view(-1) \
             if self.pos.camera_embedding else None
-        if n <= self.CLIP_ROUND:
-            return self._run(_capi.R3D_INPUT_RAYS, clip, 1, n, p, 0)
-        sizes = [self.CLIP_CHUNK] * (n // self.CLIP_CHUNK)
-        if n % self.CLIP_CHUNK:
-            sizes.append(-(-(n % self.CLIP_CHUNK) // self.CLIP_ROUND) * self.CLIP_ROUND)
+        sizes = self.clip_batch_sizes(n)
         total = sum(sizes)
+        if total == n and len(sizes) == 1:
+            return self._run(_capi.R3D_INPUT_RAYS, clip, 1, n, p, 0)
         if total > n:
             clip = torch.cat([clip, clip[-1:].expand(total - n, -1, -1)], dim=0)
         out = torch.empty((total, 1, self.pos.num_joints_in, 3), dtype=torch.float32, device=clip.device)
@@ -351,6 +367,15 @@ class Ray3DLifter(nn.Module):
             self._run(_capi.R3D_INPUT_RAYS, clip[start:], 1, b, p, 0, out=out[start:start + b])
             start += b
         return out[:n]
+
+    def prepare(self, batch_sizes, device=None):
+        """Build and upload the tile schedules of these batch sizes now (r3d_prepare) instead of inside the first
+        forward that meets them: needed before capturing a forward into a hipGraph, useful before a timed run."""
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        hp, ht = self.pos.handle(dev), self.trj.handle(dev)
+        with torch.cuda.device(dev):
+            for b in batch_sizes:
+                _capi.prepare(hp, ht, int(b))
 
     def forward_uv(self, uv: torch.Tensor, cam_rows: torch.Tensor, param: Optional[torch.Tensor] = None,
                    window_stride: Optional[int] = None):

@@ -90,7 +90,7 @@ def test_forward_clip_equals_materialised_windows():
     windows = np.stack([clip[i:i + rf] for i in range(n)])
     prow = np.array([1.5, 0.2], np.float32)
     with torch.no_grad():
-        lifter.CLIP_ROUND = 256                                   # one forward of exactly n windows
+        lifter.CLIP_ROUND = 0                                     # one forward of exactly n windows
         a = lifter.forward_clip(torch.from_numpy(clip).cuda(), torch.from_numpy(prow).cuda()).cpu().numpy()
         b = lifter(torch.from_numpy(windows).cuda(), torch.from_numpy(np.tile(prow, (n, 1))).cuda()).cpu().numpy()
         assert a.shape == (n, 1, 17, 3)

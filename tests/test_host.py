@@ -26,6 +26,11 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert b"gfx950" in _capi.load().r3d_version()
+    # ... and exports nothing under the r3d_ prefix that the header does not declare
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\b[TW] (r3d_[a-z_0-9]+)$", out, flags=re.M))
+    assert exported == declared, exported ^ declared
 
 
 @pytest.mark.parametrize("name", MODEL_CASES)
@@ -390,6 +395,13 @@ def test_pose_archives_load_like_the_reference_front_end(tmp_path):
     # filters, the 14-joint layout, and the sanity checks
     only = dataset.load_pose_data(p3, p2, cams, ["TS1"], action_filter=["Other"], downsample=2)
     assert len(only.clips) == 1 and only.clips[0].rays.shape[0] == 12
+    # ACTIONS entries are exact action keys, as Trainer.evaluate uses them (trainer.py:412-417): a prefix is not a match
+    second = [a for a in acts if a.split(" ")[0] == "Seq"][1]
+    exact = dataset.load_pose_data(p3, p2, cams, ["TS1"], action_filter=[second])
+    assert len(exact.clips) == 1 and exact.actions == {"Seq": [0]}
+    assert np.array_equal(exact.clips[0].rays, pd.clips[1].rays)
+    with pytest.raises(KeyError, match="exact"):
+        dataset.load_pose_data(p3, p2, cams, ["TS1"], action_filter=["Se"])
     uni = dataset.load_pose_data(p3, p2, cams, ["TS1"], joints_3d=dataset.KEEP_UNIVERSAL_14_OF_17,
                                  joints_2d=dataset.KEEP_UNIVERSAL_14_OF_17)
     assert uni.clips[0].rays.shape[1] == 14 and (uni.kps_left, uni.kps_right) == ([4, 5, 6, 8, 9, 10], [1, 2, 3, 11, 12, 13])
@@ -474,3 +486,21 @@ def test_plan_tile_lists_cover_every_problem_once(monkeypatch):
     _plan_check(default_model_config(ARCHITECTURE="3,3,3,3", CHANNELS=512), [3, 256])
     monkeypatch.setenv("R3D_NO_SPILL", "1")
     assert all(s == 0 for _, s in _plan_check(mc, [100, 256, 1024]))
+
+
+def test_plans_do_not_outlive_a_partner_model():
+    """A (pos, trj) plan holds the partner's layer indices and K paddings.  It is keyed by model ids that are never
+    reused and dropped when either model is destroyed: a new trajectory model - which malloc may well place at the old
+    one's address - gets a plan built for ITS configuration."""
+    lib = _capi.load()
+    fn = lib.r3d_debug_plan_check
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    fn.restype = ctypes.c_int
+    mc = default_model_config(ARCHITECTURE="3,3,3")
+    hp = _capi.Handle(config_from_dicts(mc, "pos"))
+    n, sp = ctypes.c_int(), ctypes.c_int()
+    for over in (dict(), dict(CHANNELS=128), dict(LATENT_FEATURES_DIM=128), dict(CHANNELS=512), dict()):
+        ht = _capi.Handle(config_from_dicts(dict(mc, **over), "trj"))
+        assert fn(hp.ptr, ht.ptr, 200, 256, ctypes.byref(n), ctypes.byref(sp)) == 0, over
+        ht.close()                                     # the plan goes with it
+    hp.close()
