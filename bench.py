@@ -1,23 +1,36 @@
 #!/usr/bin/env python3
 """Throughput of the Ray3D lifting forward pass on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--mode windows|eval] [--batch B]
 
-Workload (BASELINE.json configs[1]): synthetic 17-joint, 243-frame ray-encoded windows, batch 256
-per GPU, forward only, pos + trj networks (C=256, latent 256, stage 3, camera embedding on),
-random-init (deterministic synthetic) weights, fp32.  A step = one pass of the whole path over one
-batch already resident in HBM.  Weak scaling: every rank lifts its own 256-window batch, no
-collective on the data path (the only collectives are the timing barrier / max).
+--mode windows (default; BASELINE.json configs[1]): synthetic 17-joint, 243-frame ray-encoded windows, batch 256 per
+GPU, forward only, pos + trj networks (C=256, latent 256, stage 3, camera embedding on), random-init (deterministic
+synthetic) weights, fp32.  A step = one pass of the whole path over one batch already resident in HBM.  Weak scaling:
+every rank lifts its own batch, no collective on the data path (only the timing barrier / max).
+
+--mode eval (BASELINE.json configs[2]): the Human3.6M evaluation SHAPE (the data set is not in the image) - 240
+synthetic clips of U(1000, 6000) frames, four cameras, fifteen actions - sharded over the ranks as whole clips
+(longest first), lifted with in-kernel sliding windows, errors summed on the device, ONE RCCL all_gather of the
+per-clip partial rows per pass.  A step = one pass over the whole clip set (strong scaling: the set is fixed);
+the gathered MPJPE is part of the line and must not depend on N.
+
+With --gpus N > 1 and no WORLD_SIZE in the environment the script launches its own N ranks through
+torch.distributed.run (one process per GPU, RCCL) and fails loudly when fewer GPUs are visible.
 
 Prints ONE JSON line (rank 0).  Besides the driver's keys it carries
-  roofline      - the dominant kernel's measured rate (HIP events on the launch stream, inside
-                  this process) against the gfx950 fp32-MFMA peak, plus the HBM view;
-  cpu_baseline  - the PyTorch-CPU port of the same module graph (oracle/torch_port.py) timed on
-                  this host's cores on a bounded sample of the same workload.
+  roofline        the dominant kernel's rate against the gfx950 fp32-MFMA peak.  Per-launch HIP events on the launch
+                  stream give every launch's duration; they are scaled so that their sum per step equals the step time
+                  of the timed region (HIP events around it, same stream) - bracketing every launch slows the chip's
+                  clock and adds gaps, and a kernel cannot take longer than the step it is part of;
+  roofline_b1024  the same at north_star's 1024-window batch (windows mode, N = 1);
+  cpu_baseline    the PyTorch-CPU port of the same module graph (oracle/torch_port.py) and the C restatement
+                  (oracle/ray3d_oracle.c) timed on this host's cores on a bounded sample of the same workload.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,6 +44,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 2
 PEAK_HBM_GBS = 8000.0
 BATCH = 256
 ARCH = "3,3,3,3,3"
+EVAL_CLIPS = 240                # 2 subjects x 15 actions x 2 sub-actions x 4 cameras (cfg 3)
 
 
 def build(device, arch=ARCH):
@@ -46,15 +60,15 @@ def build(device, arch=ARCH):
         states[kind] = (cfg, st)
         ray3d_amd.load_weight(m, {k: torch.from_numpy(np.asarray(v)) for k, v in st.items()})
         m.eval()
-    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    lifter = ray3d_amd.Ray3DLifter(pos.to(device), trj.to(device)).eval()
     return lifter, states
 
 
 def cpu_baseline(states, x, p, budget_s=20.0):
-    """oracle/torch_port.py (the ATen CPU kernels the reference would run) on this host's cores.
-    Thread counts above the cgroup's share thrash badly, so a short ladder of thread counts is tried
-    inside the time budget and the fastest one is reported (cores = threads actually used)."""
-    from oracle import torch_port
+    """oracle/torch_port.py (the ATen CPU kernels the reference would run) on this host's cores, and the C
+    restatement beside it.  Thread counts above the cgroup's share thrash badly, so a short ladder of thread counts is
+    tried inside the time budget and the fastest one is reported (cores = threads actually used)."""
+    from oracle import oracle, torch_port
     sds = {k: {n: torch.from_numpy(np.asarray(v)) for n, v in st.items()} for k, (_, st) in states.items()}
     xt, pt = torch.from_numpy(x), torch.from_numpy(p)
 
@@ -83,15 +97,44 @@ def cpu_baseline(states, x, p, budget_s=20.0):
             runs += 1
             if dt < best:
                 best, best_threads = dt, threads
-    return {"value": round(x.shape[0] / best, 1), "unit": "poses/s", "cores": best_threads, "kind": "port",
-            "host_cpus": avail,
-            "sample": "best of %d timed forwards (thread ladder %s) of one %d-window batch (pos+trj, RF 243) "
-                      "through oracle/torch_port.py (PyTorch-CPU functional port of the reference graph)"
-                      % (runs, ladder, x.shape[0])}
+    out = {"value": round(x.shape[0] / best, 1), "unit": "poses/s", "cores": best_threads, "kind": "port",
+           "host_cpus": avail,
+           "sample": "best of %d timed forwards (thread ladder %s) of one %d-window batch (pos+trj, RF 243) "
+                     "through oracle/torch_port.py (PyTorch-CPU functional port of the reference graph)"
+                     % (runs, ladder, x.shape[0])}
+    # the C restatement (OpenMP, double accumulation, un-folded BatchNorm: a checker, not a tuned GEMM) on a smaller sample
+    ns = min(64, x.shape[0])
+    threads = min(avail, 64)
+    t0 = time.perf_counter()
+    oracle.forward(states["pos"][0], states["pos"][1], x[:ns], p[:ns], threads=threads)
+    oracle.forward(states["trj"][0], states["trj"][1], x[:ns], p[:ns], threads=threads)
+    dt = time.perf_counter() - t0
+    out["c_oracle"] = {"value": round(ns / dt, 1), "unit": "poses/s", "cores": threads,
+                       "sample": "one forward of %d windows (pos+trj, RF 243) through oracle/ray3d_oracle.c" % ns}
+    return out
 
 
-def roofline(lifter, x, p, reps=5):
-    """Per-launch HIP events (bracketing each launch on its stream) -> dominant kernel's rate."""
+def timed_steps(fn, steps, warmup, barrier, dev):
+    """W untimed + exactly K timed steps between barriers; host wall time and the device time between two HIP events
+    recorded on the launch stream around the same K steps."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    out = None
+    for _ in range(warmup):
+        out = fn()
+    barrier()
+    t0 = time.perf_counter()
+    e0.record(torch.cuda.current_stream(dev))
+    for _ in range(steps):
+        out = fn()
+    e1.record(torch.cuda.current_stream(dev))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    return elapsed, e0.elapsed_time(e1) * 1e-3, out
+
+
+def roofline(lifter, x, p, step_ms, reps=5):
+    """Per-launch HIP events (bracketing each launch on its stream) -> the dominant kernel's rate.
+    `step_ms`: device time of one step of the timed region; the launch durations are scaled to sum to it."""
     agg = {}
     lifter.profile(x, p)
     pair_ms = []
@@ -108,48 +151,105 @@ def roofline(lifter, x, p, reps=5):
             print("launch %2d %-20s blocks %5d  %8.1f us  %7.2f GFLOP  %6.1f TFLOP/s" % (
                 r["stage"], r["kernel"], r["blocks"], r["ms"] * 1e3, r["flops"] / 1e9,
                 r["flops"] / max(r["ms"], 1e-9) / 1e9), file=sys.stderr)
+    # a bracket = the kernel + the event records around it; the empty bracket measures the latter (median of the
+    # reps) and is taken off every launch
+    for d in agg.values():
+        d["raw_ms"] = d["ms"]
+        d["ms"] = max(d["ms"] - pair * d["launches"], 0.5 * d["ms"])
+    sum_ms = sum(d["ms"] for d in agg.values()) / reps                 # all kernels of one profiled step
+    # Bracketed launches run slower than the free-running step (clock give-back, serialised event records); the
+    # kernels of a step cannot take longer than the step, so the profile supplies the SHARES and the timed region the
+    # total.  Never scaled up: idle gaps inside a step are not kernel time.
+    scale = min(1.0, step_ms / sum_ms) if sum_ms > 0 else 1.0
     name = max(agg, key=lambda k: agg[k]["ms"])
     d = agg[name]
-    raw_ms = d["ms"]
-    # a bracket = the kernel + the event records around it; the empty bracket measures the latter (median of the
-    # reps) and is taken off every launch - rocprofv3's kernel-trace durations (profiles/) have no such term
-    d = dict(d, ms=max(d["ms"] - pair * d["launches"], 0.5 * d["ms"]))
-    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    ms = d["ms"] * scale
+    achieved = d["flops"] / (ms * 1e-3) / 1e12
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if measured
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
-            traffic = tj.get(name) if tj.get("batch") == x.shape[0] else None   # measured at that batch size only
+            traffic = tj.get("batches", {}).get(str(x.shape[0]), {}).get(name)   # measured at that batch size only
         except Exception:
             traffic = None
-    out = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-           "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-           "launches_per_step": d["launches"] // reps,
-           "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2),
-           "avg_launch_us_with_events": round(raw_ms / d["launches"] * 1e3, 2), "event_pair_us": round(pair * 1e3, 2),
-           "flops_per_launch": d["flops"] / d["launches"],
-           "hbm_view": {"algorithmic_GBps": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
-                        "frac": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
-           "all_kernels_us_per_step": {k: round(v["ms"] / reps * 1e3, 1) for k, v in agg.items()}}
-    return out
+    return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "launches_per_step": d["launches"] // reps,
+            "avg_launch_us": round(ms / d["launches"] * 1e3, 2),
+            "avg_launch_us_bracketed": round(d["ms"] / d["launches"] * 1e3, 2),
+            "event_pair_us": round(pair * 1e3, 2), "scale_to_step": round(scale, 4),
+            "step_us": round(step_ms * 1e3, 1),
+            "kernels_us_per_step": {k: round(v["ms"] * scale / reps * 1e3, 1) for k, v in agg.items()},
+            "flops_per_launch": d["flops"] / d["launches"],
+            "hbm_view": {"algorithmic_GBps": round(d["bytes"] / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+                         "frac": round(d["bytes"] / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}}
+
+
+def synthetic_eval_set(n_clips, seed=0):
+    """Clip lengths and cameras of the H36M-shaped stand-in: a pure function of (n_clips, seed), so every rank derives
+    the same set (and the same sharding) without communicating.  Clip i is generated from its own stream."""
+    import ray3d_amd
+    rng = np.random.default_rng(seed)
+    lengths = [int(rng.integers(1000, 6001)) for _ in range(n_clips)]
+    cams = [ray3d_amd.synthetic_camera(yaw, 4.5, -12.0, name="cam%d" % i) for i, yaw in enumerate((20, 110, 200, 290))]
+    return lengths, cams
+
+
+def make_clip(i, n, cams, seed=0):
+    from ray3d_amd import evaluate
+    rng = np.random.default_rng([seed, i])
+    cam = cams[i % 4]
+    world = rng.normal(0, 0.3, (1, 17, 3)) + np.array([0, 0, 1.0]) + 0.02 * np.cumsum(rng.normal(0, 1.0, (n, 1, 3)), axis=0) \
+        + rng.normal(0, 0.02, (n, 17, 3))
+    rays = cam.rays_from_uv(cam.project(world)).astype(np.float32)
+    return evaluate.Clip(cam, rays, cam.world2normalized(world).astype(np.float32), "A%d" % (i % 15), i)
+
+
+def self_launch(args):
+    """--gpus N without a launcher: start N ranks through torch.distributed.run, forward their output."""
+    n = torch.cuda.device_count()
+    if n < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible to this process" % (args.gpus, n))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--mode", choices=("windows", "eval"), default="windows")
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--clips", type=int, default=EVAL_CLIPS, help="eval mode: number of clips in the set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-b1024", action="store_true", help="windows mode: skip the roofline point at 1024 windows")
     ap.add_argument("--two-stream", action="store_true", help="also time Ray3DLifter.forward_overlapped (two half batches on two streams)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 50 if args.mode == "windows" else 3
+    if args.warmup is None:
+        args.warmup = 10 if args.mode == "windows" else 1
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU (no CPU fallback exists)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an AMD GPU (no CPU fallback exists)")
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch it with torch.distributed.run "
+                         "--nproc-per-node %d (or without a launcher: it starts its own ranks)" % (args.gpus, world, args.gpus))
+    if local >= torch.cuda.device_count():
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -157,14 +257,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
-
-    from ray3d_amd import synth
-    lifter, states = build(dev)
-    cfg = states["pos"][0]
-    x_np = synth.synth_rays(args.batch, cfg, seed=100 + rank)
-    p_np = synth.synth_param(args.batch, seed=0, vary=False)
-    x, p = torch.from_numpy(x_np).to(dev), torch.from_numpy(p_np).to(dev)
+        assert dist.get_world_size() == world
 
     def barrier():
         torch.cuda.synchronize()
@@ -172,60 +265,114 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    with torch.no_grad():
-        # one-time set-up of the library for this batch size (launch plan, tile schedule upload, workspace
-        # allocation) - not a warm-up step
-        lifter(x, p)
-        torch.cuda.synchronize()
-        for _ in range(args.warmup):
-            out = lifter(x, p)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = lifter(x, p)
-        barrier()
-        elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    def max_over_ranks(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(out).all()
+        return float(t.item())
 
-    if rank == 0:
-        n_gpus = world
-        value = n_gpus * args.batch * args.steps / elapsed
-        line = {
-            "metric": "lifted poses/sec (17-joint, 243-frame window)",
-            "value": round(value, 1), "unit": "poses/s", "n_gpus": n_gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: synthetic 17-joint 243-frame windows, batch %d per GPU, "
-                                   "forward-only pos+trj (C=256, latent 256, stage 3, camera embedding)" % args.batch,
-                       "batch_per_gpu": args.batch, "receptive_field": 243, "joints": 17,
-                       "parallelism": "dp%d (independent window batches, no data-path collective)" % n_gpus},
-        }
+    from ray3d_amd import evaluate, synth
+    lifter, states = build(dev)
+    cfg = states["pos"][0]
+    line = {"metric": "lifted poses/sec (17-joint, 243-frame window)", "unit": "poses/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic"}
+
+    if args.mode == "windows":
+        x_np = synth.synth_rays(args.batch, cfg, seed=100 + rank)
+        p_np = synth.synth_param(args.batch, seed=0, vary=False)
+        x, p = torch.from_numpy(x_np).to(dev), torch.from_numpy(p_np).to(dev)
         with torch.no_grad():
-            line["roofline"] = roofline(lifter, x, p)
-        if n_gpus == 1 and args.two_stream:
-            # informative, not the headline (opt-in so that the default command - the one profiles/prof_recipe.sh
-            # traces - launches full batches only): the same batch as two independent half batches on two HIP streams
-            # (Ray3DLifter.forward_overlapped) - launch tails and small levels of one half overlap the other's work
+            # one-time set-up of the library for this batch size (launch plan, tile schedule upload, workspace
+            # allocation) - not a warm-up step; its cost is reported
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            lifter.prepare([args.batch], dev)
+            prepare_ms = (time.perf_counter() - t0) * 1e3
+            lifter(x, p)
+            torch.cuda.synchronize()
+            elapsed, dev_s, out = timed_steps(lambda: lifter(x, p), args.steps, args.warmup, barrier, dev)
+        elapsed = max_over_ranks(elapsed)
+        assert torch.isfinite(out).all()
+        if rank == 0:
+            line.update({
+                "value": round(world * args.batch * args.steps / elapsed, 1),
+                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "scaling": "weak",
+                "config": {"workload": "BASELINE configs[1]: synthetic 17-joint 243-frame windows, batch %d per GPU, "
+                                       "forward-only pos+trj (C=256, latent 256, stage 3, camera embedding)" % args.batch,
+                           "batch_per_gpu": args.batch, "receptive_field": 243, "joints": 17,
+                           "parallelism": "dp%d (independent window batches, no data-path collective)" % world,
+                           "schedule_build_ms": round(prepare_ms, 1)}})
             with torch.no_grad():
-                for _ in range(args.warmup):
-                    lifter.forward_overlapped(x, p)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    lifter.forward_overlapped(x, p)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t0
-            line["two_stream_variant"] = {"value": round(args.batch * args.steps / dt, 1), "unit": "poses/s",
-                                          "ms_per_step": round(dt / args.steps * 1e3, 4),
-                                          "note": "same work as `value`, issued as 2 half batches on 2 streams"}
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(states, x_np, p_np)
-        print(json.dumps(line))
+                line["roofline"] = roofline(lifter, x, p, dev_s / args.steps * 1e3)
+            if world == 1 and args.batch == BATCH and not args.no_b1024:
+                # north_star quotes its roofline target at 1024 x 243 x 17: the same measurement at that batch
+                xb = torch.from_numpy(synth.synth_rays(1024, cfg, seed=100)).to(dev)
+                pb = torch.from_numpy(synth.synth_param(1024, seed=0, vary=False)).to(dev)
+                with torch.no_grad():
+                    lifter.prepare([1024], dev)
+                    lifter(xb, pb)
+                    el_b, dev_b, _ = timed_steps(lambda: lifter(xb, pb), max(args.steps // 2, 5), max(args.warmup // 2, 2), barrier, dev)
+                    nb = max(args.steps // 2, 5)
+                    rb = roofline(lifter, xb, pb, dev_b / nb * 1e3)
+                rb.update({"batch": 1024, "value": round(1024 * nb / el_b, 1), "ms_per_step": round(el_b / nb * 1e3, 4), "steps": nb})
+                line["roofline_b1024"] = rb
+                del xb, pb
+            if world == 1 and args.two_stream:
+                with torch.no_grad():
+                    el2, _, _ = timed_steps(lambda: lifter.forward_overlapped(x, p), args.steps, args.warmup, barrier, dev)
+                line["two_stream_variant"] = {"value": round(args.batch * args.steps / el2, 1), "unit": "poses/s",
+                                              "ms_per_step": round(el2 / args.steps * 1e3, 4),
+                                              "note": "same work as `value`, issued as 2 half batches on 2 streams"}
+            if world == 1 and not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(states, x_np, p_np)
+            print(json.dumps(line))
+    else:
+        # ---- clip-sharded evaluation (configs[2]): whole clips per rank, resident in HBM, one all_gather per pass
+        lengths, cams = synthetic_eval_set(args.clips)
+        shards = evaluate.shard_clips(lengths, world)
+        actions = sorted(set("A%d" % (i % 15) for i in range(args.clips)))
+        aid = {a: i for i, a in enumerate(actions)}
+        mine = []
+        for idx in shards[rank]:
+            c = make_clip(idx, lengths[idx], cams)
+            padded = torch.from_numpy(evaluate.pad_clip(c.rays, 121)).to(dev)
+            mine.append((c, padded, torch.from_numpy(c.camera.param()).to(dev), torch.from_numpy(c.gt_norm).to(dev)))
+        sizes = sorted(set(b for c, _, _, _ in mine for b in lifter.clip_batch_sizes(c.rays.shape[0])))
+        lifter.prepare(sizes, dev)
+        result = {}
+
+        def one_pass():
+            rows = [evaluate.clip_partials_hip(lifter.forward_clip(padded, prow), c, aid[c.action], gt_dev=gt)
+                    for c, padded, prow, gt in mine]
+            local_rows = torch.stack(rows) if rows else torch.zeros((0, evaluate.PARTIAL_COLS), dtype=torch.float64, device=dev)
+            allrows = evaluate.gather_partials(local_rows, [len(s) for s in shards]) if dist is not None else local_rows
+            result["rows"] = allrows
+            return allrows
+
+        with torch.no_grad():
+            one_pass()                          # first touch: workspace allocation
+            elapsed, dev_s, allrows = timed_steps(one_pass, args.steps, args.warmup, barrier, dev)
+        elapsed = max_over_ranks(elapsed)
+        per = evaluate.reduce_partials(allrows)
+        avg = evaluate.action_average(per)
+        frames = sum(lengths)
+        if rank == 0:
+            assert allrows.shape[0] == args.clips and sorted(int(v) for v in allrows[:, 0].tolist()) == list(range(args.clips))
+            line.update({
+                "value": round(frames * args.steps / elapsed, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                "scaling": "strong",
+                "config": {"workload": "BASELINE configs[2] stand-in: %d synthetic clips of U(1000,6000) frames (%d frames), 17 joints, "
+                                       "RF 243, whole clips sharded over the ranks longest-first, in-kernel sliding windows, device "
+                                       "metrics, one RCCL all_gather of the per-clip partial rows per pass" % (args.clips, frames),
+                           "clips": args.clips, "frames": frames, "receptive_field": 243, "joints": 17,
+                           "batch_sizes": sizes if world == 1 else None,
+                           "parallelism": "clips sharded over %d rank(s); collective = all_gather of %d x %d float64"
+                                          % (world, args.clips, evaluate.PARTIAL_COLS)},
+                "mpjpe_mm": {"action_average": avg[0], "p_mpjpe": avg[1], "n_mpjpe": avg[2], "mpjve": avg[3], "mrpe": avg[4],
+                             "checksum": float(allrows[allrows[:, 0].argsort()][:, 3].sum().item())}})
+            print(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

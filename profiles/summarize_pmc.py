@@ -29,9 +29,15 @@ def one_forward(per):
 
 
 root = sys.argv[1]
+batch = '?'
+try:
+    import json
+    batch = json.load(open(root + '/bench_line.json'))['config']['batch_per_gpu']
+except Exception:
+    pass
 f1, f2, f3, f4 = (one_forward(load('%s/pmc%d' % (root, i))) for i in (1, 2, 3, 4))
-print('# one forward (B=256, RF 243, pos+trj); cycles in millions (SQ_* quad-cycle counters x4); FETCH_SIZE x2 per '
-      'MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); clk = GRBM_GUI_ACTIVE / 8 XCDs / duration')
+print('# one forward (B=%s, RF 243, pos+trj); cycles in millions (SQ_* quad-cycle counters x4); FETCH_SIZE x2 per '
+      'MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); clk = GRBM_GUI_ACTIVE / 8 XCDs / duration' % batch)
 print('%-20s %9s %8s %8s %8s %8s %8s %8s | %7s %6s | %8s %8s %5s' % (
     'kernel', 'grid', 'dur_us', 'waveMcy', 'mfmaMcy', 'waitAny', 'waitInst', 'active', 'ldsIdxM', 'clkGHz', 'fetchMB',
     'writeMB', 'L2hit'))
@@ -42,3 +48,9 @@ for a, b, c, d in zip(f1, f2, f3, f4):
         a['SQ_WAIT_ANY'] * 4 / 1e6, a['SQ_WAIT_INST_ANY'] * 4 / 1e6, a['SQ_ACTIVE_INST_ANY'] * 4 / 1e6,
         b['SQ_LDS_IDX_ACTIVE'] / 1e6, b['GRBM_GUI_ACTIVE'] / 8 / (b['t1'] - b['t0']), c['FETCH_SIZE'] * 2 / 1e3,
         d['WRITE_SIZE'] / 1e3, 100 * d['TCC_HIT_sum'] / max(1, d['TCC_HIT_sum'] + d['TCC_MISS_sum'])))
+
+tot_f = sum(c['FETCH_SIZE'] * 2 / 1e3 for c in f3 if c['name'].startswith('r3d_gemm'))
+tot_w = sum(d['WRITE_SIZE'] / 1e3 for d in f4 if d['name'].startswith('r3d_gemm'))
+n = sum(1 for c in f3 if c['name'].startswith('r3d_gemm'))
+print('# r3d_gemm*: %d launches, fetch %.1f MB + write %.1f MB per forward = %.0f bytes per launch (profiles/traffic.json)'
+      % (n, tot_f, tot_w, (tot_f + tot_w) * 1e6 / max(n, 1)))

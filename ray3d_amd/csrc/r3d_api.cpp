@@ -46,11 +46,9 @@ static bool same_input_shape(const Model *a, const Model *b) {
            a->cfg.num_levels == b->cfg.num_levels && a->cfg.extrinsic_dim == b->cfg.extrinsic_dim;
 }
 
-static size_t workspace_need(const Plan *pl, int64_t B, int64_t window_stride, int RF, int J) {
-    // activations + (UV mode) rays of every touched frame; sized for the worst case window_stride == RF
-    const size_t act = (size_t)pl->floats_per_window * (size_t)B;
-    const size_t frames = (size_t)((B - 1) * std::min<int64_t>(window_stride, RF) + RF);
-    return (act + frames * J * 3 + 64) * sizeof(float);
+static size_t workspace_need(const Plan *pl, int64_t B) {
+    // activations only: the input is read in place in both modes (UV mode encodes the rays inside the gather)
+    return ((size_t)pl->floats_per_window * (size_t)B + 64) * sizeof(float);
 }
 
 struct Recorder {
@@ -107,11 +105,8 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
     }
 
     Plan *pl = plan_get(a, b);
-    // UV mode keeps the encoded rays of every touched frame at the end of the workspace
     const long long frames = (B - 1) * in->window_stride + a->RF;
-    const size_t act_floats = (size_t)pl->floats_per_window * (size_t)B;
-    const size_t need = workspace_need(pl, B, in->window_stride, a->RF, a->cfg.num_joints);
-    if (in->mode == R3D_INPUT_UV && in->window_stride > a->RF) { set_error("R3D_INPUT_UV needs window_stride <= RF"); return R3D_ERR_ARG; }
+    const size_t need = workspace_need(pl, B);
     if (!ws || ws_bytes < need) {
         set_error("workspace too small: need %zu bytes, got %zu", need, ws_bytes);
         return R3D_ERR_WORKSPACE;
@@ -126,29 +121,9 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
     if ((e = rec.begin("r3d_event_pair", -1, 0, 0.0, 0.0)) != hipSuccess) return hip_fail(e, "hipEventRecord");
     if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
 
-    // ---- pointwise prologue: uv -> rays (UV mode), camera embeddings
-    const float *x_rays = in->x_dev;
-    PrologueArgs pa;
-    memset(&pa, 0, sizeof pa);
-    pa.B = B;
-    pa.J = a->cfg.num_joints;
-    pa.RF = a->RF;
-    pa.window_stride = in->window_stride;
-    if (in->mode == R3D_INPUT_UV) {
-        pa.uv = in->x_dev;
-        pa.cam = in->cam_dev;
-        pa.cam_stride = in->cam_stride;
-        pa.rays = wsf + act_floats;
-        pa.frames = frames;
-        x_rays = pa.rays;
-    }
-    if (pa.uv) {
-        if ((e = rec.begin("r3d_prologue_f32", stage_no, 0, 0.0, (double)frames * pa.J * (pa.uv ? 20.0 : 0.0))) != hipSuccess) return hip_fail(e, "hipEventRecord");
-        if ((e = launch_prologue(pa, stream)) != hipSuccess) return hip_fail(e, "launch r3d_prologue_f32");
-        if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
-        ++stage_no;
-    }
-    const int JF = a->cfg.num_joints * a->cfg.in_features;
+    // UV mode: the kernels read pixel keypoints (frames, J, 2) and encode the rays while gathering them
+    const bool uv = in->mode == R3D_INPUT_UV;
+    const int JF = a->cfg.num_joints * (uv ? 2 : a->cfg.in_features);   // floats per input frame
 
     // ---- persistent GEMM launches, one per DAG level
     Schedule *sched = schedule_get(pl, B, device_cu_count());
@@ -174,9 +149,6 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
                     if (pl->buffers[q.seg[s].buf].external == 3) {      // the caller's camera-parameter rows
                         g.a[s] = in->param_dev;
                         g.lda[s] = (int)in->param_stride;
-                    } else if (pl->buffers[q.seg[s].buf].external == 4) {   // the windows' current frames (quirk Q1), in place
-                        g.a[s] = x_rays + (size_t)(a->RF / a->cfg.in_features) * JF;
-                        g.lda[s] = (int)(in->window_stride * JF);
                     } else {
                         g.a[s] = buf_ptr(q.seg[s].buf) + q.seg[s].col;
                         g.lda[s] = q.seg[s].ld;
@@ -192,9 +164,12 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             // the 2-wide parameter rows): its true width bounds the buffer descriptor, the rest reads as zeros
             if (q.nseg > 0 && !(q.nseg == 1 && kend < L.Kpad)) g.kend[q.nseg - 1] = 0x7fffffff;
             if (q.enc_lut >= 0) {
-                if (q.layer3 < 0) ++n_enc;                  // (the fused first level runs in the GEMM kernel)
-                g.lut = m->d_iarena + q.enc_lut;
-                g.x = x_rays;
+                if (q.enc_kernel) ++n_enc;                  // (with a fused first level these run in the GEMM kernel)
+                if (uv && q.enc_lut_uv < 0) { set_error("internal: no UV tables for an encoded operand"); return R3D_ERR_STATE; }
+                g.lut = m->d_iarena + (uv ? q.enc_lut_uv : q.enc_lut);
+                g.x = in->x_dev;
+                g.cam = uv ? in->cam_dev : nullptr;
+                g.cam_stride = in->cam_stride;
                 g.enc_ws = in->window_stride * JF;
                 g.enc_rows = q.enc_rows;
                 g.enc_jf = JF;
@@ -231,7 +206,10 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         }
         if (n_enc != 0 && n_enc != la.nprob) { set_error("internal: launch mixes encoded and plain operands"); return R3D_ERR_STATE; }
         if ((n_enc != 0) != (ss.kind == STAGE_ENC)) { set_error("internal: schedule and plan disagree on the launch kind"); return R3D_ERR_STATE; }
-        const char *kname = ss.kind == STAGE_ENC ? "r3d_gemm_enc_f32" : "r3d_gemm_f32";
+        bool uv_launch = false;                             // UV mode: only the launches that gather from the input
+        for (int i = 0; i < la.nprob; ++i) uv_launch = uv_launch || la.p[i].cam != nullptr;
+        const char *kname = ss.kind == STAGE_ENC ? (uv_launch ? "r3d_gemm_enc_uv_f32" : "r3d_gemm_enc_f32")
+                                                 : (uv_launch ? "r3d_gemm_uv_f32" : "r3d_gemm_f32");
         if ((e = rec.begin(kname, stage_no, ss.nwg, ss.flops, ss.bytes)) != hipSuccess) return hip_fail(e, "hipEventRecord");
 #ifdef R3D_TIMING
         // development build only (tools/build_probe.sh): phase stamps of the first tiles of launch $R3D_TIMING_STAGE
@@ -244,7 +222,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             la.dbg = timing_buf;
         }
 #endif
-        if ((e = launch_gemm_stage(la, ss.nwg, ss.kind, stream)) != hipSuccess) return hip_fail(e, "launch r3d_gemm_f32");
+        if ((e = launch_gemm_stage(la, ss.nwg, ss.kind, uv_launch, stream)) != hipSuccess) return hip_fail(e, "launch r3d_gemm_f32");
 #ifdef R3D_TIMING
         if (timed) {
             (void)hipStreamSynchronize(stream);
@@ -359,7 +337,7 @@ size_t r3d_workspace_bytes(const r3d_model *pos, const r3d_model *trj, int64_t B
     Model *t = const_cast<Model *>(reinterpret_cast<const Model *>(trj));
     Model *a = p ? p : t, *b = p ? t : nullptr;
     if (!a || B <= 0) return 0;
-    return workspace_need(plan_get(a, b), B, a->RF, a->RF, a->cfg.num_joints);
+    return workspace_need(plan_get(a, b), B);
 }
 
 int r3d_prepare(r3d_model *pos, r3d_model *trj, int64_t B) {

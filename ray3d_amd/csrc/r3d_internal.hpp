@@ -61,6 +61,12 @@ struct GemmProb {
     unsigned enc_bytes;       // size of the raw input in bytes (buffer-descriptor bound)
     int res_tap;              // fused first level: which frame of a triple is the residual (1 centre, 2 causal)
     int pad2_;
+    // --- UV input mode (cam != nullptr): x holds pixel keypoints (frames, J, 2), `lut` is the UV variant of the
+    // tables (element byte offsets into that layout, the ray component 0/1/2 in the two low bits) and every gathered
+    // value is encoded on its way into LDS with the camera row of the window its operand row belongs to:
+    // ray = ((u-cx)/fx, c*y+s, -s*y+c), y = (v-cy)/fy, in float64 then cast (lib/camera/camera.py:423-471).
+    const double *cam;        // rows {fx, fy, cx, cy, cos(pitch), sin(pitch), 0, 0}
+    long long cam_stride;     // doubles between consecutive windows' rows (0: one camera for all)
 };
 
 // Kernel argument of one persistent GEMM launch.  `tiles`/`wg_off` live in HBM (built once per
@@ -72,18 +78,6 @@ struct LaunchArgs {
     int ks;               // (unused: the split-K factor travels with each tile)
     long long *dbg;       // optional phase timestamps (R3D_TIMING builds only)
     GemmProb p[MAX_PROB];
-};
-
-// Pointwise prologue: optional uv -> ray encoding and the camera-embedding MLPs.
-struct PrologueArgs {
-    const float *uv;           // UV mode: (frames, J, 2) pixel keypoints, else nullptr
-    const double *cam;         // rows {fx, fy, cx, cy, cos p, sin p, 0, 0}
-    float *rays;               // UV mode: (frames, J, 3) output
-    long long frames;          // number of input frames touched
-    long long window_stride;   // frames between windows (to find a frame's camera row)
-    long long cam_stride;
-    long long B;
-    int J, RF;
 };
 
 constexpr int MAX_DEC = 6;     // 5 body-part decoders + the trajectory decoder
@@ -149,9 +143,11 @@ struct Model {
         std::vector<int> joints;
         int cin, k0, k0pad;
         size_t lut_off;               // offset (ints) into the int arena
+        size_t lut_uv_off;            // the same tables for the UV input mode (in_features == 3 only)
     };
     std::vector<Branch> branches;
     size_t global_lut_off = 0;        // LUT of GlobalInfo.fc_1's input (the current frame)
+    size_t global_lut_uv_off = 0;
     bool use_b3 = false;              // opt-in (R3D_BF16X3=1 at r3d_create): M = B layers on the bf16 matrix cores
     std::vector<float> arena;         // packed floats (host mirror)
     std::vector<int> iarena;          // LUTs
@@ -177,8 +173,7 @@ struct Model {
 struct BufferSpec {
     std::string name;
     int64_t floats_per_window;   // rows_per_window * ld
-    int external;                // 0 workspace, 1 out_dev, 2 out_trj_dev, 3 the caller's camera-parameter rows (input),
-                                 // 4 the windows' "current" frames inside the caller's input (row stride = window stride)
+    int external;                // 0 workspace, 3 the caller's camera-parameter rows (input)
     int64_t offset_per_window;   // workspace offset / B (floats)
 };
 
@@ -193,6 +188,8 @@ struct ProbSpec {
     int layer2;                  // >= 0: second layer of a fused pair (applied to the first one's output tile)
     int layer3;                  // >= 0 (with enc_lut >= 0): third layer of the fused first level
     int enc_lut;                 // >= 0: fused-encode problem, offset of its LUT in the model's int arena
+    int enc_lut_uv;              // the UV-mode tables of the same problem (-1: in_features != 3)
+    bool enc_kernel;             // runs in r3d_gemm_enc_f32 (the model's first level is not fused), not in r3d_gemm_f32
     int enc_rows;
     std::vector<int> deps;
     int depth;
@@ -237,8 +234,6 @@ struct Plan {
     int64_t floats_per_window = 0;
     int emb_buf[2] = {-1, -1};
     int param_buf = -1;          // pseudo-buffer standing for r3d_input::param_dev
-    int xcur_buf = -1;           // pseudo-buffer: the windows' current frames inside r3d_input::x_dev
-    int rays_buf = -1;           // UV mode scratch for the encoded rays (sized per call)
     // fused decoder tail: (model, layer, hidden buffer) per Integration block
     struct Dec { int model, layer, hbuf; };
     std::vector<Dec> decs;
@@ -280,9 +275,8 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg);   // nullptr + set_error o
 int device_cu_count();
 
 // kernel launchers (r3d_kernels.hip)
-hipError_t launch_prologue(const PrologueArgs &args, hipStream_t stream);
 enum { STAGE_BIG = 0, STAGE_ENC = 1 };   // r3d_gemm_f32 / r3d_gemm_enc_f32
-hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, int kind, hipStream_t stream);
+hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, int kind, bool uv, hipStream_t stream);   // uv: the launch gathers pixel keypoints
 hipError_t launch_decode(const DecodeArgs &args, hipStream_t stream);
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -298,6 +292,9 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 //               (quirk Q1) when lutk[k/4] is set; ENC_INVALID for padding columns;
 //   lutk[k/4] = 1 when the chunk is current-frame relative (GlobalInfo's input: every chunk).
 // ENC_INVALID pushes the address past the buffer descriptor's bound: the load returns 0.
+// UV variant (Model::Branch::lut_uv_off): the element (frame, joint, f) of the ray layout is computed from the pixel
+// coordinate at ((frame * J + joint) * 2 + (f > 0)) * 4 bytes of the (frames, J, 2) input; lut1[k] holds that offset
+// with f in its two low bits (offsets are multiples of four).
 constexpr int ENC_INVALID = (int)0x80000000u;
 
 int launch_clip_metrics(const float *pred, const float *gt, long long n, int J, const double *Rn2w, const double *Tn2w,

@@ -17,8 +17,9 @@
 //                      more than 256 channels): expand_conv / GlobalInfo.fc_1 with the gather fused.
 //  r3d_decode_f32      last Linear of the decoders + joint reassembly (rie.py:409-432) + trajectory
 //                      add (lib/train_val/trainer.py:353).
-//  r3d_prologue_f32    pointwise, UV input mode only: ray encoding (uv -> [(u-cx)/fx, c*y+s, -s*y+c],
-//                      float64 like the reference's NumPy, lib/camera/camera.py:423-471).
+//  UV input mode (pixel keypoints + per-window camera rows) has no kernel of its own: the gathers of first_level_run
+//  and enc_tile encode each value they stage - ray = ((u-cx)/fx, c*y+s, -s*y+c), float64 like the reference's NumPy
+//  (lib/camera/camera.py:423-471) - with the camera of the window the operand row belongs to.
 #include <hip/hip_runtime.h>
 
 #include "r3d_internal.hpp"
@@ -667,6 +668,27 @@ __device__ __forceinline__ void gemm_tile_b3(ProbRef P, const int row0, const in
     R3D_TSTAMP(4);
 }
 
+
+// ------------------------------------------------------------------------------------ UV input mode
+//
+// get_cam_ray_given_uv (lib/camera/camera.py:460-471) applied to a gathered value on its way into LDS: the operand
+// column says which ray component it is (two low bits of its table entry), the operand row which window - hence
+// which camera row {fx, fy, cx, cy, cos(pitch), sin(pitch)} - it belongs to.  float64 then cast, exactly as the
+// reference encodes on the host (NumPy float64) and casts at lib/train_val/trainer.py:298: the result is bit-identical
+// to feeding the host-encoded rays.
+struct CamRow { double fx, fy, cx, cy, c, s; };
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ CamRow load_cam_row(const double *row) {
+    const f64x2 a = *(const R3D_AS1 f64x2 *)row, b = *(const R3D_AS1 f64x2 *)(row + 2), c = *(const R3D_AS1 f64x2 *)(row + 4);
+    return CamRow{a[0], a[1], b[0], b[1], c[0], c[1]};
+}
+__device__ __forceinline__ float uv_to_ray(const float px, const int code, const CamRow &k) {
+    const int f = code & 3;
+    const double t = ((double)px - (f == 0 ? k.cx : k.cy)) / (f == 0 ? k.fx : k.fy);     // x = (u-cx)/fx, y = (v-cy)/fy
+    const double r = f == 1 ? k.c * t + k.s : -k.s * t + k.c;                            // [x, y, 1] @ Rx(pitch)^T
+    return (float)(f == 0 ? t : r);
+}
+
 // ------------------------------------------------------------------------------------ first layers
 //
 // r3d_gemm_enc_f32: expand_conv of every temporal branch and GlobalInfo.fc_1, with the input encoding
@@ -681,7 +703,7 @@ __device__ __forceinline__ void gemm_tile_b3(ProbRef P, const int row0, const in
 constexpr int ENC_TILE_BYTES = 64 * 1024;                  // encoded tile: rows * (K + 4) floats
 constexpr int ENC_LDS_BYTES = ENC_TILE_BYTES + LUT_LDS_INTS * 4;
 
-template <int MI>
+template <int MI, bool UV>
 __device__ __forceinline__ void enc_tile(ProbRef P, const int row0, const int col0, const bool new_prob, float *smem, long long *dbg) {
     R3D_TSTAMP(0);
     constexpr int R = MI * 32;
@@ -707,6 +729,7 @@ __device__ __forceinline__ void enc_tile(ProbRef P, const int row0, const int co
     __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x), 0, P.enc_bytes, 0x00020000);
     unsigned b_first[NA], b_cur[NA];                 // byte offsets into the raw input
     bool on[NA];
+    CamRow camr[UV ? NA : 1];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int vr = srow + 64 * i;
@@ -717,13 +740,14 @@ __device__ __forceinline__ void enc_tile(ProbRef P, const int row0, const int co
         const unsigned wbase = (unsigned)win * (unsigned)P.enc_ws;
         b_first[i] = (wbase + (unsigned)(t3 * 3 * P.enc_jf)) * 4;   // first frame of the row (3 frames per row)
         b_cur[i] = (wbase + (unsigned)P.enc_cur) * 4;               // the window's "current" frame (quirk Q1)
+        if constexpr (UV) camr[i] = load_cam_row(P.cam + (long long)win * P.cam_stride);
     }
     struct Raw { f32x4 a[NA]; };
     auto issue = [&](int kt, Raw &r) {
         const int k = kt * BK + a_kq;
         const int4 o1 = *reinterpret_cast<const int4 *>(lut1 + k);
         const bool cur = lutk[k >> 2] != 0;
-        const int c1[4] = {o1.x, o1.y, o1.z, o1.w};
+        const int c1[4] = {o1.x & ~3, o1.y & ~3, o1.z & ~3, o1.w & ~3};   // (UV tables: ray component in the low bits)
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if (!on[i]) continue;
@@ -734,10 +758,19 @@ __device__ __forceinline__ void enc_tile(ProbRef P, const int row0, const int co
         }
     };
     auto commit = [&](int kt, const Raw &r) {
+        int4 code = make_int4(0, 0, 0, 0);
+        if constexpr (UV) code = *reinterpret_cast<const int4 *>(lut1 + kt * BK + a_kq);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if (!on[i]) continue;
-            *reinterpret_cast<f32x4 *>(smem + (srow + 64 * i) * ldt + kt * BK + a_kq) = r.a[i];
+            f32x4 v = r.a[i];
+            if constexpr (UV) {
+                v[0] = uv_to_ray(v[0], code.x, camr[i]);
+                v[1] = uv_to_ray(v[1], code.y, camr[i]);
+                v[2] = uv_to_ray(v[2], code.z, camr[i]);
+                v[3] = uv_to_ray(v[3], code.w, camr[i]);
+            }
+            *reinterpret_cast<f32x4 *>(smem + (srow + 64 * i) * ldt + kt * BK + a_kq) = v;
         }
     };
     {
@@ -826,7 +859,7 @@ static_assert((FL_LUT_OFF + FL_LUT_INTS) * 4 <= GEMM_LDS_BYTES, "the fused first
 // gather pass are requested while this tile's 3-tap loop runs and wait in registers until the gather region is free
 // again (phase stamps: a body-part tile spent 9.8 us in the expand phase for 2.9 us of MFMA work, most of it the
 // latency of the scattered loads).
-template <int MI0>   // expand_conv rows per pass / 32: 3 (K0 <= 64) or 1
+template <int MI0, bool UV>   // expand_conv rows per pass / 32: 3 (K0 <= 64) or 1; UV input mode
 __device__ __forceinline__ void first_level_run(ProbRef P, const int4 *tile_list, const int ntiles, const bool new_prob, float *smem,
                                                 long long *dbg_base) {
     constexpr int R0 = MI0 * 32, NA = (R0 + 63) / 64;
@@ -860,6 +893,7 @@ __device__ __forceinline__ void first_level_run(ProbRef P, const int4 *tile_list
     const float bias0 = gload1(P.bias + wave * 32 + li), slope0 = P.slope;
     unsigned b_first[NA], b_cur[NA];
     bool on[NA];
+    CamRow camr[UV ? NA : 1];                                // camera of each staged row's window (of the pass in gq)
     auto row_bases = [&](int prow0) {                        // prow0: first expand_conv row of a pass
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -871,6 +905,7 @@ __device__ __forceinline__ void first_level_run(ProbRef P, const int4 *tile_list
             const unsigned wbase = (unsigned)win * (unsigned)P.enc_ws;
             b_first[i] = (wbase + (unsigned)(t3 * 3 * P.enc_jf)) * 4;
             b_cur[i] = (wbase + (unsigned)P.enc_cur) * 4;
+            if constexpr (UV) camr[i] = load_cam_row(P.cam + (long long)win * P.cam_stride);
         }
     };
     struct Raw { f32x4 a[NA]; };
@@ -878,7 +913,7 @@ __device__ __forceinline__ void first_level_run(ProbRef P, const int4 *tile_list
         const int k = kt * BK + a_kq;
         const int4 o1 = *reinterpret_cast<const int4 *>(lut1 + k);
         const bool cur = lutk[k >> 2] != 0;
-        const int c1[4] = {o1.x, o1.y, o1.z, o1.w};
+        const int c1[4] = {o1.x & ~3, o1.y & ~3, o1.z & ~3, o1.w & ~3};   // (UV tables: ray component in the low bits)
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if (!on[i]) continue;
@@ -889,10 +924,19 @@ __device__ __forceinline__ void first_level_run(ProbRef P, const int4 *tile_list
         }
     };
     auto commit = [&](int kt, const Raw &r) {
+        int4 code = make_int4(0, 0, 0, 0);
+        if constexpr (UV) code = *reinterpret_cast<const int4 *>(lut1 + kt * BK + a_kq);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if (!on[i]) continue;
-            *reinterpret_cast<f32x4 *>(r2 + (srow + 64 * i) * ldt + kt * BK + a_kq) = r.a[i];
+            f32x4 v = r.a[i];
+            if constexpr (UV) {
+                v[0] = uv_to_ray(v[0], code.x, camr[i]);
+                v[1] = uv_to_ray(v[1], code.y, camr[i]);
+                v[2] = uv_to_ray(v[2], code.z, camr[i]);
+                v[3] = uv_to_ray(v[3], code.w, camr[i]);
+            }
+            *reinterpret_cast<f32x4 *>(r2 + (srow + 64 * i) * ldt + kt * BK + a_kq) = v;
         }
     };
     Raw gq[NQ];                                              // the first pass of the coming tile
@@ -1091,7 +1135,7 @@ __device__ __forceinline__ void first_level_run(ProbRef P, const int4 *tile_list
   }
 }
 
-template <bool ENC>
+template <bool ENC, bool UV>
 __device__ __forceinline__ void gemm_persistent(float *smem) {
     LaunchArgsPtr args = (LaunchArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     // XCD-aware chunk order: workgroup b runs on XCD b % 8 (observed; speed only), so give each XCD a
@@ -1128,9 +1172,9 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
         if constexpr (ENC) {
             (void)ks;
             switch (mi) {
-                case 1: enc_tile<1>(P, row0, col0, new_prob, smem, dbg); break;
-                case 2: enc_tile<2>(P, row0, col0, new_prob, smem, dbg); break;
-                default: enc_tile<3>(P, row0, col0, new_prob, smem, dbg); break;
+                case 1: enc_tile<1, UV>(P, row0, col0, new_prob, smem, dbg); break;
+                case 2: enc_tile<2, UV>(P, row0, col0, new_prob, smem, dbg); break;
+                default: enc_tile<3, UV>(P, row0, col0, new_prob, smem, dbg); break;
             }
         } else {
             if (P.w3 != nullptr) {       // first level of the pyramid, fused (32 output rows per tile): this
@@ -1141,9 +1185,17 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
 #else
                 long long *run_dbg = nullptr;
 #endif
-                if (P.K <= 64) first_level_run<3>(P, args->tiles + t, n, new_prob, smem, run_dbg);
-                else first_level_run<1>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                if (P.K <= 64) first_level_run<3, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                else first_level_run<1, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
                 t += n - 1;
+                continue;
+            }
+            if (P.lut != nullptr) {      // gathered operand without the fused level: GlobalInfo.fc_1's current frames
+                switch (mi) {
+                    case 1: enc_tile<1, UV>(P, row0, col0, new_prob, smem, dbg); break;
+                    case 2: enc_tile<2, UV>(P, row0, col0, new_prob, smem, dbg); break;
+                    default: enc_tile<3, UV>(P, row0, col0, new_prob, smem, dbg); break;
+                }
                 continue;
             }
             if (P.wb3 != nullptr) {      // fp32 on the bf16 matrix cores (whole tiles of <= 128 rows)
@@ -1188,67 +1240,54 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
 #endif
 }
 
-// every layer whose input is an activation matrix in HBM: one workgroup per CU
+// every layer whose input is an activation matrix in HBM, plus the gathered first layers: one workgroup per CU
 extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_f32(const LaunchArgs args_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     (void)args_;
-    gemm_persistent<false>(smem);
+    gemm_persistent<false, false>(smem);
+}
+// the same for launches whose gathered operands are pixel keypoints (UV input mode: rays encoded while staging)
+extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_uv_f32(const LaunchArgs args_) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    (void)args_;
+    gemm_persistent<false, true>(smem);
 }
 
 // first layers with the input encoding fused in: two workgroups per CU (4 wavefronts per SIMD)
 extern "C" __global__ __launch_bounds__(GEMM_THREADS, 4) void r3d_gemm_enc_f32(const LaunchArgs args_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     (void)args_;
-    gemm_persistent<true>(smem);
+    gemm_persistent<true, false>(smem);
+}
+extern "C" __global__ __launch_bounds__(GEMM_THREADS, 4) void r3d_gemm_enc_uv_f32(const LaunchArgs args_) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    (void)args_;
+    gemm_persistent<true, true>(smem);
 }
 
-hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, int kind, hipStream_t stream) {
+hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, int kind, bool uv, hipStream_t stream) {
     // more dynamic LDS than the 64 KiB default cap: raised once per device (a process may drive several)
     static bool attr_done_dev[64] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     bool &attr_done = attr_done_dev[dev];
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(r3d_gemm_f32),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(r3d_gemm_enc_f32),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS_BYTES);
-        if (e != hipSuccess) return e;
+        const void *big[2] = {reinterpret_cast<const void *>(r3d_gemm_f32), reinterpret_cast<const void *>(r3d_gemm_uv_f32)};
+        const void *enc[2] = {reinterpret_cast<const void *>(r3d_gemm_enc_f32), reinterpret_cast<const void *>(r3d_gemm_enc_uv_f32)};
+        for (int i = 0; i < 2; ++i) {
+            hipError_t e = hipFuncSetAttribute(big[i], hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+            if (e != hipSuccess) return e;
+            if ((e = hipFuncSetAttribute(enc[i], hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS_BYTES)) != hipSuccess) return e;
+        }
         attr_done = true;
     }
-    if (kind == STAGE_ENC)
-        r3d_gemm_enc_f32<<<dim3(nwg), dim3(GEMM_THREADS), ENC_LDS_BYTES, stream>>>(args);
-    else
-        r3d_gemm_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------ prologue
-
-// Pointwise front end of the UV input mode: pixel keypoints -> rays, float64 like the reference's NumPy
-// (lib/camera/camera.py:438-439 then pt_cam @ Rc2n^T, :471, Rc2n = Rx(pitch), :333-338):
-// ray = ((u-cx)/fx, c*y + s, -s*y + c) with y = (v-cy)/fy, cast to float32 as lib/train_val/trainer.py:298 does.
-extern "C" __global__ __launch_bounds__(256) void r3d_prologue_f32(const PrologueArgs a) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long n = a.frames * a.J;
-    if (gid >= n) return;
-    const long long frame = gid / a.J;
-    // the camera of the (first) window this frame belongs to
-    long long win = a.window_stride >= a.RF ? frame / a.window_stride : frame - (a.RF - 1);
-    win = win < 0 ? 0 : (win >= a.B ? a.B - 1 : win);
-    const double *cam = a.cam + win * a.cam_stride;
-    const double u = a.uv[gid * 2], v = a.uv[gid * 2 + 1];
-    const double y = (v - cam[3]) / cam[1];
-    a.rays[gid * 3 + 0] = (float)((u - cam[2]) / cam[0]);
-    a.rays[gid * 3 + 1] = (float)(cam[4] * y + cam[5]);
-    a.rays[gid * 3 + 2] = (float)(-cam[5] * y + cam[4]);
-}
-
-hipError_t launch_prologue(const PrologueArgs &args, hipStream_t stream) {
-    const long long most = args.uv ? args.frames * args.J : 0;
-    if (most == 0) return hipSuccess;
-    r3d_prologue_f32<<<dim3((unsigned)((most + 255) / 256)), dim3(256), 0, stream>>>(args);
+    if (kind == STAGE_ENC) {
+        if (uv) r3d_gemm_enc_uv_f32<<<dim3(nwg), dim3(GEMM_THREADS), ENC_LDS_BYTES, stream>>>(args);
+        else r3d_gemm_enc_f32<<<dim3(nwg), dim3(GEMM_THREADS), ENC_LDS_BYTES, stream>>>(args);
+    } else {
+        if (uv) r3d_gemm_uv_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
+        else r3d_gemm_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
+    }
     return hipGetLastError();
 }
 

@@ -168,7 +168,7 @@ Model *model_create(const r3d_config &cfg) {
             br.cin = 3 * (int)br.joints.size() * F;
             br.k0 = 3 * br.cin;
             br.k0pad = round_up(br.k0, BK);
-            br.lut_off = 0;
+            br.lut_off = br.lut_uv_off = 0;
             m->branches.push_back(br);
             g.temporal_block(br.prefix, br.cin);
         }
@@ -186,7 +186,7 @@ Model *model_create(const r3d_config &cfg) {
         br.cin = 3 * J * F;
         br.k0 = 3 * br.cin;
         br.k0pad = round_up(br.k0, BK);
-        br.lut_off = 0;
+        br.lut_off = br.lut_uv_off = 0;
         m->branches.push_back(br);
         g.temporal_block(br.prefix, br.cin);
         g.fc_block("GlobalInfo", J * F, lat, 2);
@@ -215,17 +215,24 @@ Model *model_create(const r3d_config &cfg) {
         L.Kpad = br.k0pad;
         L.colmap.assign(3 * br.cin, -1);
         L.colmap_neg.assign(3 * br.cin, -1);
-        std::vector<int> l1(br.k0pad, ENC_INVALID), lk(br.k0pad / 4, 0);
+        std::vector<int> l1(br.k0pad, ENC_INVALID), l1uv(br.k0pad, ENC_INVALID), lk(br.k0pad / 4, 0);
+        // UV mode: element (frame, joint, f) comes from pixel coordinate (f > 0) of that joint, f kept in the low bits
+        auto uv_off = [&](int frame, int joint, int f) { return ((frame * J + joint) * 2 + (f > 0 ? 1 : 0)) * 4 + f; };
         for (int tap = 0; tap < 3; ++tap)
             for (int c = 0; c < nF; ++c) {
                 const int src = br.joints[c / F] * F + c % F;           // element of the (J,F) frame
                 const int xcol = tap * nF + c;
                 l1[xcol] = (tap * JF + src) * 4;
+                l1uv[xcol] = uv_off(tap, br.joints[c / F], c % F);
                 // the root term's column: the group's own joint-0 column, or a dedicated one
                 const int rcol = root_pos >= 0 ? tap * nF + root_pos * F + c % F : GX + tap * F + c % F;
-                if (root_pos < 0) l1[rcol] = (tap * JF + c % F) * 4;
+                if (root_pos < 0) {
+                    l1[rcol] = (tap * JF + c % F) * 4;
+                    l1uv[rcol] = uv_off(tap, 0, c % F);
+                }
                 const int ccol = GX + GR + c;
                 l1[ccol] = src * 4;
+                l1uv[ccol] = uv_off(0, br.joints[c / F], c % F);
                 lk[ccol / 4] = 1;                                       // relative to the window's current frame
                 for (int kind = 0; kind < 3; ++kind) {
                     const int t = tap * br.cin + kind * nF + c;         // torch column (tap, channel kind*nF + c)
@@ -236,13 +243,22 @@ Model *model_create(const r3d_config &cfg) {
         br.lut_off = m->iarena.size();
         m->iarena.insert(m->iarena.end(), l1.begin(), l1.end());
         m->iarena.insert(m->iarena.end(), lk.begin(), lk.end());
+        br.lut_uv_off = m->iarena.size();
+        m->iarena.insert(m->iarena.end(), l1uv.begin(), l1uv.end());
+        m->iarena.insert(m->iarena.end(), lk.begin(), lk.end());
     }
     // GlobalInfo.fc_1 reads in_current = x[:, RF // F] flattened (rie.py:290-292), zero padded to CUR_LD
     {
-        std::vector<int> l1(CUR_LD, ENC_INVALID), lk(CUR_LD / 4, 1);
-        for (int col = 0; col < JF; ++col) l1[col] = col * 4;
+        std::vector<int> l1(CUR_LD, ENC_INVALID), l1uv(CUR_LD, ENC_INVALID), lk(CUR_LD / 4, 1);
+        for (int col = 0; col < JF; ++col) {
+            l1[col] = col * 4;
+            l1uv[col] = ((col / F) * 2 + (col % F > 0 ? 1 : 0)) * 4 + col % F;
+        }
         m->global_lut_off = m->iarena.size();
         m->iarena.insert(m->iarena.end(), l1.begin(), l1.end());
+        m->iarena.insert(m->iarena.end(), lk.begin(), lk.end());
+        m->global_lut_uv_off = m->iarena.size();
+        m->iarena.insert(m->iarena.end(), l1uv.begin(), l1uv.end());
         m->iarena.insert(m->iarena.end(), lk.begin(), lk.end());
     }
     for (auto &kv : m->layer_index)

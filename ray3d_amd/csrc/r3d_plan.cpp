@@ -41,7 +41,8 @@ struct Builder {
     bool first_level_fused = false;
     struct In { int buf, col, ld, width, dep; };
     int problem(const std::string &layer_prefix, int rows_pw, const std::vector<In> &ins, int res_buf, int res_col,
-                int res_ld, int c_buf, int c_col, int c_ld, std::vector<int> extra_deps = {}, int enc_lut = -1) {
+                int res_ld, int c_buf, int c_col, int c_ld, std::vector<int> extra_deps = {}, int enc_lut = -1,
+                int enc_lut_uv = -1) {
         ProbSpec q;
         q.model = mi;
         q.layer = m.layer_index.at(layer_prefix);
@@ -50,6 +51,8 @@ struct Builder {
         q.layer2 = -1;
         q.layer3 = -1;
         q.enc_lut = enc_lut;
+        q.enc_lut_uv = m.cfg.in_features == 3 ? enc_lut_uv : -1;
+        q.enc_kernel = enc_lut >= 0 && !first_level_fused;
         q.enc_rows = rows_pw;
         const Layer &L0 = m.layers[q.layer];
         int k = enc_lut >= 0 ? L0.Kpad : 0;
@@ -79,10 +82,10 @@ struct Builder {
     // FCBlock.forward (lib/model/rie.py:159-169): fc_1+bn+lrelu, n residual units, fc_2.
     // c_buf < 0: the last Linear is left to the fused decoder kernel (recorded in plan.decs).
     int fc_block(const std::string &prefix, const std::vector<In> &ins, int nblocks, int c_buf, int c_col, int c_ld,
-                 int enc_lut = -1) {
+                 int enc_lut = -1, int enc_lut_uv = -1) {
         const int H = MLP_HIDDEN;
         const int h = buffer(prefix + ".h", H), y = buffer(prefix + ".y", H);
-        int last = problem(prefix + ".fc_1", 1, ins, -1, 0, 0, h, 0, H, {}, enc_lut);
+        int last = problem(prefix + ".fc_1", 1, ins, -1, 0, 0, h, 0, H, {}, enc_lut, enc_lut_uv);
         for (int n = 0; n < nblocks; ++n) {
             const std::string q = prefix + ".layers." + std::to_string(n);
             const int p1 = problem(q + ".w1", 1, {{h, 0, H, H, last}}, -1, 0, 0, y, 0, H);
@@ -115,7 +118,7 @@ struct Builder {
         if (first_level_fused) {
             // expand_conv + level 1 (3-tap and 1x1 convolutions) as one problem of rows/3 output rows per window
             const std::string a = br.prefix + ".layers_conv.0", b = br.prefix + ".layers_conv.1";
-            last = problem(br.prefix + ".expand_conv", rows / 3, {}, -1, 0, 0, pp[1], 0, C, {}, (int)br.lut_off);
+            last = problem(br.prefix + ".expand_conv", rows / 3, {}, -1, 0, 0, pp[1], 0, C, {}, (int)br.lut_off, (int)br.lut_uv_off);
             ProbSpec &q = p.probs[last];
             q.enc_rows = rows;
             q.layer2 = m.layer_index.at(a);
@@ -124,7 +127,7 @@ struct Builder {
             rows /= 3;
             i0 = 2;
         } else {
-            last = problem(br.prefix + ".expand_conv", rows, {}, -1, 0, 0, pp[0], 0, C, {}, (int)br.lut_off);
+            last = problem(br.prefix + ".expand_conv", rows, {}, -1, 0, 0, pp[0], 0, C, {}, (int)br.lut_off, (int)br.lut_uv_off);
         }
         for (int i = i0; i < L; ++i) {
             const int src = pp[(i - 1) & 1], dst = pp[i & 1];
@@ -179,15 +182,9 @@ static Plan *build_plan(const Model *a, const Model *b) {
             pe = B.problem("embedder.w2", 1, {{eh, 0, EMBED_MID, EMBED_MID, p1}}, -1, 0, 0, pl->emb_buf[mi], 0, D);
         }
         const int g = B.buffer("global", lat);
-        int pg;
-        if (B.first_level_fused) {
-            // in_current = x[:, RF // F] (rie.py:290-292) read in place: a matrix whose rows are a window stride apart
-            if (pl->xcur_buf < 0) pl->xcur_buf = B.buffer("x.current", 0, 4);
-            const int JF = m->cfg.num_joints * m->cfg.in_features;
-            pg = B.fc_block("GlobalInfo", {{pl->xcur_buf, 0, 0, JF, -1}}, 2, g, 0, lat);
-        } else {
-            pg = B.fc_block("GlobalInfo", {}, 2, g, 0, lat, (int)m->global_lut_off);
-        }
+        // in_current = x[:, RF // F] (rie.py:290-292): gathered from the raw input like the first layers' operands (one
+        // row per window, every column relative to the window's current frame) - in UV mode encoded on the way
+        const int pg = B.fc_block("GlobalInfo", {}, 2, g, 0, lat, (int)m->global_lut_off, (int)m->global_lut_uv_off);
         if (m->cfg.kind == R3D_KIND_POS) {
             pl->pos_model = mi;
             const int tmp5 = B.buffer("tmp5", 5 * lat);

@@ -282,7 +282,7 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
         if (q.layer3 >= 0) bytes += 4.0 * (double)L.N * L.N + 4.0 * 2.0 * (double)(M - row0) * L.K;   // (three input rows per output row)
     }
     bool enc = false;
-    for (int e : st) enc = enc || (pl->probs[e & ~STAGE_SPILL_IN].enc_lut >= 0 && pl->probs[e & ~STAGE_SPILL_IN].layer3 < 0);
+    for (int e : st) enc = enc || pl->probs[e & ~STAGE_SPILL_IN].enc_kernel;
     // the fused-prologue kernel runs two workgroups per CU (one encodes while the other multiplies)
     schedule_stage(probs, enc ? 2 * nwg : nwg, GEMM_SCHED_MAX_UNITS, tiles, wgoff, out, enc);
     out.flops = flops;

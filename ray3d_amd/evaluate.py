@@ -78,14 +78,19 @@ def predict_clip(lift_clip: Callable, clip: Clip, rf: int, device, flip: bool = 
     return pred
 
 
-def clip_partials_hip(pred_norm: torch.Tensor, clip: Clip, action_id: int = 0) -> torch.Tensor:
+def clip_partials_hip(pred_norm: torch.Tensor, clip: Clip, action_id: int = 0,
+                      gt_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """clip_partials on the GPU through r3d_clip_metrics: world transform, the five error sums and the per-frame
-    Procrustes fits in one float64 kernel on the current stream - no D2H copy of the predictions."""
+    Procrustes fits in one float64 kernel on the current stream - no D2H copy of the predictions.
+    `gt_dev`: the clip's ground truth already on the device (callers that keep a data set resident in HBM)."""
     from . import _capi
     dev = pred_norm.device
     n = pred_norm.shape[0]
     pred = pred_norm.reshape(n, -1, 3).contiguous().float()
-    gt = torch.from_numpy(np.ascontiguousarray(clip.gt_norm, dtype=np.float32)).to(dev, non_blocking=True).reshape(n, -1, 3)
+    if gt_dev is not None:
+        gt = gt_dev.to(dev, torch.float32).reshape(n, -1, 3).contiguous()
+    else:
+        gt = torch.from_numpy(np.ascontiguousarray(clip.gt_norm, dtype=np.float32)).to(dev, non_blocking=True).reshape(n, -1, 3)
     assert gt.shape == pred.shape, "ground truth %s vs prediction %s" % (tuple(gt.shape), tuple(pred.shape))
     sums = torch.empty(_capi.METRIC_OUT_DOUBLES, dtype=torch.float64, device=dev)
     _capi.clip_metrics(pred.data_ptr(), gt.data_ptr(), n, pred.shape[1], np.asarray(clip.camera.Rn2w, dtype=np.float64),

@@ -379,19 +379,31 @@ class Ray3DLifter(nn.Module):
 
     def forward_uv(self, uv: torch.Tensor, cam_rows: torch.Tensor, param: Optional[torch.Tensor] = None,
                    window_stride: Optional[int] = None):
-        """Pixel keypoints in, rays computed on the fly (lib/camera/camera.py:423-471, float64).
-        uv (B,RF,J,2) float32 [or a padded clip (N+RF-1,J,2) with window_stride=1];
-        cam_rows (B,8) or (8,) float64 {fx,fy,cx,cy,cos(pitch),sin(pitch),0,0};
+        """Pixel keypoints in; the rays are computed inside the first layers' gathers (float64 then cast, as
+        lib/camera/camera.py:423-471 + lib/train_val/trainer.py:298 do on the host) - no rays tensor exists.
+        uv (B,RF,J,2) float32 - or a frame sequence (T,J,2) with `window_stride` (1: slide over an edge-padded clip);
+        window i covers frames [i*stride, i*stride + RF) and is encoded with ITS camera row, also where windows
+        overlap (BASELINE configs[3]: mixed intrinsics per batch);
+        cam_rows (B,8) or (8,) float64 {fx,fy,cx,cy,cos(pitch),sin(pitch),0,0} (:meth:`Camera.cam_row`);
         param (B,E) or (E,) float32 [height, pitch]."""
         rf = self.receptive_field()
         uv = uv.detach().to(torch.float32).contiguous()
+        if self.pos.in_features != 3:
+            raise RuntimeError("forward_uv needs INPUT_DIM == 3 models (the ray encoding has three components)")
         if uv.dim() == 4:
+            assert uv.shape[1] == rf and uv.shape[2] == self.pos.num_joints_in and uv.shape[3] == 2
             B, ws_ = uv.shape[0], rf
+            if window_stride is not None and window_stride != rf:
+                raise RuntimeError("a (B,RF,J,2) batch has window_stride == RF")
         else:
-            B, ws_ = uv.shape[0] - rf + 1, 1
-        if window_stride is not None:
-            ws_ = window_stride
+            assert uv.dim() == 3 and uv.shape[1] == self.pos.num_joints_in and uv.shape[2] == 2
+            ws_ = 1 if window_stride is None else int(window_stride)
+            if ws_ < 1 or uv.shape[0] < rf:
+                raise RuntimeError("window_stride must be >= 1 and the sequence at least RF frames long")
+            B = (uv.shape[0] - rf) // ws_ + 1
         cam = cam_rows.detach().to(uv.device, torch.float64).contiguous()
+        if cam.dim() == 2 and cam.shape != (B, 8) or cam.dim() == 1 and cam.shape != (8,):
+            raise RuntimeError("cam_rows must be (%d, 8) or (8,), got %s" % (B, tuple(cam.shape)))
         p = param.detach().to(uv.device, torch.float32).contiguous() if self.pos.camera_embedding else None
         return self._run(_capi.R3D_INPUT_UV, uv, ws_, B, p,
                          0 if (p is None or p.dim() == 1) else self.pos.extrinsic_dim,

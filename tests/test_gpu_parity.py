@@ -104,28 +104,173 @@ def test_forward_clip_equals_materialised_windows():
         c += 1.0                                                   # caller-owned and writable (trainer.py:353)
 
 
-def test_forward_uv_matches_host_ray_encoding():
-    """uv + per-window camera rows -> rays on the GPU (float64) == reference-pinned host encoding."""
+def _reference_cameras():
+    """The real H36M / 3DHP calibration tables of tests/golden/cameras.npz (reference-generated), as product cameras
+    and as oracle cameras (the C restatement, pinned to the same fixture by tests/test_oracle.py)."""
     import os
     import ray3d_amd
     from conftest import GOLDEN
-    from ray3d_amd import synth
+    from oracle import oracle
     z = np.load(os.path.join(GOLDEN, "cameras.npz"))
     tags = [t for t in z["tags"]]
-    cams = [ray3d_amd.Camera(z[t + "/K"], z[t + "/R"], z[t + "/t"]) for t in tags]
-    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3")
+    return ([ray3d_amd.Camera(z[t + "/K"], z[t + "/R"], z[t + "/t"]) for t in tags],
+            [oracle.Camera(z[t + "/K"], z[t + "/R"], z[t + "/t"]) for t in tags], z, tags)
+
+
+@pytest.mark.parametrize("arch,B", [("3,3", 24), ("3,3,3,3,3", 48)])
+def test_forward_uv_matches_oracle_on_reference_cameras(arch, B):
+    """BASELINE configs[3] (mixed intrinsics per batch) at RF 9 and RF 243: pixel keypoints + one camera row PER WINDOW in,
+    rays encoded inside the first-level gather.  Comparand: the ORACLE chain - rays from the oracle's camera restatement
+    (float64, pinned to the reference's uv -> ray pairs in cameras.npz), cast as lib/train_val/trainer.py:298 does, through
+    oracle.forward.  Also: bit-identical to the HIP path fed with those rays (the encoding is the same float64 arithmetic),
+    and no more launches than the rays mode (no separate encoding kernel)."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    from oracle import oracle
+    cams, ocams, z, tags = _reference_cameras()
+    mc = ray3d_amd.default_model_config(ARCHITECTURE=arch)
+    pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    rf = cp.receptive_field
+    uv = (1000.0 * synth.hash_uniform("uvtest%d" % rf, (B, rf, 17, 2), 9)).astype(np.float32)
+    pick = [i % len(cams) for i in range(B)]
+    rays = np.stack([ocams[c].rays_from_uv(uv[i].astype(np.float64)) for i, c in enumerate(pick)]).astype(np.float32)
+    # the fixture's own uv -> ray pairs pin that encoding to the reference
+    t0 = tags[0]
+    assert np.abs(ocams[0].rays_from_uv(z[t0 + "/uv"]) - z[t0 + "/rays"]).max() < 1e-12
+    rows = np.stack([cams[c].cam_row() for c in pick])
+    par = np.stack([cams[c].param() for c in pick])
+    uvd, rowsd, pard = torch.from_numpy(uv).cuda(), torch.from_numpy(rows).cuda(), torch.from_numpy(par).cuda()
+    with torch.no_grad():
+        a = lifter.forward_uv(uvd, rowsd, pard)
+        b = lifter(torch.from_numpy(rays).cuda(), pard)
+    ref = oracle.forward(cp, sp, rays, par) + oracle.forward(ct, st, rays, par)
+    assert np.abs(a.cpu().numpy() - ref).max() <= tol_for(ref), np.abs(a.cpu().numpy() - ref).max()
+    assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+    h = lifter.pos.handle(uvd.device)
+    counts = []
+    for run in (lambda: lifter.forward_uv(uvd, rowsd, pard), lambda: lifter(torch.from_numpy(rays).cuda(), pard)):
+        h.profile_enable(True)
+        with torch.no_grad():
+            run()
+        recs = [r for r in h.profile_read() if r["stage"] >= 0]
+        h.profile_enable(False)
+        counts.append(len(recs))
+        assert not any("prologue" in r["kernel"] for r in recs)
+    assert counts[0] == counts[1], counts
+
+
+def test_forward_uv_overlapping_windows_each_with_its_own_camera():
+    """Windows that share frames but not the camera (window_stride < RF with per-window camera rows): every window's
+    frames are encoded with THAT window's camera - equal to materialising the windows and encoding each on the host.
+    Also the sliding-clip form (stride 1, one camera) against forward_clip on host-encoded rays."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    cams, _, _, _ = _reference_cameras()
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
     pos, trj, (cp, _), _ = build_modules(mc)
     lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
-    B = 24                                           # mixed intrinsics per batch (BASELINE configs[3])
-    uv = (1000.0 * synth.hash_uniform("uvtest", (B, 9, 17, 2), 9)).astype(np.float32)
-    pick = [cams[i % len(cams)] for i in range(B)]
-    rays = np.stack([c.rays_from_uv(uv[i].astype(np.float64)) for i, c in enumerate(pick)]).astype(np.float32)
-    rows = np.stack([c.cam_row() for c in pick])
-    par = np.stack([c.param() for c in pick])
+    rf, stride, B = 27, 5, 40
+    T = (B - 1) * stride + rf
+    seq = (1000.0 * synth.hash_uniform("uvseq", (T, 17, 2), 3)).astype(np.float32)
+    pick = [cams[(3 * i) % len(cams)] for i in range(B)]
+    windows = np.stack([pick[i].rays_from_uv(seq[i * stride:i * stride + rf].astype(np.float64)) for i in range(B)]).astype(np.float32)
+    rows, par = np.stack([c.cam_row() for c in pick]), np.stack([c.param() for c in pick])
     with torch.no_grad():
-        a = lifter.forward_uv(torch.from_numpy(uv).cuda(), torch.from_numpy(rows).cuda(), torch.from_numpy(par).cuda())
-        b = lifter(torch.from_numpy(rays).cuda(), torch.from_numpy(par).cuda())
-    assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())   # float64 ray math on both sides -> identical rays
+        a = lifter.forward_uv(torch.from_numpy(seq).cuda(), torch.from_numpy(rows).cuda(), torch.from_numpy(par).cuda(),
+                              window_stride=stride)
+        b = lifter(torch.from_numpy(windows).cuda(), torch.from_numpy(par).cuda())
+        assert a.shape == (B, 1, 17, 3) and np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+        cam = cams[1]
+        n = 100
+        clip_uv = (1000.0 * synth.hash_uniform("uvclip", (n + rf - 1, 17, 2), 4)).astype(np.float32)
+        lifter.CLIP_ROUND = 0
+        c = lifter.forward_uv(torch.from_numpy(clip_uv).cuda(), torch.from_numpy(cam.cam_row()).cuda(),
+                              torch.from_numpy(cam.param()).cuda())
+        d = lifter.forward_clip(torch.from_numpy(cam.rays_from_uv(clip_uv.astype(np.float64)).astype(np.float32)).cuda(),
+                                torch.from_numpy(cam.param()).cuda())
+    assert c.shape == (n, 1, 17, 3) and np.array_equal(c.cpu().numpy(), d.cpu().numpy())
+
+
+def _oracle_lift(states, windows, prm, threads=None):
+    """pos + trj through oracle/torch_port.py (the PyTorch-CPU restatement, pinned to the reference fixtures)."""
+    from oracle import torch_port
+    (cp, sp), (ct, st) = states
+    sds = [{k: torch.from_numpy(np.asarray(v)) for k, v in s.items()} for s in (sp, st)]
+    out = []
+    with torch.no_grad():
+        for i in range(0, windows.shape[0], 512):
+            xw, pw = torch.from_numpy(windows[i:i + 512]), torch.from_numpy(prm[i:i + 512])
+            out.append((torch_port.forward(cp, sds[0], xw, pw) + torch_port.forward(ct, sds[1], xw, pw)).numpy())
+    return np.concatenate(out)
+
+
+def test_h36m_shape_eval_rf243_against_the_oracle_chain():
+    """BASELINE configs[2] on one GPU: the Human3.6M evaluation SHAPE (the data set is not in the image: synthetic clips,
+    lengths ~ U(1000, 6000) frames, four cameras, fifteen actions) at RF 243 through evaluate_clips(forward_clip) with the
+    default chunking (2048 windows per forward, tail rounded to 128) and r3d_clip_metrics.  Against the oracle chain
+    (lib/train_val/trainer.py:283-405 restated: edge pad, materialised windows, CPU forward, float64 world transform,
+    NumPy metrics): the per-clip partial rows of three whole clips, and 64 sampled frames of every other clip."""
+    import ray3d_amd
+    from ray3d_amd import evaluate
+    from oracle import oracle, metrics_oracle as mo
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3,3,3")
+    pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    assert (lifter.CLIP_CHUNK, lifter.CLIP_ROUND) == (2048, 128)
+    rng = np.random.default_rng(0)
+    cams = [ray3d_amd.synthetic_camera(yaw, 4.5, -12.0, name="cam%d" % i) for i, yaw in enumerate((20, 110, 200, 290))]
+    clips = []
+    n_clips = 40
+    for i in range(n_clips):
+        n = int(rng.integers(1000, 6001))
+        cam = cams[i % 4]
+        # a slowly moving skeleton: per-frame noise on a random walk, so that sliding windows differ from frame to frame
+        world = rng.normal(0, 0.3, (1, 17, 3)) + np.array([0, 0, 1.0]) + 0.02 * np.cumsum(rng.normal(0, 1.0, (n, 1, 3)), axis=0) \
+            + rng.normal(0, 0.02, (n, 17, 3))
+        rays = cam.rays_from_uv(cam.project(world)).astype(np.float32)
+        clips.append(evaluate.Clip(cam, rays, cam.world2normalized(world).astype(np.float32), "A%d" % (i % 15), i))
+    dev = torch.device("cuda:0")
+    with torch.no_grad():
+        named, avg, rows = evaluate.evaluate_clips(lifter.forward_clip, clips, 243, dev)
+        torch.cuda.synchronize()
+    rows = rows.cpu().numpy()
+    assert rows.shape == (n_clips, evaluate.PARTIAL_COLS) and np.all(np.isfinite(rows))
+    assert sorted(rows[:, 0].astype(int).tolist()) == list(range(n_clips))
+    assert len(named) == 15
+    by_id = {int(r[0]): r for r in rows}
+    order = sorted(range(n_clips), key=lambda i: clips[i].rays.shape[0])
+    whole = [order[0], order[1], order[len(order) // 3]]           # three whole clips (the two shortest and a mid-sized one)
+    states = ((cp, sp), (ct, st))
+    for cid in range(n_clips):
+        c = clips[cid]
+        n = c.rays.shape[0]
+        assert int(by_id[cid][2]) == n
+        padded = evaluate.pad_clip(c.rays, 121)                      # generators.py:213-216
+        if cid in whole:
+            frames = np.arange(n)
+        else:
+            # the seams of the 2048-window chunks and of the rounded tail, the clip's ends, and random frames
+            seams = np.clip([0, 1, n - 2, n - 1, 2047, 2048, (n // 2048) * 2048 - 1, (n // 2048) * 2048], 0, n - 1)
+            frames = np.unique(np.concatenate([seams, rng.integers(0, n, 64)]))[:64]
+        windows = np.stack([padded[i:i + 243] for i in frames])    # trainer.py:47-58
+        prm = np.tile(c.camera.param(), (len(frames), 1))            # trainer.py:297,324
+        ref = _oracle_lift(states, windows, prm).reshape(len(frames), 17, 3)
+        if cid in whole:
+            pw, gw = c.camera.normalized2world(ref), c.camera.normalized2world(c.gt_norm)       # trainer.py:358-359
+            want = np.array([mo.mpjpe(pw, gw), mo.p_mpjpe(pw, gw), mo.n_mpjpe(pw[:, None], gw[:, None]),
+                             mo.mean_velocity_error(pw, gw), mo.mpjpe(pw[:, :1], gw[:, :1])]) * 1000.0
+            got = by_id[cid][3:8] / n * 1000.0
+            assert np.abs(got - want).max() < 0.1, (cid, n, got, want)                      # millimetres
+            # the C restatement on a few of the same windows (the torch port is the bulk checker)
+            few = [0, n // 2, n - 1]
+            cref = (oracle.forward(cp, sp, windows[few], prm[few]) + oracle.forward(ct, st, windows[few], prm[few])).reshape(3, 17, 3)
+            assert np.abs(cref - ref[few]).max() <= 1e-4
+        else:
+            with torch.no_grad():
+                pred = evaluate.predict_clip(lifter.forward_clip, c, 243, dev)
+            got = pred.reshape(n, 17, 3)[torch.from_numpy(frames).to(dev)].cpu().numpy()
+            assert np.abs(got - ref).max() <= tol_for(ref), (cid, n, np.abs(got - ref).max())
 
 
 @pytest.mark.parametrize("flip", [False, True])
@@ -176,7 +321,11 @@ def test_full_size_batch_properties():
     # summation orders: agreement is to rounding noise of the ~14-layer chain, not bit-exact
     assert (full[perm] - permuted).abs().max().item() <= 6e-5         # windows are independent
     assert (full - halves).abs().max().item() <= 6e-5
-    idx = [0, 77, 255]
+    # every window against the oracle chain (torch port: every tile class - first / last row unit of every launch, the
+    # spilled first-level tiles, the split-K tiles of the M = B layers), and a spread of them against the C restatement
+    ref_all = _oracle_lift(((cp, sp), (ct, st)), x, p)
+    assert np.abs(full.cpu().numpy() - ref_all).max() <= tol_for(ref_all), np.abs(full.cpu().numpy() - ref_all).max()
+    idx = [0, 31, 32, 77, 128, 200, 254, 255]
     ref = oracle.forward(cp, sp, x[idx], p[idx]) + oracle.forward(ct, st, x[idx], p[idx])
     assert np.abs(full[idx].cpu().numpy() - ref).max() <= tol_for(ref)
     # output buffer is fresh and caller-owned (callers mutate it in place, trainer.py:340-353)
@@ -198,6 +347,10 @@ def test_large_batch_1024():
         parts = torch.cat([lifter(x[i:i + 256].contiguous(), p[i:i + 256].contiguous()) for i in range(0, 1024, 256)])
     assert torch.isfinite(big).all()
     assert (big - parts).abs().max().item() <= 6e-5
+    idx = np.unique(np.concatenate([np.arange(0, 1024, 8), [1, 31, 32, 33, 1022, 1023]]))      # 134 windows over every tile class
+    (cp, sp), (ct, st) = synth_states(mc)
+    ref = _oracle_lift(((cp, sp), (ct, st)), x[idx].cpu().numpy(), p[idx].cpu().numpy())
+    assert np.abs(big[idx].cpu().numpy() - ref).max() <= tol_for(ref)
 
 
 def test_universal_14_joint_batch_4096():
@@ -218,7 +371,9 @@ def test_universal_14_joint_batch_4096():
         parts = torch.cat([lifter(xd[i:i + 512].contiguous(), pd[i:i + 512].contiguous()) for i in range(0, B, 512)])
     assert big.shape == (B, 1, 14, 3) and torch.isfinite(big).all()
     assert (big - parts).abs().max().item() <= 6e-5
-    idx = [0, 1, 2047, 4095]
+    ref_all = _oracle_lift(((cp, sp), (ct, st)), x, p)              # all 4096 windows against the torch port
+    assert np.abs(big.cpu().numpy() - ref_all).max() <= tol_for(ref_all), np.abs(big.cpu().numpy() - ref_all).max()
+    idx = [0, 1, 31, 32, 511, 512, 2047, 4095]
     ref = oracle.forward(cp, sp, x[idx], p[idx]) + oracle.forward(ct, st, x[idx], p[idx])
     assert np.abs(big[idx].cpu().numpy() - ref).max() <= tol_for(ref)
 

@@ -85,12 +85,12 @@ int main(int argc, char **argv) {
     printf("grid %d tiles %d ks %d kind %d imbalance %.3f (CUs %d)\n", ss.nwg, ss.ntiles, ss.ks, ss.kind, ss.imbalance, nwg);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) CK(launch_gemm_stage(la, ss.nwg, ss.kind, 0));
+    for (int i = 0; i < 3; ++i) CK(launch_gemm_stage(la, ss.nwg, ss.kind, false, 0));
     CK(hipDeviceSynchronize());
     float best = 1e9, sum = 0;
     for (int i = 0; i < reps; ++i) {
         CK(hipEventRecord(e0, 0));
-        CK(launch_gemm_stage(la, ss.nwg, ss.kind, 0));
+        CK(launch_gemm_stage(la, ss.nwg, ss.kind, false, 0));
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
