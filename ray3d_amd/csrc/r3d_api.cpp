@@ -176,6 +176,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
                 g.enc_cur = (a->RF / a->cfg.in_features) * JF;   // quirk Q1: "current" frame is RF // in_features
                 g.enc_bytes = (unsigned)((size_t)frames * JF * sizeof(float));
                 g.res_tap = 1 + m->cfg.causal;
+                g.fl_v1 = first_level_v1() ? 1 : 0;
             }
             g.w = m->d_arena + L.w_off;
             if (L.bf3 && q.layer2 < 0 && q.enc_lut < 0)
@@ -243,8 +244,11 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
                 for (int t = 0; t < 8; ++t) {
                     const long long *q = &ht[w * 64 + t * 8];
                     if (!q[0]) continue;
-                    fprintf(stderr, "  wg %2d tile %d: %6.2f %6.2f %6.2f %6.2f | total %6.2f\n", w, t, (q[1] - q[0]) / 100.0,
+                    fprintf(stderr, "  wg %2d tile %d: %6.2f %6.2f %6.2f %6.2f | total %6.2f", w, t, (q[1] - q[0]) / 100.0,
                             (q[2] - q[1]) / 100.0, (q[3] - q[2]) / 100.0, (q[4] - q[3]) / 100.0, (q[4] - q[0]) / 100.0);
+                    if (q[5]) fprintf(stderr, " | first tap: expand %6.2f  H write %6.2f  3-tap third %6.2f", (q[5] - q[0]) / 100.0,
+                                      (q[6] - q[5]) / 100.0, (q[7] - q[6]) / 100.0);
+                    fprintf(stderr, "\n");
                 }
         }
 #endif

@@ -100,7 +100,9 @@ __device__ __forceinline__ void store_tile(ProbRef P, const f32x16 (&acc)[MI], c
     constexpr int COLS = GEMM_BN / KS, WN = 8 / KS;
     constexpr int TPR = COLS / 4;                 // threads per output row (16 bytes each)
     constexpr int RPP = GEMM_THREADS / TPR;       // rows per pass: 8 / 16 / 32
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                 // (opaque: keeps this function's per-thread constants out of the persistent loop's preheader)
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int M = P.M, N = P.N;
     const float slope = second ? P.slope2 : P.slope;
     const float *res = P.res;
@@ -708,7 +710,8 @@ __device__ __forceinline__ void enc_tile(ProbRef P, const int row0, const int co
     R3D_TSTAMP(0);
     constexpr int R = MI * 32;
     constexpr int NA = (R + 63) / 64;
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int M = P.M, K = P.K;
@@ -1135,6 +1138,340 @@ __device__ __forceinline__ void first_level_run(ProbRef P, const int4 *tile_list
   }
 }
 
+
+// ------------------------------------------------------------------------------------ first level, tap by tap
+//
+// first_level_taps: the same three layers for 32 * MI output rows (MI = 1, 2), organised around the taps of the 3-tap
+// convolution instead of around the 96 expand_conv rows of a 32-row tile.  Output row r of the level reads the
+// expand_conv rows 3r, 3r+1, 3r+2 - one per tap - so the tile walks the taps: gather the raw elements of the rows
+// {3r + tap}, run expand_conv on them (activations -> H, one [32 MI x C] buffer in MFMA operand order), multiply H
+// with the tap's third of the 3-tap weights into the level's accumulators, next tap.  Only ONE tap's activations
+// are alive at a time, which is what lets a tile hold 64 output rows in 67 KB where the row-major form needed 100 KB
+// for 32: every weight fragment of the two big layers now feeds two row blocks (a single-row-block K loop is bound
+// by the weight stream), and half as many weight bytes cross the L2.  The residual tap (centre;
+// the last one for causal models, rie.py:92-94) is visited LAST and its activations simply stay in the expand
+// accumulators: they have the C layout of the final accumulators (same wavefront, same columns, same rows), so the
+// residual add of the epilogue is register + register.  (Summation order over the taps therefore differs from the
+// reference's k-major order; the result is the same to fp32 rounding.)
+//   per tap:  raw values (requested one phase earlier) -> G (encoded on the way in UV mode) | barrier |
+//             request the next phase's raw values | expand_conv MFMAs on G          [K0 > 64: in chunks of 64 columns]
+//             activations -> H | barrier | 3-tap partial: C/32 K tiles, weights streaming, barrier-free
+//   then:     level activations -> H | barrier | 1x1 convolution | epilogue (+ residual from registers) through H.
+// G is double buffered, so a phase costs one barrier.
+constexpr int FLT_MAX_MI = 2;
+constexpr int FLT_H_FLOATS = FLT_MAX_MI * 32 * PAIR_LD;                  // 16,640
+constexpr int FLT_G_LD = 64 + 4;                                         // a 64-column chunk, conflict-free b128 rows
+constexpr int FLT_G_FLOATS = FLT_MAX_MI * 32 * FLT_G_LD;                 //  4,352 per buffer
+constexpr int FLT_LUT_OFF = FLT_H_FLOATS + 2 * FLT_G_FLOATS;
+static_assert((FLT_LUT_OFF + FL_LUT_INTS) * 4 <= GEMM_LDS_BYTES, "the tap-wise first level fits the GEMM kernel's LDS allocation");
+
+template <int MI, bool MULTI, bool UV>   // MULTI: K0 > 64 (several 64-column chunks per tap: the trajectory model)
+__device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_list, const int ntiles, const bool new_prob, float *smem,
+                                                 long long *dbg_base) {
+    static_assert(MI >= 1 && MI <= FLT_MAX_MI, "tile height");
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int w_voff = lane * 16;
+    const int srow = tid >> 3, a_kq = (tid & 7) * 4;         // staging: 64 rows x 8 threads x 4 columns per K tile
+    const int K0 = P.K, nk0 = K0 / BK, nch = (nk0 + 1) >> 1;
+    const int M = P.M, M0 = 3 * M;
+    const int res_tap = P.res_tap;
+    float *H = smem, *G0 = smem + FLT_H_FLOATS;
+    int *lut_lds = reinterpret_cast<int *>(smem + FLT_LUT_OFF);
+    const int *lut1 = lut_lds, *lutk = lut_lds + K0;
+    if (new_prob) {
+        for (int i = tid; i < K0 + K0 / 4; i += GEMM_THREADS) lut_lds[i] = *(const R3D_AS1 int *)(P.lut + i);
+    }
+    __syncthreads();                                         // (also: the previous tile is done with LDS)
+    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x), 0, P.enc_bytes, 0x00020000);
+    auto load_frag = [&](__amdgpu_buffer_rsrc_t rs, int kt, f32x4 (&dst)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            dst[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, w_voff + q * 1024, kt * 4096, 0));
+    };
+    const int nk1 = P.K2 / BK, tiles_per_tap = nk1 / 3, nk2 = P.K3 / BK;
+    __amdgpu_buffer_rsrc_t w0rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.w + ((size_t)wave_u * nk0) * 1024), 0, nk0 * 4096, 0x00020000);
+    __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.w2 + ((size_t)wave_u * nk1) * 1024), 0, nk1 * 4096, 0x00020000);
+    __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.w3 + ((size_t)wave_u * nk2) * 1024), 0, nk2 * 4096, 0x00020000);
+    const float bias0 = gload1(P.bias + wave * 32 + li), slope0 = P.slope;
+    const float bias1 = gload1(P.bias2 + wave * 32 + li), slope1 = P.slope2;
+    const float bias2 = gload1(P.bias3 + wave * 32 + li), slope2 = P.slope3;
+
+    // ---- gather state of the phase whose raw values are in flight / in registers
+    struct Raw { f32x4 a[2]; };                              // the two K tiles of a 64-column chunk
+    Raw gq;
+    unsigned b_first, b_cur;
+    const bool on = srow < MI * 32;
+    CamRow camr;
+    auto issue_phase = [&](int row0, int tap, int ch) {      // tile rows [row0, row0 + 32 MI), expand_conv rows 3r + tap
+        const int orow = row0 + srow;
+        const int e = 3 * (orow < M ? orow : M - 1) + tap;
+        const int win = e / P.enc_rows, t3 = e - win * P.enc_rows;
+        const unsigned wbase = (unsigned)win * (unsigned)P.enc_ws;
+        b_first = (wbase + (unsigned)(t3 * 3 * P.enc_jf)) * 4;
+        b_cur = (wbase + (unsigned)P.enc_cur) * 4;
+        if constexpr (UV) camr = load_cam_row(P.cam + (long long)win * P.cam_stride);
+        if (!on) return;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = (ch * 2 + h) * BK + a_kq;
+            if (MULTI && k >= K0) break;                     // (uniform: the last chunk may hold one K tile)
+            const int4 o1 = *reinterpret_cast<const int4 *>(lut1 + k);
+            const unsigned b = lutk[k >> 2] != 0 ? b_cur : b_first;
+            const int c1[4] = {o1.x & ~3, o1.y & ~3, o1.z & ~3, o1.w & ~3};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                gq.a[h][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, b + (unsigned)c1[c], 0, 0));
+        }
+    };
+    auto commit_phase = [&](int ch, float *G) {
+        if (!on) return;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = (ch * 2 + h) * BK + a_kq;
+            if (MULTI && k >= K0) break;
+            f32x4 v = gq.a[h];
+            if constexpr (UV) {
+                const int4 code = *reinterpret_cast<const int4 *>(lut1 + k);
+                v[0] = uv_to_ray(v[0], code.x, camr);
+                v[1] = uv_to_ray(v[1], code.y, camr);
+                v[2] = uv_to_ray(v[2], code.z, camr);
+                v[3] = uv_to_ray(v[3], code.w, camr);
+            }
+            *reinterpret_cast<f32x4 *>(G + srow * FLT_G_LD + h * BK + a_kq) = v;
+        }
+    };
+
+    f32x4 rb[4], rbn[4], rbn2[4];                            // streaming weight fragments (three sets rotating)
+    // expand_conv fragments: two K tiles per 64-column chunk.  One chunk (K0 <= 64): resident in w0a/w0b for the whole
+    // run.  Several: chunks alternate between the sets (w0a, w0b) and (w0c, w0d), the next chunk's fragments requested
+    // in front of the current chunk's matrix work; chunk 0 returns to the first set after every tap's 3-tap loop.
+    f32x4 w0a[4], w0b[4], w0c[4], w0d[4];
+    load_frag(w0rsrc, 0, w0a);
+    load_frag(w0rsrc, nk0 > 1 ? 1 : 0, w0b);
+    int phase = 0;                                           // parity selects the G buffer
+    auto tap_of = [&](int ts) { return ts == 0 ? 0 : ts == 2 ? res_tap : 3 - res_tap; };   // the residual tap comes last
+    issue_phase(__builtin_amdgcn_readfirstlane(tile_list[0].y), 0, 0);
+#pragma unroll 1
+    for (int ti = 0; ti < ntiles; ++ti) {
+        const int row0 = __builtin_amdgcn_readfirstlane(tile_list[ti].y);
+        const int next_row0 = ti + 1 < ntiles ? __builtin_amdgcn_readfirstlane(tile_list[ti + 1].y) : -1;
+#ifdef R3D_TIMING
+        long long *dbg = dbg_base && ti < 8 ? dbg_base + ti * 8 : nullptr;
+#else
+        long long *dbg = nullptr;
+        (void)dbg;
+#endif
+        R3D_TSTAMP(0);
+        f32x16 acc0[MI], acc1[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[mi][r] = 0.0f;
+#pragma unroll 1
+        for (int ts = 0; ts < 3; ++ts) {
+            const int tap = tap_of(ts);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc0[mi][r] = 0.0f;
+            // ---- expand_conv on the rows {3r + tap}, one 64-column chunk of the operand per phase
+            auto chunk = [&](int ch, f32x4 (&ua)[4], f32x4 (&ub)[4], f32x4 (&la)[4], f32x4 (&lb)[4]) {
+                float *G = G0 + (phase & 1) * FLT_G_FLOATS;
+                commit_phase(ch, G);
+                __syncthreads();
+                if constexpr (MULTI) {
+                    if (ch + 1 < nch) {
+                        load_frag(w0rsrc, (ch + 1) * 2, la);
+                        load_frag(w0rsrc, (ch + 1) * 2 + 1 < nk0 ? (ch + 1) * 2 + 1 : (ch + 1) * 2, lb);
+                    }
+                }
+                // the next phase's raw values, in front of this phase's matrix work
+                if (ch + 1 < nch) issue_phase(row0, tap, ch + 1);
+                else if (ts < 2) issue_phase(row0, tap_of(ts + 1), 0);
+                else if (next_row0 >= 0) issue_phase(next_row0, 0, 0);
+                const float *a_frag = G + li * FLT_G_LD + lh * 16;
+                const int nkc = ch * 2 + 1 < nk0 ? 2 : 1;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (h >= nkc) break;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 av[MI];
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) av[mi] = *reinterpret_cast<const f32x4 *>(a_frag + mi * 32 * FLT_G_LD + h * BK + q * 4);
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi)
+                                acc0[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][kk], h == 0 ? ua[q][kk] : ub[q][kk], acc0[mi], 0, 0, 0);
+                    }
+                }
+                ++phase;
+            };
+            if constexpr (MULTI) {
+#pragma unroll 1
+                for (int ch = 0; ch < nch; ch += 2) {
+                    chunk(ch, w0a, w0b, w0c, w0d);
+                    if (ch + 1 < nch) chunk(ch + 1, w0c, w0d, w0a, w0b);
+                }
+            } else {
+                chunk(0, w0a, w0b, w0c, w0d);
+            }
+            if (ts == 0) R3D_TSTAMP(5);
+            // ---- activations (in place: the residual tap's stay in acc0 for the epilogue) -> H
+            load_frag(w1rsrc, tap * tiles_per_tap, rb);
+            load_frag(w1rsrc, tap * tiles_per_tap + (tiles_per_tap > 1 ? 1 : 0), rbn);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                float *wr = H + (mi * 32 + 4 * lh) * PAIR_LD + wave * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc0[mi][r] + bias0;
+                    v = v > 0.0f ? v : v * slope0;
+                    acc0[mi][r] = v;
+                    wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = v;
+                }
+            }
+            __syncthreads();
+            if (ts == 0) R3D_TSTAMP(6);
+            // ---- this tap's third of the 3-tap convolution: K = C, barrier-free, weights two K tiles ahead
+            {
+                const float *h_frag = H + li * PAIR_LD + lh * 16;
+                const int kbase = tap * tiles_per_tap, lastk = tiles_per_tap - 1;
+                auto k_tile1 = [&](int kin, f32x4 (&w_use)[4], f32x4 (&w_load)[4]) {
+                    load_frag(w1rsrc, kbase + (kin + 2 < lastk ? kin + 2 : lastk), w_load);
+                    const float *sp = h_frag + kin * BK;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 av[MI];
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) av[mi] = *reinterpret_cast<const f32x4 *>(sp + mi * 32 * PAIR_LD + q * 4);
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi)
+                                acc1[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][kk], w_use[q][kk], acc1[mi], 0, 0, 0);
+                    }
+                };
+                int kin = 0;
+                for (; kin + 2 < tiles_per_tap; kin += 3) {
+                    k_tile1(kin, rb, rbn2);
+                    k_tile1(kin + 1, rbn, rb);
+                    k_tile1(kin + 2, rbn2, rbn);
+                }
+                if (kin < tiles_per_tap) {
+                    k_tile1(kin, rb, rbn2);
+                    if (kin + 1 < tiles_per_tap) k_tile1(kin + 1, rbn, rb);
+                }
+            }
+            // (no barrier here: the next tap's first chunk phase has one between this loop and the next write of H)
+            if (ts == 0) R3D_TSTAMP(7);
+            if constexpr (MULTI) {
+                if (ts < 2) {                                // chunk 0 again for the next tap (the streaming sets are dead here)
+                    load_frag(w0rsrc, 0, w0a);
+                    load_frag(w0rsrc, nk0 > 1 ? 1 : 0, w0b);
+                }
+            }
+        }
+        R3D_TSTAMP(1);
+        // ---- level activations -> H; the 1x1 convolution on them
+        load_frag(w2rsrc, 0, rb);
+        load_frag(w2rsrc, nk2 > 1 ? 1 : 0, rbn);
+        __syncthreads();                                     // every wavefront is done reading the last tap's H
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            float *wr = H + (mi * 32 + 4 * lh) * PAIR_LD + wave * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc1[mi][r] + bias1;
+                wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = v > 0.0f ? v : v * slope1;
+            }
+        }
+        __syncthreads();
+        R3D_TSTAMP(2);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[mi][r] = 0.0f;
+        {
+            const float *h_frag = H + li * PAIR_LD + lh * 16;
+            const int last2 = nk2 - 1;
+            auto k_tile2 = [&](int kt, f32x4 (&w_use)[4], f32x4 (&w_load)[4]) {
+                load_frag(w2rsrc, kt + 2 < last2 ? kt + 2 : last2, w_load);
+                const float *sp = h_frag + kt * BK;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 av[MI];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) av[mi] = *reinterpret_cast<const f32x4 *>(sp + mi * 32 * PAIR_LD + q * 4);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+                            acc1[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][kk], w_use[q][kk], acc1[mi], 0, 0, 0);
+                }
+            };
+            int kt = 0;
+            for (; kt + 2 < nk2; kt += 3) {
+                k_tile2(kt, rb, rbn2);
+                k_tile2(kt + 1, rbn, rb);
+                k_tile2(kt + 2, rbn2, rbn);
+            }
+            if (kt < nk2) {
+                k_tile2(kt, rb, rbn2);
+                if (kt + 1 < nk2) k_tile2(kt + 1, rbn, rb);
+            }
+        }
+        R3D_TSTAMP(3);
+        if constexpr (MULTI) {
+            if (next_row0 >= 0) {                            // chunk 0 for the next tile: lands behind the epilogue
+                load_frag(w0rsrc, 0, w0a);
+                load_frag(w0rsrc, nk0 > 1 ? 1 : 0, w0b);
+            }
+        }
+        // ---- epilogue: + the residual tap's activations (registers), rows transposed through H, 1 KiB stores
+        __syncthreads();                                     // every wavefront is done reading H
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            float *wr = H + (mi * 32 + 4 * lh) * PAIR_LD + wave * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc1[mi][r] + bias2;
+                v = v > 0.0f ? v : v * slope2;
+                wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = v + acc0[mi][r];
+            }
+        }
+        __syncthreads();
+        {
+            const int rd_row = tid >> 6, rd_c4 = (tid & 63) * 4;
+            const int N = P.N;
+#pragma unroll
+            for (int j = 0; j < 4 * MI; ++j) {
+                const int lr = rd_row + 8 * j, row = row0 + lr;
+                if (row >= M) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(H + lr * PAIR_LD + rd_c4);
+                if (rd_c4 + 4 <= N) {
+                    __builtin_nontemporal_store(v, (R3D_AS1 f32x4 *)(P.c + (size_t)row * P.ldc + rd_c4));
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (rd_c4 + c < N) gstore1(P.c + (size_t)row * P.ldc + rd_c4 + c, v[c]);
+                }
+            }
+        }
+        __syncthreads();                                     // H is free for the next tile's activations
+        R3D_TSTAMP(4);
+    }
+    (void)M0;
+}
+
 template <bool ENC, bool UV>
 __device__ __forceinline__ void gemm_persistent(float *smem) {
     LaunchArgsPtr args = (LaunchArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1179,14 +1516,22 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
         } else {
             if (P.w3 != nullptr) {       // first level of the pyramid, fused (32 output rows per tile): this
                 int n = 1;               // workgroup's consecutive tiles of the problem as one run
-                while (t + n < t1 && __builtin_amdgcn_readfirstlane(args->tiles[t + n].x & 0xff) == pi) ++n;
+                while (t + n < t1 && __builtin_amdgcn_readfirstlane(args->tiles[t + n].x) == __builtin_amdgcn_readfirstlane(td.x)) ++n;   // same problem, same height
 #ifdef R3D_TIMING
                 long long *run_dbg = dbg_base && t - t0 < 8 ? dbg_base + (t - t0) * 8 : nullptr;
 #else
                 long long *run_dbg = nullptr;
 #endif
-                if (P.K <= 64) first_level_run<3, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
-                else first_level_run<1, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                if (P.fl_v1) {           // the row-major form (one 32-row tile at a time), kept for A/B runs: R3D_FL_V1=1
+                    if (P.K <= 64) first_level_run<3, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                    else first_level_run<1, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                } else if (P.K <= 64) {
+                    if (mi >= 2) first_level_taps<2, false, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                    else first_level_taps<1, false, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                } else {
+                    if (mi >= 2) first_level_taps<2, true, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                    else first_level_taps<1, true, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                }
                 t += n - 1;
                 continue;
             }
