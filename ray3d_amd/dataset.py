@@ -32,6 +32,13 @@ H36M_32_TO_17 = (0, 1, 2, 3, 6, 7, 8, 12, 13, 14, 15, 17, 18, 19, 25, 26, 27)   
 KEEP_UNIVERSAL_14_OF_17 = (0, 1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, 15, 16)      # h36m_dataset.py:430, mpii_3dhp:357
 SYMMETRY_17 = ((4, 5, 6, 11, 12, 13), (1, 2, 3, 14, 15, 16))                    # joints_left, joints_right
 SYMMETRY_14 = ((4, 5, 6, 8, 9, 10), (1, 2, 3, 11, 12, 13))                      # h36m_dataset.py:432
+SYMMETRY_HUMANEVA_15 = ((2, 3, 4, 8, 9, 10), (5, 6, 7, 11, 12, 13))             # humaneva_dataset.py:7-9 (joints_left, joints_right)
+HUMANEVA_15_TO_UNIVERSAL_14 = (0, 11, 12, 13, 8, 9, 10, 14, 2, 3, 4, 5, 6, 7)   # humaneva_dataset.py:126,150: order AND selection
+# Subjects of the camera-augmented H36M set: the seven originals and their copies scaled by 0.6 ... 1.1
+# (lib/dataset/h36m_aug_dataset.py:26-34); every one of them is seen by every camera of the JSON list.
+H36M_AUG_SCALES = ("0.6", "0.7", "0.8", "0.9", "1.1")
+H36M_AUG_SUBJECTS = tuple(["S1", "S5", "S6", "S7", "S8", "S9", "S11"] +
+                          ["%s_%s" % (s, k) for k in H36M_AUG_SCALES for s in ("S1", "S5", "S6", "S7", "S8", "S9", "S11")])
 
 
 def cameras_from_tables(extrinsics: Mapping[str, Sequence[Mapping]], intrinsics: Optional[Sequence[Mapping]] = None,
@@ -68,6 +75,51 @@ def cameras_from_tables(extrinsics: Mapping[str, Sequence[Mapping]], intrinsics:
     return out
 
 
+def cameras_from_json(camera_meta, subjects: Sequence[str] = H36M_AUG_SUBJECTS) -> Tuple[Dict[str, List[Camera]], List[str]]:
+    """The camera-augmented H36M front end (lib/dataset/h36m_aug_dataset.py:21-60): ONE list of cameras - the JSON file
+    ``data/aggregate_camera.py`` writes from the per-camera files of ``data/camera_augmentation.py:720-731``, each entry
+    holding ``id, center, focal_length, radial_distortion, tangential_distortion, res_w, res_h, azimuth, R, translation`` -
+    shared by every subject of the set (the originals and the scaled copies ``S1_0.9`` ...).  ``camera_meta`` is that
+    list or the path of the JSON file.  Unlike the plain H36M tables nothing is rounded to float32 and the translation
+    is already in metres (:44-53); the cameras are built with ``undistort=False`` (:57-59).
+    Returns ``({subject: [Camera per JSON entry]}, camera ids)`` - the ids are ``camera_dist`` of
+    ``CAMERA_WISE_PERFORMANCE`` (:36-41), in file order."""
+    if isinstance(camera_meta, (str, bytes)):
+        import json
+        with open(camera_meta, "r") as fh:
+            camera_meta = json.load(fh)
+    per_cam = []
+    ids = []
+    for cam in camera_meta:
+        K = np.eye(3, dtype=np.float64)
+        K[0, 0], K[1, 1] = cam["focal_length"][0], cam["focal_length"][1]
+        K[0, 2], K[1, 2] = cam["center"][0], cam["center"][1]
+        R = np.array(cam["R"], dtype=np.float64).reshape(3, 3)
+        t = np.array(cam["translation"], dtype=np.float64).reshape(3, 1)
+        dist = np.array(list(cam["radial_distortion"][:2]) + list(cam["tangential_distortion"]) +
+                        list(cam["radial_distortion"][2:]), dtype=np.float64).reshape(5)
+        per_cam.append((K, R, t, dist))
+        ids.append(str(cam["id"]))
+    out = {s: [Camera(K, R, t, dist_coeff=d, undistort=False, name="%s/%s" % (s, cid))
+               for (K, R, t, d), cid in zip(per_cam, ids)] for s in subjects}
+    return out, ids
+
+
+def cameras_humaneva(extrinsics: Mapping[str, Sequence[Mapping]], intrinsics: Sequence[Mapping],
+                     undistort: bool = True) -> Dict[str, List[Camera]]:
+    """HumanEva-I's layout (lib/dataset/humaneva_dataset.py:70-106): per-subject extrinsic tables ('S1', 'S2', 'S3'),
+    one intrinsic table per camera index, numbers through float32 and translations from millimetres (:76-82), and every
+    subject's cameras registered under BOTH archive prefixes, ``'Train/S1'`` and ``'Validate/S1'`` (:100-104).  The
+    reference builds these cameras with CameraInfoPacket's default ``undistort=True``; that path is the OpenCV
+    restatement of :meth:`Camera.undistort_points` (parity unpinned)."""
+    base = cameras_from_tables(extrinsics, intrinsics, translation_divisor=1000, undistort=undistort)
+    out: Dict[str, List[Camera]] = {}
+    for subject, cams in base.items():
+        for prefix in ("Train/", "Validate/"):
+            out[prefix + subject] = cams
+    return out
+
+
 @dataclass
 class PoseData:
     """What ``Data`` + ``fetch_via_action`` hand to the evaluation loop, as clips."""
@@ -78,6 +130,7 @@ class PoseData:
     joints_left: List[int]
     joints_right: List[int]
     actions: Dict[str, List[int]] = field(default_factory=dict)    # action key ('Walking' of 'Walking 1') -> clip ids
+    camera_index: List[int] = field(default_factory=list)          # per clip: index of its camera in the subject's list
 
 
 def _per_camera_keypoints(entry) -> np.ndarray:
@@ -113,6 +166,7 @@ def load_pose_data(path_3d: str, path_2d: str, cameras: Mapping[str, Sequence[Ca
         kps_right = [pos[j] for j in kps_right if j in pos]
     clips: List[Clip] = []
     groups: Dict[str, List[int]] = {}
+    cam_of_clip: List[int] = []
     n_joints = None
     for subject in subjects:
         if subject not in a3:
@@ -157,10 +211,12 @@ def load_pose_data(path_3d: str, path_2d: str, cameras: Mapping[str, Sequence[Ca
                 cid = len(clips)
                 clips.append(Clip(cam, rays.astype(np.float32), gt.astype(np.float32), key, cid))
                 groups.setdefault(key, []).append(cid)
+                cam_of_clip.append(ci)
     if joints_symmetry is not None:
         jl, jr = joints_symmetry
     elif n_joints in (14, 17, None):
         jl, jr = SYMMETRY_14 if n_joints == 14 else SYMMETRY_17
     else:
-        raise ValueError("give joints_symmetry=(left, right) for a %d-joint skeleton" % n_joints)
-    return PoseData(clips, list(subjects), kps_left, kps_right, list(jl), list(jr), groups)
+        raise ValueError("give joints_symmetry=(left, right) for a %d-joint skeleton (HumanEva's 15 joints: "
+                         "dataset.SYMMETRY_HUMANEVA_15)" % n_joints)
+    return PoseData(clips, list(subjects), kps_left, kps_right, list(jl), list(jr), groups, cam_of_clip)

@@ -135,6 +135,33 @@ def reduce_partials(rows: torch.Tensor) -> Dict[int, tuple]:
     return out
 
 
+def reduce_camera_wise(rows: torch.Tensor, camera_index: Sequence[int], camera_ids: Sequence[str]) -> List[tuple]:
+    """``CAMERA_WISE_PERFORMANCE`` (lib/train_val/trainer.py:425-446) from the gathered per-clip rows: for every camera
+    of the list (file order) and every action, the frame-weighted errors of THAT camera's clips (what
+    ``fetch_via_action(..., camera_idx=cam_idx)`` + ``evaluate_core`` produce); after each camera the reference logs
+    the mean over all (camera, action) errors collected SO FAR - its lists are not reset between cameras - rounded to
+    0.1 mm.  ``camera_index[clip_id]`` is the clip's camera position (``PoseData.camera_index``).
+    Returns ``[(camera id, (p1, p2, p3, vel, root))]`` in that cumulative form; :func:`format_camera_report` prints it."""
+    rows = rows.detach().to("cpu", torch.float64)
+    cam_of = torch.tensor([int(camera_index[int(c)]) for c in rows[:, 0].tolist()], dtype=torch.int64)
+    collected: List[List[float]] = []
+    out = []
+    for ci, cid in enumerate(camera_ids):
+        sel_c = rows[cam_of == ci]
+        for a in sorted(set(int(v) for v in sel_c[:, 1].tolist())):
+            sel = sel_c[sel_c[:, 1] == a]
+            n = sel[:, 2].sum()
+            collected.append([float(sel[:, c].sum() / n * 1000.0) for c in (3, 4, 5, 6, 7)])
+        if collected:
+            out.append((str(cid), tuple(round(float(v), 1) for v in np.mean(np.array(collected), axis=0))))
+    return out
+
+
+def format_camera_report(per_camera: Sequence[tuple]) -> List[str]:
+    """'CAM ID <id>, p1 p2 p3 vel root' lines (trainer.py:446)."""
+    return ["CAM ID %s, %s %s %s %s %s" % ((cid,) + tuple(v)) for cid, v in per_camera]
+
+
 def action_average(per_action: Dict[int, tuple]) -> tuple:
     """Unweighted mean over actions, rounded to 0.1 mm like trainer.py:473-477."""
     arr = np.array(list(per_action.values()), dtype=np.float64)

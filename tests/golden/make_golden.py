@@ -15,6 +15,8 @@ What is pinned:
   3. evalcore.npz     : Trainer.evaluate_core's five metrics (with and without flip TTA) and its
      return_predictions output on synthetic clips.
   4. losses.npz       : mpjpe / n_mpjpe / p_mpjpe / mean_velocity_error known answers.
+  6. frontends.npz    : the camera-augmented H36M front end (JSON camera list, scaled subjects, per-camera fetches) and
+     HumanEva-I's camera layout / joint conventions.
   5. dataset.npz      : the reference's Data front end on a small synthetic archive pair: per-clip ground truth in
      the normalised frame and ray-encoded keypoints, the left/right index lists, the H36M joint selection.
 Only numbers leave this script; no reference source text is stored.
@@ -303,6 +305,105 @@ def gen_dataset():
     print("dataset: clips", {k: v.shape for k, v in blob.items() if k.startswith("rays/")}, "kept", blob["h36m_kept_17"])
 
 
+def gen_frontends():
+    """The other two camera front ends of the reference, on small synthetic archives:
+    (a) the camera-augmented H36M set (lib/dataset/h36m_aug_dataset.py through lib/dataset/__init__.py ``Data``): a
+        JSON camera list shared by the original and the scaled subjects, 32-joint mocap archive reduced to 17 joints,
+        per-camera fetches as ``CAMERA_WISE_PERFORMANCE`` does them;
+    (b) HumanEva-I (lib/dataset/humaneva_dataset.py): the camera tables registered under 'Train/' and 'Validate/'
+        prefixes, the 15-joint symmetry lists and the universal 14-joint selection.  Its cameras are built with
+        undistort=True, whose only effect in the constructor is ``pp_cam`` (through cv2, absent here: the stub below
+        returns the points unchanged) - no number stored here depends on it."""
+    import json
+    import tempfile
+    from lib.dataset import Data
+    rng = np.random.default_rng(23)
+    blob = {}
+    # ---------------- (a) h36m_aug
+    cams_json = []
+    for i in range(3):
+        e = dict(h36m_cameras_intrinsic_params[i])
+        ext = h36m_cameras_extrinsic_params["S9"][i]
+        e["R"] = np.array(ext["R"], dtype=np.float64).tolist()
+        e["translation"] = (np.array(ext["translation"], dtype=np.float64).reshape(3, 1) / 1000.0).tolist()
+        cams_json.append(e)
+    subjects = ["S9", "S9_0.9"]
+    acts = {"Walk 1": 14, "Sit": 9}
+    pos3d, pos2d = {}, {}
+    keep17 = [0, 1, 2, 3, 6, 7, 8, 12, 13, 14, 15, 17, 18, 19, 25, 26, 27]
+    for s_i, sub in enumerate(subjects):
+        pos3d[sub], pos2d[sub] = {}, {}
+        for act, n in acts.items():
+            pw = rng.normal(0, 0.35, (n, 32, 3)) * (0.9 if s_i else 1.0) + np.array([0.2, -0.1, 0.95])
+            pos3d[sub][act] = pw.astype(np.float32)
+            views = []
+            for e in cams_json:
+                R, t = np.array(e["R"]), np.array(e["translation"]).reshape(3, 1)
+                pc = pw[:, keep17] @ R.T + t.T
+                uv = np.stack([pc[..., 0] / pc[..., 2] * e["focal_length"][0] + e["center"][0],
+                               pc[..., 1] / pc[..., 2] * e["focal_length"][1] + e["center"][1]], -1)
+                views.append((uv + rng.normal(0, 0.5, uv.shape)).astype(np.float32))
+            pos2d[sub][act] = views
+    meta = {"layout_name": "h36m", "num_joints": 17, "keypoints_symmetry": [[4, 5, 6, 11, 12, 13], [1, 2, 3, 14, 15, 16]]}
+    with tempfile.TemporaryDirectory() as d:
+        p3, p2, pj = os.path.join(d, "d3.npz"), os.path.join(d, "d2.npz"), os.path.join(d, "cams.json")
+        np.savez_compressed(p3, positions_3d=pos3d)
+        np.savez_compressed(p2, positions_2d=pos2d, metadata=meta)
+        json.dump(cams_json, open(pj, "w"), indent=4)
+        data = Data({"DATASET": "h36m_aug", "CAMERA_PARAM": pj, "CAMERA_WISE_PERFORMANCE": True, "WORLD_3D_GT_EVAL": True,
+                     "KEYPOINTS": "gt", "REMOVE_IRRELEVANT_KPTS": False, "GT_3D": p3, "GT_2D": p2, "FRAME_PATH": d,
+                     "INTRINSIC_ENCODING": False, "RAY_ENCODING": True, "DOWNSAMPLE": 1})
+        ds = data.get_dataset()
+        blob["aug/cams_json"] = np.array(json.dumps(cams_json))
+        blob["aug/camera_dist"] = np.array([str(c) for c in ds.camera_dist])
+        blob["aug/subjects_all"] = np.array(list(ds.camera_info.keys()))
+        blob["aug/subjects"] = np.array(subjects)
+        blob["aug/actions"] = np.array(list(acts.keys()))
+        for s_i, sub in enumerate(subjects):
+            for a_i, act in enumerate(acts):
+                blob["aug/in3d/%d/%d" % (s_i, a_i)] = pos3d[sub][act]
+                for ci in range(3):
+                    blob["aug/in2d/%d/%d/%d" % (s_i, a_i, ci)] = pos2d[sub][act][ci]
+                    cams, p3d, p2d = data.fetch_via_action([(sub, act)], camera_idx=ci)
+                    assert len(p3d) == 1 and len(p2d) == 1
+                    blob["aug/gt_norm/%d/%d/%d" % (s_i, a_i, ci)] = p3d[0]
+                    blob["aug/rays/%d/%d/%d" % (s_i, a_i, ci)] = p2d[0]
+        for ci in range(3):
+            c = ds.camera_info["S9_0.9"][ci]
+            blob["aug/cam%d/Rn2w" % ci], blob["aug/cam%d/Tn2w" % ci] = c.Rn2w, c.Tn2w
+            blob["aug/cam%d/height_pitch" % ci] = np.array([c.cam_orig_world.reshape(-1)[2], c.cam_pitch_rad])
+    # ---------------- (b) HumanEva
+    import cv2 as cv2_stub
+    cv2_stub.undistortPoints = lambda pts, K, dist, P=None: pts          # only feeds pp_cam, which nothing here reads
+    from lib.dataset.humaneva_dataset import (HumanEvaDataset, humaneva_cameras_extrinsic_params,
+                                              humaneva_cameras_intrinsic_params, humaneva_skeleton)
+    with tempfile.TemporaryDirectory() as d:
+        p3 = os.path.join(d, "he3.npz")
+        np.savez_compressed(p3, positions_3d={"Train/S1": {"Walking 1 chunk0": rng.normal(0, 0.3, (5, 15, 3)).astype(np.float32)}})
+        he = HumanEvaDataset(p3)
+        keys = list(he.camera_info.keys())
+        blob["he/keys"] = np.array(keys)
+        blob["he/ext_json"] = np.array(json.dumps(humaneva_cameras_extrinsic_params))
+        blob["he/int_json"] = np.array(json.dumps(humaneva_cameras_intrinsic_params))
+        for k in keys:
+            c = he.camera_info[k][0]
+            tag = "he/" + k.replace("/", "_")
+            blob[tag + "/K"], blob[tag + "/Rn2w"], blob[tag + "/Tn2w"] = c.K, c.Rn2w, c.Tn2w
+            blob[tag + "/height_pitch"] = np.array([c.cam_orig_world.reshape(-1)[2], c.cam_pitch_rad])
+            blob[tag + "/dist"] = c.dist_coeff
+            blob[tag + "/n"] = np.array(len(he.camera_info[k]))
+        blob["he/joints_left"] = np.array(humaneva_skeleton.joints_left())
+        blob["he/joints_right"] = np.array(humaneva_skeleton.joints_right())
+        kp = {"positions_2d": np.array({"Train/S1": {"A": [np.arange(2 * 15 * 2, dtype=np.float32).reshape(2, 15, 2)]}}, dtype=object),
+              "metadata": np.array({"layout_name": "humaneva15", "num_joints": 15, "keypoints_symmetry": [[2, 3, 4, 8, 9, 10], [5, 6, 7, 11, 12, 13]]}, dtype=object)}
+        upd, upd_meta = HumanEvaDataset.remove_irrelevant_kpts(kp, universal=True)
+        blob["he/universal_in"] = kp["positions_2d"].item()["Train/S1"]["A"][0]
+        blob["he/universal_out"] = upd["Train/S1"]["A"][0]
+        blob["he/universal_symmetry"] = np.array(upd_meta["keypoints_symmetry"])
+    np.savez_compressed(os.path.join(HERE, "frontends.npz"), **blob)
+    print("frontends: aug subjects", len(blob["aug/subjects_all"]), "camera_dist", list(blob["aug/camera_dist"]), "| humaneva keys", keys)
+
+
 def gen_losses():
     a = (synth.hash_uniform("loss.a", (6, 1, 17, 3), 5) * 2 - 1)
     b = a + 0.1 * (synth.hash_uniform("loss.b", (6, 1, 17, 3), 5) * 2 - 1)
@@ -320,12 +421,15 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:                      # python make_golden.py <case> ... | dataset: only those
         if "dataset" in sys.argv[1:]:
             gen_dataset()
-        gen_models(only=set(sys.argv[1:]) - {"dataset"} or {"-"})
+        if "frontends" in sys.argv[1:]:
+            gen_frontends()
+        gen_models(only=set(sys.argv[1:]) - {"dataset", "frontends"} or {"-"})
         sys.exit(0)
     gen_cameras()
     gen_losses()
     gen_models()
     gen_evalcore()
     gen_dataset()
+    gen_frontends()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("total fixture bytes: %.2f MB" % (tot / 1e6))

@@ -504,3 +504,91 @@ def test_plans_do_not_outlive_a_partner_model():
         assert fn(hp.ptr, ht.ptr, 200, 256, ctypes.byref(n), ctypes.byref(sp)) == 0, over
         ht.close()                                     # the plan goes with it
     hp.close()
+
+
+# ------------------------------------------------------------------ camera-augmented H36M and HumanEva front ends
+
+def test_h36m_aug_json_cameras_and_per_camera_fetch(tmp_path):
+    """ray3d_amd.dataset.cameras_from_json + load_pose_data vs the reference's h36m_aug front end
+    (lib/dataset/h36m_aug_dataset.py through lib/dataset/__init__.py Data; tests/golden/frontends.npz): one JSON camera
+    list for the original and the scaled subjects, 32-joint mocap reduced to 17 joints, per-camera clips."""
+    import json
+    from ray3d_amd import dataset
+    z = np.load(os.path.join(GOLDEN, "frontends.npz"))
+    meta = json.loads(str(z["aug/cams_json"]))
+    pj = str(tmp_path / "cams.json")
+    json.dump(meta, open(pj, "w"))
+    cams, ids = dataset.cameras_from_json(pj)
+    assert list(cams.keys()) == [str(s) for s in z["aug/subjects_all"]] == list(dataset.H36M_AUG_SUBJECTS)
+    assert ids == [str(c) for c in z["aug/camera_dist"]]
+    for ci in range(3):
+        c = cams["S9_0.9"][ci]
+        assert c is not cams["S9"][ci] and np.array_equal(c.Rn2w, cams["S9"][ci].Rn2w)      # same calibration for every subject
+        assert np.abs(c.Rn2w - z["aug/cam%d/Rn2w" % ci]).max() < 1e-12
+        assert np.abs(c.Tn2w - z["aug/cam%d/Tn2w" % ci]).max() < 1e-12
+        assert np.abs(np.array([c.height, c.pitch]) - z["aug/cam%d/height_pitch" % ci]).max() < 1e-12
+    subjects, acts = [str(s) for s in z["aug/subjects"]], [str(a) for a in z["aug/actions"]]
+    pos3d = {s: {a: z["aug/in3d/%d/%d" % (si, ai)] for ai, a in enumerate(acts)} for si, s in enumerate(subjects)}
+    pos2d = {s: {a: [z["aug/in2d/%d/%d/%d" % (si, ai, ci)] for ci in range(3)] for ai, a in enumerate(acts)}
+             for si, s in enumerate(subjects)}
+    p3, p2 = str(tmp_path / "d3.npz"), str(tmp_path / "d2.npz")
+    np.savez_compressed(p3, positions_3d=pos3d)
+    np.savez_compressed(p2, positions_2d=pos2d, metadata={"layout_name": "h36m", "num_joints": 17,
+                                                          "keypoints_symmetry": [[4, 5, 6, 11, 12, 13], [1, 2, 3, 14, 15, 16]]})
+    pd = dataset.load_pose_data(p3, p2, cams, subjects, joints_3d=dataset.H36M_32_TO_17)
+    assert len(pd.clips) == len(subjects) * len(acts) * 3 and pd.camera_index == [0, 1, 2] * (len(subjects) * len(acts))
+    k = 0
+    for si in range(len(subjects)):
+        for ai in range(len(acts)):
+            for ci in range(3):
+                c = pd.clips[k]
+                assert np.array_equal(c.gt_norm, z["aug/gt_norm/%d/%d/%d" % (si, ai, ci)].astype(np.float32))
+                assert np.array_equal(c.rays, z["aug/rays/%d/%d/%d" % (si, ai, ci)].astype(np.float32))
+                k += 1
+    assert set(pd.actions) == {"Walk", "Sit"}
+
+
+def test_camera_wise_reduction_follows_the_reference_loop():
+    """evaluate.reduce_camera_wise vs a literal restatement of lib/train_val/trainer.py:425-446 (cumulative means)."""
+    rng = np.random.default_rng(5)
+    n_clips, n_cam, n_act = 24, 3, 4
+    rows = np.zeros((n_clips, evaluate.PARTIAL_COLS))
+    cam_of = [i % n_cam for i in range(n_clips)]
+    for i in range(n_clips):
+        n = int(rng.integers(50, 200))
+        rows[i] = [i, (i // n_cam) % n_act, n] + list(n * rng.uniform(0.02, 0.08, 5))
+    got = evaluate.reduce_camera_wise(torch.from_numpy(rows[rng.permutation(n_clips)]), cam_of, ["a", "b", "c"])
+    lists = [[] for _ in range(5)]
+    want = []
+    for ci, cid in enumerate(["a", "b", "c"]):
+        for a in range(n_act):                                         # evaluate_core per (camera, action): trainer.py:399-403
+            sel = [r for i, r in enumerate(rows) if cam_of[i] == ci and int(r[1]) == a]
+            n = sum(r[2] for r in sel)
+            for m in range(5):
+                lists[m].append(sum(r[3 + m] for r in sel) / n * 1000.0)
+        want.append((cid, tuple(round(float(np.mean(l)), 1) for l in lists)))
+    assert got == want
+    assert evaluate.format_camera_report(got)[0].startswith("CAM ID a, ")
+
+
+def test_humaneva_camera_layout_and_joint_conventions():
+    """ray3d_amd.dataset.cameras_humaneva / SYMMETRY_HUMANEVA_15 / HUMANEVA_15_TO_UNIVERSAL_14 vs
+    lib/dataset/humaneva_dataset.py (tests/golden/frontends.npz)."""
+    import json
+    from ray3d_amd import dataset
+    z = np.load(os.path.join(GOLDEN, "frontends.npz"))
+    ext, intr = json.loads(str(z["he/ext_json"])), json.loads(str(z["he/int_json"]))
+    cams = dataset.cameras_humaneva(ext, intr)
+    assert list(cams.keys()) == [str(k) for k in z["he/keys"]]
+    for k, cl in cams.items():
+        tag = "he/" + k.replace("/", "_")
+        assert len(cl) == int(z[tag + "/n"])
+        c = cl[0]
+        assert c.undistort and np.abs(c.dist_coeff - z[tag + "/dist"]).max() < 1e-12
+        assert np.abs(c.K - z[tag + "/K"]).max() < 1e-12
+        assert np.abs(c.Rn2w - z[tag + "/Rn2w"]).max() < 1e-12 and np.abs(c.Tn2w - z[tag + "/Tn2w"]).max() < 1e-12
+        assert np.abs(np.array([c.height, c.pitch]) - z[tag + "/height_pitch"]).max() < 1e-12
+    assert list(dataset.SYMMETRY_HUMANEVA_15[0]) == list(z["he/joints_left"])
+    assert list(dataset.SYMMETRY_HUMANEVA_15[1]) == list(z["he/joints_right"])
+    assert np.array_equal(z["he/universal_in"][:, list(dataset.HUMANEVA_15_TO_UNIVERSAL_14)], z["he/universal_out"])
+    assert [list(v) for v in dataset.SYMMETRY_14] == z["he/universal_symmetry"].tolist()
