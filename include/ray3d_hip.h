@@ -57,6 +57,12 @@ typedef struct {
                             * not a configuration the reference can run (rie.py:94-97 raises);
                             * DISABLE_OPTIMIZATIONS alone computes the same function for an
                             * RF-long window and needs no flag.                             */
+    int32_t dense;         /* DENSE with DISABLE_OPTIMIZATIONS (the dense-convolution ablation,
+                            * rie.py:49-53): level i's convolution has 2*3^i + 1 taps, stride 1,
+                            * and every level is evaluated at all RF positions of a window
+                            * (cost grows with RF^2: meant for the short receptive fields the
+                            * ablation is run at).  DENSE without DISABLE_OPTIMIZATIONS is
+                            * ignored by the reference constructor (:54-55): pass 0.          */
 } r3d_config;
 
 typedef struct r3d_model r3d_model;

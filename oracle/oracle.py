@@ -23,7 +23,7 @@ class _Tensor(C.Structure):
 
 class _Config(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("kind", "num_joints", "in_features", "num_levels",
-                                       "channels", "latent", "stage", "extrinsic_dim", "embed_dim", "causal")]
+                                       "channels", "latent", "stage", "extrinsic_dim", "embed_dim", "causal", "dense")]
 
 
 class _Camera(C.Structure):
@@ -62,7 +62,8 @@ def _cfg_struct(cfg) -> _Config:
     return _Config(0 if cfg.kind == "pos" else 1, cfg.num_joints, cfg.in_features,
                    len(cfg.filter_widths), cfg.channels, cfg.latent, cfg.stage,
                    cfg.extrinsic_dim if cfg.camera_embedding else 0,
-                   cfg.embed_dim if cfg.camera_embedding else 0, 1 if cfg.causal else 0)
+                   cfg.embed_dim if cfg.camera_embedding else 0, 1 if cfg.causal else 0,
+                   1 if cfg.dense_convs else 0)
 
 
 def forward(cfg, state: Dict[str, np.ndarray], x: np.ndarray, param: Optional[np.ndarray],

@@ -150,8 +150,11 @@ static void emit(r3o_tap_fn tap, void *user, const char *name, const float *d, i
 /* TemporalBlock.forward, lib/model/rie.py:85-105, on one RF-long window: the strided (Optimize1f) form; the
  * dilated form (:91-92) evaluates the same ternary tree, with the residual at the last tap when causal.
  * x: channels-last (B*T, Cin) with T = 3^L.  out: (B, latent). */
+static int temporal_block_dense(store *s, const r3o_config *cfg, const char *prefix, const float *x,
+                                int64_t B, int64_t T, int64_t Cin, float *out, r3o_tap_fn tap, void *user);
 static int temporal_block(store *s, const r3o_config *cfg, const char *prefix, const float *x,
                           int64_t B, int64_t T, int64_t Cin, float *out, r3o_tap_fn tap, void *user) {
+    if (cfg->dense) return temporal_block_dense(s, cfg, prefix, x, B, T, Cin, out, tap, user);
     const int64_t C = cfg->channels;
     char key[256], tapname[256];
     int64_t rows = B * T / 3;
@@ -203,6 +206,73 @@ static int temporal_block(store *s, const r3o_config *cfg, const char *prefix, c
     const float *bs = want(s, key, 1, cfg->latent, 0, 0);
     if (!ws || !bs) { free(cur); return s->err; }
     conv_stride_k(cur, B * Tcur, C, ws, 1, bs, cfg->latent, out);           /* :99 shrink */
+    free(cur);
+    emit(tap, user, prefix, out, B, cfg->latent, 0, 2);
+    return 0;
+}
+
+/* nn.Conv1d(Cin, Cout, k) (stride 1, no padding) on channels-last x (B, T, Cin) -> y (B, T-k+1, Cout): the k input
+ * frames of an output position are k*Cin contiguous floats, so each window is one GEMM whose rows overlap
+ * (row stride Cin).  lib/model/rie.py:34,49-53 (the un-optimised constructor branch). */
+static void conv_dense_k(const float *x, int64_t B, int64_t T, int64_t Cin, const float *w, int k, int64_t Cout, float *y) {
+    const int64_t K = (int64_t)k * Cin, Tout = T - k + 1;
+    float *W2 = (float *)malloc(sizeof(float) * (size_t)(Cout * K));
+    for (int64_t o = 0; o < Cout; ++o)
+        for (int64_t c = 0; c < Cin; ++c)
+            for (int j = 0; j < k; ++j) W2[o * K + j * Cin + c] = w[(o * Cin + c) * k + j];
+    for (int64_t b = 0; b < B; ++b) linear_rows(x + b * T * Cin, Tout, K, Cin, W2, NULL, Cout, y + b * Tout * Cout, Cout);
+    free(W2);
+}
+
+/* TemporalBlock.forward (rie.py:85-105) with Optimize1f == False and dense == True: stride-1 convolutions of
+ * 3, then 2*3^i + 1 taps; res = x[:, :, pad+shift : T-pad+shift] (:91-92) with pad = 3^i, shift = pad when causal. */
+static int temporal_block_dense(store *s, const r3o_config *cfg, const char *prefix, const float *x,
+                                int64_t B, int64_t T, int64_t Cin, float *out, r3o_tap_fn tap, void *user) {
+    const int64_t C = cfg->channels;
+    char key[256];
+    int64_t Tcur = T - 2;
+    float *cur = (float *)malloc(sizeof(float) * (size_t)(B * Tcur * C));
+    snprintf(key, sizeof key, "%s.expand_conv.weight", prefix);
+    const float *w = want(s, key, 3, C, Cin, 3);
+    if (!w) { free(cur); return s->err; }
+    conv_dense_k(x, B, T, Cin, w, 3, C, cur);                                /* :86 */
+    snprintf(key, sizeof key, "%s.expand_bn", prefix);
+    if (bn_named(s, key, cur, B * Tcur, C)) { free(cur); return s->err; }
+    leaky(cur, B * Tcur * C, 0.2f);
+    int64_t d = 3;
+    for (int i = 0; i < cfg->num_levels - 1; ++i, d *= 3) {
+        const int k = (int)(2 * d + 1);
+        const int64_t Tn = Tcur - 2 * d, shift = cfg->causal ? d : 0;
+        float *h = (float *)malloc(sizeof(float) * (size_t)(B * Tn * C));
+        float *g = (float *)malloc(sizeof(float) * (size_t)(B * Tn * C));
+        snprintf(key, sizeof key, "%s.layers_conv.%d.weight", prefix, 2 * i);
+        const float *wa = want(s, key, 3, C, C, k);
+        snprintf(key, sizeof key, "%s.layers_conv.%d.weight", prefix, 2 * i + 1);
+        const float *wb = want(s, key, 3, C, C, 1);
+        if (!wa || !wb) { free(h); free(g); free(cur); return s->err; }
+        conv_dense_k(cur, B, Tcur, C, wa, k, C, h);                           /* :96 */
+        snprintf(key, sizeof key, "%s.layers_bn.%d", prefix, 2 * i);
+        if (bn_named(s, key, h, B * Tn, C)) { free(h); free(g); free(cur); return s->err; }
+        leaky(h, B * Tn * C, 0.2f);
+        conv_stride_k(h, B * Tn, C, wb, 1, NULL, C, g);                       /* :97 conv k1 */
+        snprintf(key, sizeof key, "%s.layers_bn.%d", prefix, 2 * i + 1);
+        if (bn_named(s, key, g, B * Tn, C)) { free(h); free(g); free(cur); return s->err; }
+        leaky(g, B * Tn * C, 0.2f);
+        for (int64_t b = 0; b < B; ++b)                                        /* :91-92, :97 */
+            for (int64_t p = 0; p < Tn; ++p)
+                for (int64_t c = 0; c < C; ++c) g[(b * Tn + p) * C + c] += cur[(b * Tcur + p + d + shift) * C + c];
+        free(h);
+        free(cur);
+        cur = g;
+        Tcur = Tn;
+    }
+    if (Tcur != 1) { free(cur); return fail(-1, "dense temporal block: %lld frames left, expected 1", (long long)Tcur); }
+    snprintf(key, sizeof key, "%s.shrink.weight", prefix);
+    const float *ws = want(s, key, 3, cfg->latent, C, 1);
+    snprintf(key, sizeof key, "%s.shrink.bias", prefix);
+    const float *bs = want(s, key, 1, cfg->latent, 0, 0);
+    if (!ws || !bs) { free(cur); return s->err; }
+    conv_stride_k(cur, B, C, ws, 1, bs, cfg->latent, out);                    /* :99 */
     free(cur);
     emit(tap, user, prefix, out, B, cfg->latent, 0, 2);
     return 0;

@@ -41,6 +41,7 @@ typedef struct {
     int extrinsic_dim; /* 0 when CAMERA_EMBDDING is False */
     int embed_dim;     /* 0 when CAMERA_EMBDDING is False */
     int causal;        /* CAUSAL (with the dilated convolutions, the only pairing the reference runs) */
+    int dense;         /* DENSE with DISABLE_OPTIMIZATIONS: (2*pad+1)-tap stride-1 convolutions, rie.py:49-53 */
 } r3o_config;
 
 /* Tap sink: called with intermediate tensors (float32, row-major).  Names:

@@ -39,6 +39,23 @@ def temporal_block(sd: Dict[str, torch.Tensor], p: str, x: torch.Tensor, nlev: i
     return x[:, :, 0]
 
 
+def temporal_block_dense(sd: Dict[str, torch.Tensor], p: str, x: torch.Tensor, nlev: int, causal: bool) -> torch.Tensor:
+    """:85-105 in the un-optimised form with dense=True (:49-53): stride-1 convolutions of 3, then 2*3^i + 1 taps;
+    res = x[:, :, pad+shift : T-pad+shift] (:91-92), pad = 3^i, shift = pad for causal models."""
+    x = F.leaky_relu(_bn(F.conv1d(x, sd[p + ".expand_conv.weight"]), sd, p + ".expand_bn"), 0.2)
+    d = 3
+    for i in range(nlev - 1):
+        shift = d if causal else 0
+        res = x[:, :, d + shift: x.shape[2] - d + shift]
+        x = F.leaky_relu(_bn(F.conv1d(x, sd["%s.layers_conv.%d.weight" % (p, 2 * i)]), sd, "%s.layers_bn.%d" % (p, 2 * i)), 0.2)
+        x = res + F.leaky_relu(_bn(F.conv1d(x, sd["%s.layers_conv.%d.weight" % (p, 2 * i + 1)]),
+                                   sd, "%s.layers_bn.%d" % (p, 2 * i + 1)), 0.2)
+        d *= 3
+    x = F.conv1d(x, sd[p + ".shrink.weight"], sd[p + ".shrink.bias"])
+    assert x.shape[2] == 1
+    return x[:, :, 0]
+
+
 def fc_block(sd, p: str, x: torch.Tensor, nblocks: int) -> torch.Tensor:
     """:159-169 with the residual units of :122-135."""
     x = F.leaky_relu(_bn(F.linear(x, sd[p + ".fc_1.weight"], sd[p + ".fc_1.bias"]), sd, p + ".bn_1"), 0.2)
@@ -78,16 +95,18 @@ def forward(cfg: LiftConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor,
     in_current, xc, diff, diff_t = _encode(x, cfg)
     x_global = fc_block(sd, "GlobalInfo", in_current, 2)
     emb = embedding(sd, "embedder", param) if cfg.camera_embedding else None
+    def tblock(prefix, inp):
+        if cfg.dense_convs:
+            return temporal_block_dense(sd, prefix, inp, L, cfg.causal)
+        return temporal_block(sd, prefix, inp, L, cfg.residual_tap)
     if cfg.kind == "trj":
-        local = temporal_block(sd, "LocalLayer", torch.cat((xc, diff, diff_t), dim=1), L, cfg.residual_tap)       # :540-546
+        local = tblock("LocalLayer", torch.cat((xc, diff, diff_t), dim=1))                                       # :540-546
         feats = [local, x_global] + ([emb] if emb is not None else [])
         return fc_block(sd, "Integration", torch.cat(feats, dim=1), 1).view(B, 1, 1, 3)
     locals_ = []
     for b in BRANCHES:                                                                            # :306-369
         idx = _rows(GROUPS[J][b], Fd)
-        locals_.append(temporal_block(sd, "LocalLayer_" + b,
-                                      torch.cat((xc[:, idx], diff[:, idx], diff_t[:, idx]), dim=1), L,
-                                      cfg.residual_tap))
+        locals_.append(tblock("LocalLayer_" + b, torch.cat((xc[:, idx], diff[:, idx], diff_t[:, idx]), dim=1)))
     dec = {}
     for i, b in enumerate(BRANCHES):
         feats = [locals_[i]]

@@ -48,7 +48,7 @@ static bool same_input_shape(const Model *a, const Model *b) {
 
 static size_t workspace_need(const Plan *pl, int64_t B) {
     // activations only: the input is read in place in both modes (UV mode encodes the rays inside the gather)
-    return ((size_t)pl->floats_per_window * (size_t)B + 64) * sizeof(float);
+    return ((size_t)pl->floats_per_window * (size_t)B + (size_t)pl->tail_floats + 64) * sizeof(float);
 }
 
 struct Recorder {
@@ -172,6 +172,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
                 g.cam_stride = in->cam_stride;
                 g.enc_ws = in->window_stride * JF;
                 g.enc_rows = q.enc_rows;
+                g.enc_step = q.enc_step;
                 g.enc_jf = JF;
                 g.enc_cur = (a->RF / a->cfg.in_features) * JF;   // quirk Q1: "current" frame is RF // in_features
                 g.enc_bytes = (unsigned)((size_t)frames * JF * sizeof(float));

@@ -58,6 +58,7 @@ struct GemmProb {
     int enc_rows;             // GEMM rows per window (RF/3 for a temporal branch, 1 for GlobalInfo)
     int enc_jf;               // J*F
     int enc_cur;              // element offset of the "current" frame inside a window (tcur * J*F)
+    int enc_step;             // frames between consecutive operand rows of a window: 3 (stride-3 expand_conv), 1 (dense ablation)
     unsigned enc_bytes;       // size of the raw input in bytes (buffer-descriptor bound)
     int res_tap;              // fused first level: which frame of a triple is the residual (1 centre, 2 causal)
     int fl_v1;                // fused first level: 1 = the row-major 32-row tiles (first_level_run), 0 = tap by tap
@@ -191,6 +192,7 @@ struct ProbSpec {
     int enc_lut_uv;              // the UV-mode tables of the same problem (-1: in_features != 3)
     bool enc_kernel;             // runs in r3d_gemm_enc_f32 (the model's first level is not fused), not in r3d_gemm_f32
     int enc_rows;
+    int enc_step;                // frames between the operand rows of a window (3; 1 for the dense ablation's stride-1 expand_conv)
     std::vector<int> deps;
     int depth;
     double flops_per_window;     // 2 * rows * K_true * N_true
@@ -232,6 +234,7 @@ struct Plan {
     std::vector<std::vector<int>> stages_spill;
     int spill_prob = -1;
     int64_t floats_per_window = 0;
+    int64_t tail_floats = 0;     // slack behind the last buffer (the dense ablation's overlapping operand rows read past a window's end)
     int emb_buf[2] = {-1, -1};
     int param_buf = -1;          // pseudo-buffer standing for r3d_input::param_dev
     // fused decoder tail: (model, layer, hidden buffer) per Integration block

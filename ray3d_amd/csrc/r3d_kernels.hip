@@ -741,7 +741,7 @@ __device__ __forceinline__ void enc_tile(ProbRef P, const int row0, const int co
         const int row = gr < M ? gr : M - 1;
         const int win = row / P.enc_rows, t3 = row - win * P.enc_rows;
         const unsigned wbase = (unsigned)win * (unsigned)P.enc_ws;
-        b_first[i] = (wbase + (unsigned)(t3 * 3 * P.enc_jf)) * 4;   // first frame of the row (3 frames per row)
+        b_first[i] = (wbase + (unsigned)(t3 * P.enc_step * P.enc_jf)) * 4;   // first frame of the row (rows step by 3 frames; 1 for the dense ablation)
         b_cur[i] = (wbase + (unsigned)P.enc_cur) * 4;               // the window's "current" frame (quirk Q1)
         if constexpr (UV) camr[i] = load_cam_row(P.cam + (long long)win * P.cam_stride);
     }

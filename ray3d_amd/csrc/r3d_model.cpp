@@ -92,9 +92,11 @@ struct Grammar {
     void temporal_block(const std::string &p, int cin) {
         const int C = m->cfg.channels;
         layer(p + ".expand_conv", 3, cin, C, false, p + ".expand_bn", 0.2f, true);
-        for (int i = 1; i < m->cfg.num_levels; ++i) {
+        int dil = 3;
+        for (int i = 1; i < m->cfg.num_levels; ++i, dil *= 3) {
             const std::string a = std::to_string(2 * (i - 1)), b = std::to_string(2 * (i - 1) + 1);
-            layer(p + ".layers_conv." + a, 3, C, C, false, p + ".layers_bn." + a, 0.2f, true);
+            // 3 taps - or, for the dense ablation (rie.py:49-53), 2 * pad + 1 with pad = the level's dilation 3^i
+            layer(p + ".layers_conv." + a, m->cfg.dense ? 2 * dil + 1 : 3, C, C, false, p + ".layers_bn." + a, 0.2f, true);
             layer(p + ".layers_conv." + b, 1, C, C, false, p + ".layers_bn." + b, 0.2f, true);
         }
         layer(p + ".shrink", 1, C, m->cfg.latent, true, "", 1.0f, true);
@@ -146,6 +148,8 @@ Model *model_create(const r3d_config &cfg) {
     }
     if (cfg.kind == R3D_KIND_POS && cfg.stage < 1) { set_error("stage must be >= 1"); return nullptr; }
     if (cfg.causal != 0 && cfg.causal != 1) { set_error("causal must be 0 or 1 (got %d)", cfg.causal); return nullptr; }
+    if (cfg.dense != 0 && cfg.dense != 1) { set_error("dense must be 0 or 1 (got %d)", cfg.dense); return nullptr; }
+    if (cfg.dense && cfg.num_levels > 4) { set_error("dense convolutions are evaluated at every position of a window: num_levels <= 4 (RF <= 81)"); return nullptr; }
 
     Model *m = new Model();
     static std::atomic<uint64_t> next_id{1};

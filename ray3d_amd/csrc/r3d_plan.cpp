@@ -54,6 +54,7 @@ struct Builder {
         q.enc_lut_uv = m.cfg.in_features == 3 ? enc_lut_uv : -1;
         q.enc_kernel = enc_lut >= 0 && !first_level_fused;
         q.enc_rows = rows_pw;
+        q.enc_step = 3;
         const Layer &L0 = m.layers[q.layer];
         int k = enc_lut >= 0 ? L0.Kpad : 0;
         for (int s = 0; s < q.nseg; ++s) {
@@ -99,8 +100,35 @@ struct Builder {
         return problem(prefix + ".fc_2", 1, {{h, 0, H, H, last}}, -1, 0, 0, c_buf, c_col, c_ld);
     }
 
+    // The dense ablation (rie.py:49-53 with Optimize1f == False): stride-1 convolutions of 3, then 2*3^i + 1 taps.  Every
+    // level keeps RF rows per window (position p of a window at row w*RF + p; the valid prefix shrinks by 2*pad per level
+    // and the rows behind it hold garbage no valid row ever reads), so that an operand row - the taps*C contiguous floats
+    // that start at position p - is addressed with a plain leading dimension C: overlapping rows, no im2col.
+    int temporal_block_dense(int bi, int c_buf, int c_col, int c_ld) {
+        const Model::Branch &br = m.branches[bi];
+        const int C = m.cfg.channels, L = m.cfg.num_levels, RF = m.RF;
+        const int pp[2] = {buffer(br.prefix + ".P0", (int64_t)RF * C), L > 1 ? buffer(br.prefix + ".P1", (int64_t)RF * C) : -1};
+        const int hb = L > 1 ? buffer(br.prefix + ".H", (int64_t)RF * C) : -1;
+        int last = problem(br.prefix + ".expand_conv", RF, {}, -1, 0, 0, pp[0], 0, C, {}, (int)br.lut_off, (int)br.lut_uv_off);
+        p.probs[last].enc_step = 1;
+        int dil = 3;
+        for (int i = 1; i < L; ++i, dil *= 3) {
+            const int src = pp[(i - 1) & 1], dst = pp[i & 1], taps = 2 * dil + 1;
+            const std::string a = br.prefix + ".layers_conv." + std::to_string(2 * (i - 1));
+            const std::string b = br.prefix + ".layers_conv." + std::to_string(2 * (i - 1) + 1);
+            // res = x[:, :, pad+shift : T-pad+shift] (rie.py:91-92): position p + pad (+ pad when causal) of the input
+            const int rc = (dil + (m.cfg.causal ? dil : 0)) * C;
+            const int pa = problem(a, RF, {{src, 0, C, taps * C, last}}, -1, 0, 0, hb, 0, C);
+            last = problem(b, RF, {{hb, 0, C, C, pa}}, src, rc, C, dst, 0, C, {last});
+        }
+        p.tail_floats = std::max<int64_t>(p.tail_floats, (int64_t)(RF + 8) * C);
+        const int fin = pp[(L - 1) & 1];
+        return problem(br.prefix + ".shrink", 1, {{fin, 0, RF * C, C, last}}, -1, 0, 0, c_buf, c_col, c_ld);
+    }
+
     // TemporalBlock.forward (rie.py:85-105) for branch `bi`; returns the shrink problem id.
     int temporal_block(int bi, int c_buf, int c_col, int c_ld) {
+        if (m.cfg.dense) return temporal_block_dense(bi, c_buf, c_col, c_ld);
         const Model::Branch &br = m.branches[bi];
         const int C = m.cfg.channels, L = m.cfg.num_levels;
         int rows = m.RF / 3;
@@ -168,7 +196,8 @@ static Plan *build_plan(const Model *a, const Model *b) {
         {
             int k0max = 0;
             for (const auto &br : m->branches) k0max = std::max(k0max, br.k0pad);
-            B.first_level_fused = m->cfg.num_levels >= 2 && m->cfg.channels <= N_ALIGN && k0max <= 256 && !env_on("R3D_NO_FIRST_FUSE");
+            B.first_level_fused = m->cfg.num_levels >= 2 && m->cfg.channels <= N_ALIGN && k0max <= 256 && !m->cfg.dense &&
+                                  !env_on("R3D_NO_FIRST_FUSE");
         }
         const int lat = m->cfg.latent, D = m->cfg.embed_dim;
         int pe = -1;

@@ -79,10 +79,6 @@ class LiftConfig:
             # every shipped cfg uses width-3 filters; the ternary-tree kernels rely on it
             raise NotImplementedError("only ARCHITECTURE made of 3s is supported, got %r"
                                       % (self.filter_widths,))
-        if self.dense:
-            # dense=True swaps the dilated 3-tap convolutions for (2*pad+1)-tap ones (rie.py:49-53):
-            # a different network (ablation only, no shipped cfg), not a variant of this path
-            raise NotImplementedError("DENSE=True (dense-convolution ablation, rie.py:49-53) is out of scope")
         if self.causal and self.optimize1f:
             # the reference itself cannot run this pair: rie.py:94 slices the residual with the
             # dilated causal_shift of :47 and the add at :97 fails on mismatched lengths
@@ -96,6 +92,18 @@ class LiftConfig:
         the last one.  DISABLE_OPTIMIZATIONS alone changes nothing for an RF-long window: the dilated
         stack evaluates the same ternary tree as the strided one."""
         return 2 if self.causal else 1
+
+    @property
+    def dense_convs(self) -> bool:
+        """DENSE=True swaps every level's dilated 3-tap convolution for a dense one of 2*pad+1 taps (rie.py:49-53) -
+        but only in the un-optimised constructor branch: with the strided (Optimize1f) convolutions the flag is read
+        and ignored (:54-55), exactly as here."""
+        return self.dense and not self.optimize1f
+
+    def level_taps(self, level: int) -> int:
+        """Kernel size of layers_conv[2*(level-1)] (level >= 1): 3, or 2 * 3**level + 1 for the dense ablation
+        (pad of that level = dilation = 3**level, rie.py:44-53)."""
+        return 2 * 3 ** level + 1 if self.dense_convs else self.filter_widths[level]
 
     @property
     def camera_embedding(self) -> bool:
@@ -165,8 +173,8 @@ def temporal_block_entries(prefix: str, cin: int, cfg: LiftConfig) -> List[Entry
     out += _bn(prefix + ".expand_bn", c)
     for i in range(1, len(w)):
         a, b = 2 * (i - 1), 2 * (i - 1) + 1
-        out.append(Entry("%s.layers_conv.%d.weight" % (prefix, a), (c, c, w[i]), "conv_w",
-                         fan_in=c * w[i]))
+        out.append(Entry("%s.layers_conv.%d.weight" % (prefix, a), (c, c, cfg.level_taps(i)), "conv_w",
+                         fan_in=c * cfg.level_taps(i)))
         out += _bn("%s.layers_bn.%d" % (prefix, a), c)
         out.append(Entry("%s.layers_conv.%d.weight" % (prefix, b), (c, c, 1), "conv_w", fan_in=c))
         out += _bn("%s.layers_bn.%d" % (prefix, b), c)

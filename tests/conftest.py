@@ -35,7 +35,8 @@ def load_model_fixture(name):
 
 
 MODEL_CASES = ["j17_rf27_s3", "j17_rf243_s3", "j17_rf9_s1", "j14_rf9_s3", "j15_rf9_s3",
-               "j17_f2_rf27_noemb_s3", "j17_rf81_s2_big", "j17_rf27_dilated_s3", "j17_rf81_causal_s3"]
+               "j17_f2_rf27_noemb_s3", "j17_rf81_s2_big", "j17_rf27_dilated_s3", "j17_rf81_causal_s3",
+               "j17_rf27_dense_s3", "j14_rf9_dense_causal_s2"]
 
 
 def case_out_scale(name):

@@ -62,6 +62,9 @@ CASES = {
     # the dilated (non-Optimize1f) convolutions on RF-long windows, plain and causal (rie.py:91-92)
     "j17_rf27_dilated_s3": (dict(ARCHITECTURE="3,3,3", DISABLE_OPTIMIZATIONS=True), 3, 1.0),
     "j17_rf81_causal_s3": (dict(ARCHITECTURE="3,3,3,3", DISABLE_OPTIMIZATIONS=True, CAUSAL=True), 3, 1.0),
+    # the dense-convolution ablation (rie.py:49-53: 2*pad+1 taps, stride 1), plain and causal
+    "j17_rf27_dense_s3": (dict(ARCHITECTURE="3,3,3", DISABLE_OPTIMIZATIONS=True, DENSE=True), 3, 1.0),
+    "j14_rf9_dense_causal_s2": (dict(ARCHITECTURE="3,3", NUM_KPTS=14, DISABLE_OPTIMIZATIONS=True, DENSE=True, CAUSAL=True, STAGE=2), 4, 1.0),
 }
 
 

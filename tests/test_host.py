@@ -67,13 +67,24 @@ def test_create_rejects_unsupported_configs():
         with pytest.raises((ValueError, _capi.Ray3DHipError)):
             _capi.Handle(config_from_dicts(default_model_config(**over), "pos"))
     # CAUSAL with the strided convolutions is the pairing the reference's own forward raises on (rie.py:94-97)
-    for over in (dict(CAUSAL=True), dict(DENSE=True), dict(DENSE=True, DISABLE_OPTIMIZATIONS=True),
-                 dict(ARCHITECTURE="3,5")):
+    for over in (dict(CAUSAL=True), dict(ARCHITECTURE="3,5")):
         with pytest.raises(NotImplementedError):
             config_from_dicts(default_model_config(**over), "pos")
+    # DENSE is read and ignored by the strided constructor branch (rie.py:54-55); with DISABLE_OPTIMIZATIONS it is the
+    # dense-convolution ablation: 2 * 3^i + 1 taps per level (:49-53)
+    plain = config_from_dicts(default_model_config(DENSE=True), "pos")
+    assert not plain.dense_convs and plain.level_taps(1) == 3
+    dense = config_from_dicts(default_model_config(ARCHITECTURE="3,3,3", DENSE=True, DISABLE_OPTIMIZATIONS=True), "trj")
+    assert dense.dense_convs and (dense.level_taps(1), dense.level_taps(2)) == (7, 19)
+    h = _capi.Handle(dense)
+    shapes = {k: h.shape(i) for i, k in enumerate(h.keys())}
+    assert shapes["LocalLayer.layers_conv.0.weight"] == (256, 256, 7) and shapes["LocalLayer.layers_conv.2.weight"] == (256, 256, 19)
+    h.close()
+    with pytest.raises(_capi.Ray3DHipError, match="num_levels"):       # evaluated at every position: short receptive fields only
+        _capi.Handle(config_from_dicts(default_model_config(ARCHITECTURE="3,3,3,3,3", DENSE=True, DISABLE_OPTIMIZATIONS=True), "pos"))
     assert config_from_dicts(default_model_config(DISABLE_OPTIMIZATIONS=True), "pos").residual_tap == 1
     assert config_from_dicts(default_model_config(DISABLE_OPTIMIZATIONS=True, CAUSAL=True), "trj").residual_tap == 2
-    bad = _capi.Config(0, 17, 3, 2, 256, 256, 3, 2, 64, 7)
+    bad = _capi.Config(0, 17, 3, 2, 256, 256, 3, 2, 64, 7, 0)
     with pytest.raises(_capi.Ray3DHipError, match="causal"):
         _capi.check(_capi.load().r3d_create(_capi.C.byref(bad), _capi.C.byref(_capi.C.c_void_p())), "r3d_create")
 
@@ -484,6 +495,7 @@ def test_plan_tile_lists_cover_every_problem_once(monkeypatch):
         _plan_check(default_model_config(ARCHITECTURE=arch), [1, 64, 256, 1000, 4096])
     _plan_check(mc, [256, 1000], nwg=64)
     _plan_check(default_model_config(ARCHITECTURE="3,3,3,3", CHANNELS=512), [3, 256])
+    _plan_check(default_model_config(ARCHITECTURE="3,3,3", DENSE=True, DISABLE_OPTIMIZATIONS=True), [1, 50, 256])
     monkeypatch.setenv("R3D_NO_SPILL", "1")
     assert all(s == 0 for _, s in _plan_check(mc, [100, 256, 1024]))
 
