@@ -200,6 +200,12 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             }
             if (q.layer3 >= 0) {
                 const Layer &L3 = m->layers[q.layer3];
+                const Layer &L2b = m->layers[q.layer2];
+                if (L.bf3_conv && L2b.bf3_conv && L3.bf3_conv && !first_level_v1()) {   // first_level_taps_b3
+                    g.wb3 = m->d_arena + L.wb3_off;
+                    g.w2b3 = m->d_arena + L2b.wb3_off;
+                    g.w3b3 = m->d_arena + L3.wb3_off;
+                }
                 g.w3 = m->d_arena + L3.w_off;
                 g.bias3 = m->d_arena + L3.b_off;
                 g.K3 = L3.Kpad;

@@ -42,6 +42,7 @@ struct GemmProb {
     float slope2;
     // --- fp32 on the bf16 matrix cores (wb3 != nullptr): the same fp32 weights in bf16-MFMA operand order ---
     const float *wb3;
+    const float *w2b3, *w3b3;  // fused first level on the bf16 matrix cores: the b3 copies of w2 / w3 (all three set or none)
     // --- first level of the pyramid in one tile (w3 != nullptr; lut != nullptr): w/bias = expand_conv on the gathered
     // input (three rows per output row), w2/bias2 = the level's 3-tap convolution, w3/bias3 = its 1x1 convolution;
     // the residual is the centre one of the three expand_conv rows.  M counts OUTPUT rows. ---
@@ -126,6 +127,7 @@ struct Layer {
     bool frag;                // packed in MFMA fragment order (GEMM layers) or row-major [N][Kpad] (decoder tail)
     size_t w_off, b_off;      // offsets (floats) into the packed arena
     bool bf3 = false;         // also packed in bf16-MFMA operand order for gemm_tile_b3 (the FCBlocks' 1024-wide Linears)
+    bool bf3_conv = false;    // ... and the three layers of a fused first level (first_level_taps_b3)
     size_t wb3_off = 0;       // offset (floats) of that copy in the arena: Npad * Kpad floats
 };
 

@@ -79,7 +79,7 @@ constexpr int GEMM_STAGES = 3;
 constexpr int STAGE_FLOATS = GEMM_MAX_MI * 32 * LDS_LD;                  // one A tile: 27,648 B
 constexpr int LUT_LDS_INTS = 1152;                                       // fused-prologue tables: K + K/4 ints (K <= 480 with room to spare)
 constexpr int RING_LDS_BYTES = GEMM_STAGES * STAGE_FLOATS * 4;                      // 82,944 B
-constexpr int GEMM_LDS_BYTES = (96 * (GEMM_BN + 4) + 32 * (GEMM_BN + 4) + 320) * 4;   // 134,400 B: the fused first level's tiles (fused pairs: 133,120)
+constexpr int GEMM_LDS_BYTES = 157952;   // the bf16x3 first level: three H planes + two gather buffers of three planes + tables (fp32 first level 134,400; fused pairs 133,120)
 static_assert(GEMM_LDS_BYTES >= RING_LDS_BYTES, "the ring and the intermediate tile share the allocation");
 
 typedef const LaunchArgs __attribute__((address_space(4))) *LaunchArgsPtr;
@@ -1472,6 +1472,351 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
     (void)M0;
 }
 
+
+// ------------------------------------------------------------------------------------ first level on the bf16 matrix cores
+//
+// first_level_taps_b3: first_level_taps with every product evaluated by v_mfma_f32_32x32x16_bf16 on exact three-term
+// bf16 splits of both operands (gemm_tile_b3 above has the arithmetic: six products per fp32 product, fp32 accumulate,
+// the error of an fp32 dot product) - 6/16 of the fp32 MFMA's matrix time.  What changes around the matrix work:
+//  * operands swap roles - the weights are the MFMA's A operand, the activations its B operand - so an accumulator
+//    holds D[channel][row]: a lane owns ONE row and four consecutive channels per register quad, which is what lets
+//    the activations go to LDS as packed bf16 (one ds_write_b64 per plane and quad) and the output rows as float4;
+//  * the activations (G: the gathered chunk; H: a tap's / the level's activations) live in LDS as three bf16 planes,
+//    split when they are written - each value once per tile - and are read as ready MFMA operands (b128 per plane);
+//  * the weights stream as fp32 in bf16-MFMA operand order (GemmProb::wb3 / w2b3 / w3b3: the same bytes per K tile
+//    as the fp32 path) and are split in registers by the wavefront that owns the 32 channels, behind the matrix work.
+// Opt-in with the rest of the bf16x3 mode (R3D_BF16X3=1 at r3d_create).
+constexpr int FLB_H_PITCH = 264;                                         // bf16 per H row: 528 B (conflict-free b128 operand reads)
+constexpr int FLB_G_PITCH = 72;                                          // bf16 per G row: 144 B
+constexpr int FLB_H_PLANE = FLT_MAX_MI * 32 * FLB_H_PITCH * 2;           // bytes per H plane: 33,792
+constexpr int FLB_G_PLANE = FLT_MAX_MI * 32 * FLB_G_PITCH * 2;           // bytes per G plane:  9,216
+constexpr int FLB_G_OFF = 3 * FLB_H_PLANE;                               // two G buffers of three planes each
+constexpr int FLB_LUT_OFF = FLB_G_OFF + 6 * FLB_G_PLANE;                 // 156,672
+static_assert(FLB_LUT_OFF + FL_LUT_INTS * 4 <= GEMM_LDS_BYTES, "the bf16x3 first level fits the GEMM kernel's LDS allocation");
+static_assert(FLT_MAX_MI * 32 * PAIR_LD * 4 <= FLB_G_OFF, "the fp32 output rows are staged over the H planes");
+
+template <int MI, bool MULTI, bool UV>
+__device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_list, const int ntiles, const bool new_prob, float *smem,
+                                                    long long *dbg_base) {
+    static_assert(MI >= 1 && MI <= FLT_MAX_MI, "tile height");
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int w_voff = lane * 16;
+    const int srow = tid >> 3, a_kq = (tid & 7) * 4;
+    const int K0 = P.K, nk0 = K0 / BK, nch = (nk0 + 1) >> 1;
+    const int M = P.M;
+    const int res_tap = P.res_tap;
+    char *lds = reinterpret_cast<char *>(smem);
+    char *Hb = lds, *Gb = lds + FLB_G_OFF;
+    int *lut_lds = reinterpret_cast<int *>(lds + FLB_LUT_OFF);
+    const int *lut1 = lut_lds, *lutk = lut_lds + K0;
+    if (new_prob) {
+        for (int i = tid; i < K0 + K0 / 4; i += GEMM_THREADS) lut_lds[i] = *(const R3D_AS1 int *)(P.lut + i);
+    }
+    __syncthreads();
+    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x), 0, P.enc_bytes, 0x00020000);
+    struct WFrag { f32x4 f[2][2]; };                         // one K tile of this wavefront's 32 channels: [k16 half][4-float group]
+    auto load_w = [&](__amdgpu_buffer_rsrc_t rs, int kt, WFrag &dst) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                dst.f[h][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, w_voff + (h * 2 + j) * 1024, kt * 4096, 0));
+    };
+    const int nk1 = P.K2 / BK, tiles_per_tap = nk1 / 3, nk2 = P.K3 / BK;
+    __amdgpu_buffer_rsrc_t w0rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.wb3 + ((size_t)wave_u * nk0) * 1024), 0, nk0 * 4096, 0x00020000);
+    __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.w2b3 + ((size_t)wave_u * nk1) * 1024), 0, nk1 * 4096, 0x00020000);
+    __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.w3b3 + ((size_t)wave_u * nk2) * 1024), 0, nk2 * 4096, 0x00020000);
+    const float slope0 = P.slope, slope1 = P.slope2, slope2 = P.slope3;
+    const int ch0 = wave * 32 + 4 * lh;                      // this lane's channels: ch0 + 8 q + e
+
+    // ---- gather (as first_level_taps), committed as three bf16 planes
+    struct Raw { f32x4 a[2]; };
+    Raw gq;
+    unsigned b_first, b_cur;
+    const bool on = srow < MI * 32;
+    CamRow camr;
+    auto issue_phase = [&](int row0, int tap, int ch) {
+        const int orow = row0 + srow;
+        const int e = 3 * (orow < M ? orow : M - 1) + tap;
+        const int win = e / P.enc_rows, t3 = e - win * P.enc_rows;
+        const unsigned wbase = (unsigned)win * (unsigned)P.enc_ws;
+        b_first = (wbase + (unsigned)(t3 * 3 * P.enc_jf)) * 4;
+        b_cur = (wbase + (unsigned)P.enc_cur) * 4;
+        if constexpr (UV) camr = load_cam_row(P.cam + (long long)win * P.cam_stride);
+        if (!on) return;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = (ch * 2 + h) * BK + a_kq;
+            if (MULTI && k >= K0) break;
+            const int4 o1 = *reinterpret_cast<const int4 *>(lut1 + k);
+            const unsigned b = lutk[k >> 2] != 0 ? b_cur : b_first;
+            const int c1[4] = {o1.x & ~3, o1.y & ~3, o1.z & ~3, o1.w & ~3};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                gq.a[h][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, b + (unsigned)c1[c], 0, 0));
+        }
+    };
+    // four fp32 values -> their three bf16 terms, packed (exact: every remainder is representable in fp32)
+    auto split4 = [&](const f32x4 &x, u32x2 (&pl)[3]) {
+        const unsigned h0 = b3_pack(x[0], x[1]), h1 = b3_pack(x[2], x[3]);
+        const float r0 = x[0] - b3_lo(h0), r1 = x[1] - b3_hi(h0), r2 = x[2] - b3_lo(h1), r3 = x[3] - b3_hi(h1);
+        const unsigned m0 = b3_pack(r0, r1), m1 = b3_pack(r2, r3);
+        pl[0] = u32x2{h0, h1};
+        pl[1] = u32x2{m0, m1};
+        pl[2] = u32x2{b3_pack(r0 - b3_lo(m0), r1 - b3_hi(m0)), b3_pack(r2 - b3_lo(m1), r3 - b3_hi(m1))};
+    };
+    auto commit_phase = [&](int ch, char *G) {
+        if (!on) return;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = (ch * 2 + h) * BK + a_kq;
+            if (MULTI && k >= K0) break;
+            f32x4 v = gq.a[h];
+            if constexpr (UV) {
+                const int4 code = *reinterpret_cast<const int4 *>(lut1 + k);
+                v[0] = uv_to_ray(v[0], code.x, camr);
+                v[1] = uv_to_ray(v[1], code.y, camr);
+                v[2] = uv_to_ray(v[2], code.z, camr);
+                v[3] = uv_to_ray(v[3], code.w, camr);
+            }
+            u32x2 pl[3];
+            split4(v, pl);
+            char *d = G + (srow * FLB_G_PITCH + h * BK + a_kq) * 2;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2 *>(d + p * FLB_G_PLANE) = pl[p];
+        }
+    };
+    // one 32-deep K tile of matrix work: weights `w` (fp32, split here) x activations in planes at `xb` (row pitch `pitch` bf16)
+    auto mma_ktile = [&](const char *xb, const int pitch, const int plane_bytes, const WFrag &w, f32x16 (&acc)[MI]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 wp[3], av[MI][3];
+            b3_split8(w.f[h][0], w.f[h][1], wp);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    av[mi][p] = *reinterpret_cast<const bf16x8 *>(xb + p * plane_bytes + ((mi * 32 + li) * pitch + h * 16 + lh * 8) * 2);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {                // smallest terms first; D[channel][row]
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[0], av[mi][2], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[1], av[mi][1], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[2], av[mi][0], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[0], av[mi][1], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[1], av[mi][0], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[0], av[mi][0], acc[mi], 0, 0, 0);
+            }
+        }
+    };
+    // activations = lrelu(acc + bias) (kept in acc), written to the H planes
+    auto activate_to_planes = [&](f32x16 (&acc)[MI], const float *bias, const float slope) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bq = gload4(bias + ch0 + 8 * q);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[mi][4 * q + e] + bq[e];
+                    t = t > 0.0f ? t : t * slope;
+                    acc[mi][4 * q + e] = t;
+                    v[e] = t;
+                }
+                u32x2 pl[3];
+                split4(v, pl);
+                char *d = Hb + ((mi * 32 + li) * FLB_H_PITCH + ch0 + 8 * q) * 2;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2 *>(d + p * FLB_H_PLANE) = pl[p];
+            }
+        }
+    };
+
+    WFrag wa, wb, wc;                                        // streaming weight fragments (three sets rotating)
+    // expand_conv fragments.  One chunk: resident in (w0a, w0b).  Several chunks: the streaming sets are idle during
+    // the expand phases, so the chunks alternate between (wa, wb) and (wc, w0a) and chunk 0 returns to (wa, wb) once
+    // a tap's 3-tap loop is done with them.
+    WFrag w0a, w0b;
+    if constexpr (MULTI) {
+        load_w(w0rsrc, 0, wa);
+        load_w(w0rsrc, nk0 > 1 ? 1 : 0, wb);
+    } else {
+        load_w(w0rsrc, 0, w0a);
+        load_w(w0rsrc, nk0 > 1 ? 1 : 0, w0b);
+    }
+    int phase = 0;
+    auto tap_of = [&](int ts) { return ts == 0 ? 0 : ts == 2 ? res_tap : 3 - res_tap; };
+    issue_phase(__builtin_amdgcn_readfirstlane(tile_list[0].y), 0, 0);
+#pragma unroll 1
+    for (int ti = 0; ti < ntiles; ++ti) {
+        const int row0 = __builtin_amdgcn_readfirstlane(tile_list[ti].y);
+        const int next_row0 = ti + 1 < ntiles ? __builtin_amdgcn_readfirstlane(tile_list[ti + 1].y) : -1;
+#ifdef R3D_TIMING
+        long long *dbg = dbg_base && ti < 8 ? dbg_base + ti * 8 : nullptr;
+#else
+        long long *dbg = nullptr;
+        (void)dbg;
+#endif
+        R3D_TSTAMP(0);
+        f32x16 acc0[MI], acc1[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[mi][r] = 0.0f;
+#pragma unroll 1
+        for (int ts = 0; ts < 3; ++ts) {
+            const int tap = tap_of(ts);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc0[mi][r] = 0.0f;
+            auto chunk = [&](int ch, const WFrag &ua, const WFrag &ub, WFrag &la, WFrag &lb) {
+                char *G = Gb + (phase & 1) * 3 * FLB_G_PLANE;
+                commit_phase(ch, G);
+                __syncthreads();
+                if constexpr (MULTI) {
+                    if (ch + 1 < nch) {
+                        load_w(w0rsrc, (ch + 1) * 2, la);
+                        load_w(w0rsrc, (ch + 1) * 2 + 1 < nk0 ? (ch + 1) * 2 + 1 : (ch + 1) * 2, lb);
+                    }
+                }
+                if (ch + 1 < nch) issue_phase(row0, tap, ch + 1);
+                else if (ts < 2) issue_phase(row0, tap_of(ts + 1), 0);
+                else if (next_row0 >= 0) issue_phase(next_row0, 0, 0);
+                mma_ktile(G, FLB_G_PITCH, FLB_G_PLANE, ua, acc0);
+                if (ch * 2 + 1 < nk0) mma_ktile(G + BK * 2, FLB_G_PITCH, FLB_G_PLANE, ub, acc0);
+                ++phase;
+            };
+            if constexpr (MULTI) {
+#pragma unroll 1
+                for (int ch = 0; ch < nch; ch += 2) {
+                    chunk(ch, wa, wb, wc, w0a);
+                    if (ch + 1 < nch) chunk(ch + 1, wc, w0a, wa, wb);
+                }
+            } else {
+                chunk(0, w0a, w0b, wc, wc);
+            }
+            if (ts == 0) R3D_TSTAMP(5);
+            // ---- activations -> H planes (the residual tap's stay in acc0, fp32, for the epilogue)
+            load_w(w1rsrc, tap * tiles_per_tap, wa);
+            load_w(w1rsrc, tap * tiles_per_tap + (tiles_per_tap > 1 ? 1 : 0), wb);
+            activate_to_planes(acc0, P.bias, slope0);
+            __syncthreads();
+            if (ts == 0) R3D_TSTAMP(6);
+            // ---- this tap's third of the 3-tap convolution
+            {
+                const int kbase = tap * tiles_per_tap, lastk = tiles_per_tap - 1;
+                auto k_tile1 = [&](int kin, const WFrag &w_use, WFrag &w_load) {
+                    load_w(w1rsrc, kbase + (kin + 2 < lastk ? kin + 2 : lastk), w_load);
+                    mma_ktile(Hb + kin * BK * 2, FLB_H_PITCH, FLB_H_PLANE, w_use, acc1);
+                };
+                int kin = 0;
+                for (; kin + 2 < tiles_per_tap; kin += 3) {
+                    k_tile1(kin, wa, wc);
+                    k_tile1(kin + 1, wb, wa);
+                    k_tile1(kin + 2, wc, wb);
+                }
+                if (kin < tiles_per_tap) {
+                    k_tile1(kin, wa, wc);
+                    if (kin + 1 < tiles_per_tap) k_tile1(kin + 1, wb, wa);
+                }
+            }
+            if (ts == 0) R3D_TSTAMP(7);
+            if constexpr (MULTI) {
+                if (ts < 2) {
+                    load_w(w0rsrc, 0, wa);
+                    load_w(w0rsrc, nk0 > 1 ? 1 : 0, wb);
+                }
+            }
+        }
+        R3D_TSTAMP(1);
+        // ---- level activations -> H planes; the 1x1 convolution on them
+        load_w(w2rsrc, 0, wa);
+        load_w(w2rsrc, nk2 > 1 ? 1 : 0, wb);
+        __syncthreads();                                     // every wavefront is done reading the last tap's H
+        activate_to_planes(acc1, P.bias2, slope1);
+        __syncthreads();
+        R3D_TSTAMP(2);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[mi][r] = 0.0f;
+        {
+            const int last2 = nk2 - 1;
+            auto k_tile2 = [&](int kt, const WFrag &w_use, WFrag &w_load) {
+                load_w(w2rsrc, kt + 2 < last2 ? kt + 2 : last2, w_load);
+                mma_ktile(Hb + kt * BK * 2, FLB_H_PITCH, FLB_H_PLANE, w_use, acc1);
+            };
+            int kt = 0;
+            for (; kt + 2 < nk2; kt += 3) {
+                k_tile2(kt, wa, wc);
+                k_tile2(kt + 1, wb, wa);
+                k_tile2(kt + 2, wc, wb);
+            }
+            if (kt < nk2) {
+                k_tile2(kt, wa, wc);
+                if (kt + 1 < nk2) k_tile2(kt + 1, wb, wa);
+            }
+        }
+        R3D_TSTAMP(3);
+        if constexpr (MULTI) {
+            if (next_row0 >= 0) {
+                load_w(w0rsrc, 0, wa);
+                load_w(w0rsrc, nk0 > 1 ? 1 : 0, wb);
+            }
+        }
+        // ---- epilogue: lrelu(acc + bias) + the residual tap's activations, fp32 rows staged over the H planes
+        __syncthreads();                                     // every wavefront is done reading H
+        {
+            float *S = smem;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bq = gload4(P.bias3 + ch0 + 8 * q);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc1[mi][4 * q + e] + bq[e];
+                        t = t > 0.0f ? t : t * slope2;
+                        v[e] = t + acc0[mi][4 * q + e];
+                    }
+                    *reinterpret_cast<f32x4 *>(S + (mi * 32 + li) * PAIR_LD + ch0 + 8 * q) = v;
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const float *S = smem;
+            const int rd_row = tid >> 6, rd_c4 = (tid & 63) * 4;
+            const int N = P.N;
+#pragma unroll
+            for (int j = 0; j < 4 * MI; ++j) {
+                const int lr = rd_row + 8 * j, row = row0 + lr;
+                if (row >= M) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(S + lr * PAIR_LD + rd_c4);
+                if (rd_c4 + 4 <= N) {
+                    __builtin_nontemporal_store(v, (R3D_AS1 f32x4 *)(P.c + (size_t)row * P.ldc + rd_c4));
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (rd_c4 + c < N) gstore1(P.c + (size_t)row * P.ldc + rd_c4 + c, v[c]);
+                }
+            }
+        }
+        __syncthreads();
+        R3D_TSTAMP(4);
+    }
+}
+
 template <bool ENC, bool UV>
 __device__ __forceinline__ void gemm_persistent(float *smem) {
     LaunchArgsPtr args = (LaunchArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1525,6 +1870,14 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                 if (P.fl_v1) {           // the row-major form (one 32-row tile at a time), kept for A/B runs: R3D_FL_V1=1
                     if (P.K <= 64) first_level_run<3, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
                     else first_level_run<1, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                } else if (P.wb3 != nullptr) {   // fp32 on the bf16 matrix cores
+                    if (P.K <= 64) {
+                        if (mi >= 2) first_level_taps_b3<2, false, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                        else first_level_taps_b3<1, false, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                    } else {
+                        if (mi >= 2) first_level_taps_b3<2, true, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                        else first_level_taps_b3<1, true, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                    }
                 } else if (P.K <= 64) {
                     if (mi >= 2) first_level_taps<2, false, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
                     else first_level_taps<1, false, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);

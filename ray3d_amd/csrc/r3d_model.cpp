@@ -84,6 +84,7 @@ struct Grammar {
         if (!bn_prefix.empty()) bn(bn_prefix, n);
         // the FCBlocks' wide Linears can also run on the bf16 matrix cores (three-term split, r3d_kernels.hip)
         L.bf3 = m->use_b3 && !conv && n == MLP_HIDDEN && cin % BK == 0 && cin >= 256;
+        L.bf3_conv = false;
         m->layer_index[prefix] = (int)m->layers.size();
         m->layers.push_back(L);
         return (int)m->layers.size() - 1;
@@ -91,13 +92,18 @@ struct Grammar {
     // TemporalBlock, lib/model/rie.py:13-63
     void temporal_block(const std::string &p, int cin) {
         const int C = m->cfg.channels;
-        layer(p + ".expand_conv", 3, cin, C, false, p + ".expand_bn", 0.2f, true);
+        const int le = layer(p + ".expand_conv", 3, cin, C, false, p + ".expand_bn", 0.2f, true);
+        // fp32 on the bf16 matrix cores for the fused first level (first_level_taps_b3): its three layers also get a
+        // copy in bf16-MFMA operand order
+        const bool fl_b3 = m->use_b3 && m->cfg.num_levels >= 2 && C <= N_ALIGN && !m->cfg.dense;
+        m->layers[le].bf3_conv = fl_b3;
         int dil = 3;
         for (int i = 1; i < m->cfg.num_levels; ++i, dil *= 3) {
             const std::string a = std::to_string(2 * (i - 1)), b = std::to_string(2 * (i - 1) + 1);
             // 3 taps - or, for the dense ablation (rie.py:49-53), 2 * pad + 1 with pad = the level's dilation 3^i
-            layer(p + ".layers_conv." + a, m->cfg.dense ? 2 * dil + 1 : 3, C, C, false, p + ".layers_bn." + a, 0.2f, true);
-            layer(p + ".layers_conv." + b, 1, C, C, false, p + ".layers_bn." + b, 0.2f, true);
+            const int la = layer(p + ".layers_conv." + a, m->cfg.dense ? 2 * dil + 1 : 3, C, C, false, p + ".layers_bn." + a, 0.2f, true);
+            const int lb = layer(p + ".layers_conv." + b, 1, C, C, false, p + ".layers_bn." + b, 0.2f, true);
+            if (i == 1) m->layers[la].bf3_conv = m->layers[lb].bf3_conv = fl_b3;
         }
         layer(p + ".shrink", 1, C, m->cfg.latent, true, "", 1.0f, true);
     }
@@ -341,7 +347,7 @@ int model_finalize(Model *m) {
         off += (size_t)L.Npad * L.Kpad;
         L.b_off = off;
         off += (size_t)L.Npad;
-        if (L.bf3) {
+        if (L.bf3 || L.bf3_conv) {
             off = (off + 3) / 4 * 4;                       // 16-byte aligned planes
             L.wb3_off = off;
             off += (size_t)L.Npad * L.Kpad;
@@ -382,14 +388,15 @@ int model_finalize(Model *m) {
         }
         float *bd = m->arena.data() + L.b_off;
         for (int o = 0; o < L.N; ++o) bd[o] = (float)t[o];
-        if (L.bf3) {
-            // the same folded weights in v_mfma_f32_32x32x16_bf16 B-operand order (the kernel splits them into three
-            // bf16 terms in registers): [32-col block][K tile][k16 half][4-float group][lane][4], lane l holding
-            // column l % 32 and k = 8 * (l / 32) + 4 * group + e of the half
+        if (L.bf3 || L.bf3_conv) {
+            // the same folded weights in v_mfma_f32_32x32x16_bf16 operand order (the kernel splits them into three bf16
+            // terms in registers): [32-col block][K tile][k16 half][4-float group][lane][4], lane l holding
+            // column l % 32 and k = 8 * (l / 32) + 4 * group + e of the half.  Read back from the fragment-ordered
+            // copy, which already holds the folded (and, for first layers, column-mapped) values.
             float *pk = m->arena.data() + L.wb3_off;
             for (int o = 0; o < L.N; ++o)
-                for (int k = 0; k < L.K; ++k) {
-                    const float v = (float)((double)w[(size_t)o * L.cin + k] * s[o]);
+                for (int k = 0; k < L.Kpad; ++k) {
+                    const float v = dst[frag_index(o, k, nk)];
                     const int nb = o >> 5, kt = k >> 5, kin = k & 31, h = kin >> 4, kk = kin & 15;
                     const int lane = (kk >> 3) * 32 + (o & 31), j = (kk & 7) >> 2, e = kk & 3;
                     pk[((((size_t)(nb * nk + kt) * 2 + h) * 2 + j) * 64 + lane) * 4 + e] = v;

@@ -659,3 +659,38 @@ def test_archives_to_metrics_end_to_end(tmp_path):
         # millimetres; the lifted poses differ from the oracle's by <= 1e-4 m, i.e. 0.1 mm per joint at worst
         assert np.abs(np.array(named[key]) - want[key]).max() < 0.1, (key, named[key], want[key])
     assert evaluate.format_report(named, avg)[-5].startswith("Protocol #1   (MPJPE) action-wise average:")
+
+
+# ---------------------------------------------------------------- bench.py's evaluation mode / multi-GPU
+
+def _bench_eval(gpus, clips=10):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "eval", "--gpus", str(gpus),
+                          "--clips", str(clips), "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_eval_mode_single_gpu():
+    """bench.py --mode eval (BASELINE configs[2] stand-in) runs end to end on one GPU and reports a finite MPJPE."""
+    line = _bench_eval(1)
+    assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["value"] > 0
+    assert np.isfinite(line["mpjpe_mm"]["action_average"]) and line["config"]["clips"] == 10
+
+
+def test_clip_sharded_eval_over_rccl_two_gpus():
+    """Two ranks over RCCL (started by bench.py itself through torch.distributed.run): whole clips sharded longest
+    first, ONE all_gather of the per-clip rows; the gathered errors must equal the single-rank run's.  Skipped on a
+    box with one GPU (the CPU suite covers the same logic with gloo, tests/test_host.py)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    one, two = _bench_eval(1), _bench_eval(2)
+    assert two["n_gpus"] == 2
+    assert two["mpjpe_mm"] == one["mpjpe_mm"]            # same clips, same kernels, fixed summation order: identical
