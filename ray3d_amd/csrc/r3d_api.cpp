@@ -193,6 +193,10 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             g.slope = L.slope;
             if (q.layer2 >= 0) {
                 const Layer &L2 = m->layers[q.layer2];
+                if (q.layer3 < 0 && L.bf3_conv && L2.bf3_conv && q.nseg == 1) {   // gemm_tile_b3t
+                    g.wb3 = m->d_arena + L.wb3_off;
+                    g.w2b3 = m->d_arena + L2.wb3_off;
+                }
                 g.w2 = m->d_arena + L2.w_off;
                 g.bias2 = m->d_arena + L2.b_off;
                 g.K2 = L2.Kpad;

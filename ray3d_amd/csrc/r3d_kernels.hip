@@ -671,6 +671,260 @@ __device__ __forceinline__ void gemm_tile_b3(ProbRef P, const int row0, const in
 }
 
 
+// ---- pieces shared by the tiles that keep D[channel][row] accumulators (weights as the MFMA's A operand, activations
+// as its B operand): a lane then owns one row and, per register quad q, the four consecutive channels
+// ch0 + 8 q .. + 3 (ch0 = 32 * wavefront + 4 * (lane / 32)), so activations go to LDS as packed bf16 planes and
+// output rows as float4 - no 2- or 4-byte scatter.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+struct WFragB3 { f32x4 f[2][2]; };                           // one K tile of a wavefront's 32 channels, fp32: [k16 half][4-float group]
+constexpr int B3T_H_PITCH = 264;                             // bf16 per row of an activation plane: 528 B (conflict-free b128 reads)
+
+// four fp32 values -> their three bf16 terms, packed (exact: every remainder is representable in fp32)
+__device__ __forceinline__ void b3_split4(const f32x4 &x, u32x2 (&pl)[3]) {
+    const unsigned h0 = b3_pack(x[0], x[1]), h1 = b3_pack(x[2], x[3]);
+    const float r0 = x[0] - b3_lo(h0), r1 = x[1] - b3_hi(h0), r2 = x[2] - b3_lo(h1), r3 = x[3] - b3_hi(h1);
+    const unsigned m0 = b3_pack(r0, r1), m1 = b3_pack(r2, r3);
+    pl[0] = u32x2{h0, h1};
+    pl[1] = u32x2{m0, m1};
+    pl[2] = u32x2{b3_pack(r0 - b3_lo(m0), r1 - b3_hi(m0)), b3_pack(r2 - b3_lo(m1), r3 - b3_hi(m1))};
+}
+
+// one 32-deep K tile: weights `w` (fp32, split here) x activations in three planes at `xb` (byte pointer to the K tile's
+// first column of row 0 of plane 0; `pitch` bf16 per row, `plane_bytes` between planes); six products per term pair,
+// smallest first
+template <int MI>
+__device__ __forceinline__ void b3t_mma_ktile(const char *xb, const int pitch, const int plane_bytes, const WFragB3 &w,
+                                              f32x16 (&acc)[MI], const int li, const int lh) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        bf16x8 wp[3], av[MI][3];
+        b3_split8(w.f[h][0], w.f[h][1], wp);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                av[mi][p] = *reinterpret_cast<const bf16x8 *>(xb + p * plane_bytes + ((mi * 32 + li) * pitch + h * 16 + lh * 8) * 2);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[0], av[mi][2], acc[mi], 0, 0, 0);
+            acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[1], av[mi][1], acc[mi], 0, 0, 0);
+            acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[2], av[mi][0], acc[mi], 0, 0, 0);
+            acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[0], av[mi][1], acc[mi], 0, 0, 0);
+            acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[1], av[mi][0], acc[mi], 0, 0, 0);
+            acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[0], av[mi][0], acc[mi], 0, 0, 0);
+        }
+    }
+}
+
+// acc <- lrelu(acc + bias) (kept, fp32) and, split, into the three activation planes at `Hb` (pitch B3T_H_PITCH)
+template <int MI>
+__device__ __forceinline__ void b3t_activate_to_planes(f32x16 (&acc)[MI], const float *bias, const float slope, char *Hb,
+                                                       const int plane_bytes, const int li, const int ch0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 bq = gload4(bias + ch0 + 8 * q);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = acc[mi][4 * q + e] + bq[e];
+                t = t > 0.0f ? t : t * slope;
+                acc[mi][4 * q + e] = t;
+                v[e] = t;
+            }
+            u32x2 pl[3];
+            b3_split4(v, pl);
+            char *d = Hb + ((mi * 32 + li) * B3T_H_PITCH + ch0 + 8 * q) * 2;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2 *>(d + p * plane_bytes) = pl[p];
+        }
+    }
+}
+
+// gemm_tile_b3t<MI>: a fused pair (GemmProb::w2: a pyramid level's 3-tap and 1x1 convolutions, lib/model/rie.py:94-97)
+// on the bf16 matrix cores with D[channel][row] accumulators.  First layer: A from HBM as in gemm_tile_b3 (fp32 staged
+// through a three-stage LDS ring as three bf16 planes), weights fp32 in bf16-MFMA operand order split in registers.
+// Its activations go to three [32 MI x C] bf16 planes over the dead ring, the 1x1 convolution runs on them barrier-free,
+// and the epilogue stages fp32 rows over the planes: + residual, 1 KiB stores.  N <= 256 (one column tile), MI <= 2.
+template <int MI>
+__device__ __forceinline__ void gemm_tile_b3t(ProbRef P, const int row0, float *smem, long long *dbg) {
+    static_assert(MI >= 1 && MI <= 2, "the activation planes of a pair tile hold 64 rows");
+    R3D_TSTAMP(0);
+    constexpr int VR = MI * 32, NA = (VR + 63) / 64;
+    constexpr int PLANE = VR * B3_LD, SFB = 3 * PLANE;      // floats per ring plane / per ring stage
+    constexpr int H_PLANE = VR * B3T_H_PITCH * 2;           // bytes per activation plane
+    static_assert(3 * SFB * 4 <= GEMM_LDS_BYTES && 3 * H_PLANE <= GEMM_LDS_BYTES && VR * PAIR_LD * 4 <= 3 * H_PLANE, "LDS overlays");
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int M = P.M, K = P.K;
+    const int nk = K / BK;
+    const int srow = tid >> 3, a_kq = (tid & 7) * 4;
+    const int ch0 = wave * 32 + 4 * lh;
+    // ---- A staging (fp32 from HBM -> three bf16 planes per ring stage), one segment (pair operands are plain)
+    __amdgpu_buffer_rsrc_t arsrc;
+    int a_voff[NA];
+    {
+        const int ld = P.lda[0];
+        const float *base = P.a[0] + (size_t)row0 * ld;
+        const long long b = ((long long)(M - 1 - row0) * ld + K) * 4;
+        arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, b < 0x7fffffffLL ? (int)b : 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int gr = row0 + srow + 64 * i;
+            a_voff[i] = (((gr < M ? gr : M - 1) - row0) * ld + a_kq) * 4;
+        }
+    }
+    struct Staged { f32x4 a[NA]; };
+    Staged ra, ra2, ra3;
+    auto issue_a = [&](int kt, Staged &R) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff[i], kt * BK * 4, 0));
+    };
+    const int st_off = srow * B3_LD + (a_kq >> 1);
+    auto commit_a = [&](int stage, const Staged &R) {
+        float *s = smem + stage * SFB + st_off;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (srow + 64 * i >= VR) continue;
+            u32x2 pl[3];
+            b3_split4(R.a[i], pl);
+            float *d = s + i * 64 * B3_LD;
+            *reinterpret_cast<u32x2 *>(d) = pl[0];
+            *reinterpret_cast<u32x2 *>(d + PLANE) = pl[1];
+            *reinterpret_cast<u32x2 *>(d + 2 * PLANE) = pl[2];
+        }
+    };
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int w_voff = lane * 16;
+    auto load_w = [&](__amdgpu_buffer_rsrc_t rs, int kt, WFragB3 &dst) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                dst.f[h][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, w_voff + (h * 2 + j) * 1024, kt * 4096, 0));
+    };
+    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.wb3 + ((size_t)wave_u * nk) * 1024), 0, nk * 4096, 0x00020000);
+    WFragB3 wa, wb, wc;
+    f32x16 acc[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.0f;
+    const int last = nk - 1;
+    load_w(wrsrc, 0, wa);
+    load_w(wrsrc, 1 < last ? 1 : last, wb);
+    {
+        Staged r0, r1;
+        issue_a(0, r0);
+        issue_a(1 < last ? 1 : last, r1);
+        issue_a(2 < last ? 2 : last, ra);
+        issue_a(3 < last ? 3 : last, ra2);
+        issue_a(4 < last ? 4 : last, ra3);
+        commit_a(0, r0);
+        commit_a(1, r1);
+    }
+    __syncthreads();
+    R3D_TSTAMP(1);
+    int st_cur = 0;
+    auto k_tile = [&](int kt, const WFragB3 &w_use, WFragB3 &w_load, Staged &stg) {
+        const int st_next = st_cur == 2 ? 0 : st_cur + 1, st_next2 = st_next == 2 ? 0 : st_next + 1;
+        commit_a(st_next2, stg);                 // tile kt+2
+        load_w(wrsrc, kt + 2 < last ? kt + 2 : last, w_load);
+        issue_a(kt + 5 < last ? kt + 5 : last, stg);
+        // ring planes: row pitch B3_LD floats = 2 * B3_LD bf16
+        b3t_mma_ktile<MI>(reinterpret_cast<const char *>(smem + st_cur * SFB), 2 * B3_LD, PLANE * 4, w_use, acc, li, lh);
+        __syncthreads();
+        st_cur = st_next;
+    };
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 3) {
+        k_tile(kt, wa, wc, ra);
+        k_tile(kt + 1, wb, wa, ra2);
+        k_tile(kt + 2, wc, wb, ra3);
+    }
+    if (kt < nk) {
+        k_tile(kt, wa, wc, ra);
+        if (kt + 1 < nk) k_tile(kt + 1, wb, wa, ra2);
+    }
+    R3D_TSTAMP(2);
+    // ---- first layer's activations -> planes (the ring is dead: the last k_tile ended with a barrier)
+    const int nk2 = P.K2 / BK, last2 = nk2 - 1;
+    __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.w2b3 + ((size_t)wave_u * nk2) * 1024), 0, nk2 * 4096, 0x00020000);
+    load_w(w2rsrc, 0, wa);
+    load_w(w2rsrc, 1 < last2 ? 1 : last2, wb);
+    char *Hb = reinterpret_cast<char *>(smem);
+    b3t_activate_to_planes<MI>(acc, P.bias, P.slope, Hb, H_PLANE, li, ch0);
+    __syncthreads();
+    R3D_TSTAMP(3);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.0f;
+    {
+        auto k_tile2 = [&](int k2, const WFragB3 &w_use, WFragB3 &w_load) {
+            load_w(w2rsrc, k2 + 2 < last2 ? k2 + 2 : last2, w_load);
+            b3t_mma_ktile<MI>(Hb + k2 * BK * 2, B3T_H_PITCH, H_PLANE, w_use, acc, li, lh);
+        };
+        int k2 = 0;
+        for (; k2 + 2 < nk2; k2 += 3) {
+            k_tile2(k2, wa, wc);
+            k_tile2(k2 + 1, wb, wa);
+            k_tile2(k2 + 2, wc, wb);
+        }
+        if (k2 < nk2) {
+            k_tile2(k2, wa, wc);
+            if (k2 + 1 < nk2) k_tile2(k2 + 1, wb, wa);
+        }
+    }
+    // ---- epilogue: lrelu(acc + bias2) as fp32 rows over the planes, then + residual and 1 KiB stores
+    __syncthreads();                                         // every wavefront is done reading the planes
+    {
+        const float slope2 = P.slope2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bq = gload4(P.bias2 + ch0 + 8 * q);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = acc[mi][4 * q + e] + bq[e];
+                    v[e] = t > 0.0f ? t : t * slope2;
+                }
+                *reinterpret_cast<f32x4 *>(smem + (mi * 32 + li) * PAIR_LD + ch0 + 8 * q) = v;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int rd_row = tid >> 6, rd_c4 = (tid & 63) * 4;
+        const int N = P.N;
+        const float *res = P.res;
+#pragma unroll
+        for (int j = 0; j < 4 * MI; ++j) {
+            const int lr = rd_row + 8 * j, row = row0 + lr;
+            if (row >= M) continue;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(smem + lr * PAIR_LD + rd_c4);
+            if (rd_c4 + 4 <= N) {
+                if (res) v += gload4(res + (size_t)row * P.ldr + rd_c4);
+                __builtin_nontemporal_store(v, (R3D_AS1 f32x4 *)(P.c + (size_t)row * P.ldc + rd_c4));
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (rd_c4 + c < N) gstore1(P.c + (size_t)row * P.ldc + rd_c4 + c, v[c] + (res ? gload1(res + (size_t)row * P.ldr + rd_c4 + c) : 0.0f));
+            }
+        }
+    }
+    __syncthreads();
+    R3D_TSTAMP(4);
+}
+
 // ------------------------------------------------------------------------------------ UV input mode
 //
 // get_cam_ray_given_uv (lib/camera/camera.py:460-471) applied to a gathered value on its way into LDS: the operand
@@ -1486,7 +1740,7 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
 //  * the weights stream as fp32 in bf16-MFMA operand order (GemmProb::wb3 / w2b3 / w3b3: the same bytes per K tile
 //    as the fp32 path) and are split in registers by the wavefront that owns the 32 channels, behind the matrix work.
 // Opt-in with the rest of the bf16x3 mode (R3D_BF16X3=1 at r3d_create).
-constexpr int FLB_H_PITCH = 264;                                         // bf16 per H row: 528 B (conflict-free b128 operand reads)
+constexpr int FLB_H_PITCH = B3T_H_PITCH;                                 // bf16 per H row: 528 B (conflict-free b128 operand reads)
 constexpr int FLB_G_PITCH = 72;                                          // bf16 per G row: 144 B
 constexpr int FLB_H_PLANE = FLT_MAX_MI * 32 * FLB_H_PITCH * 2;           // bytes per H plane: 33,792
 constexpr int FLB_G_PLANE = FLT_MAX_MI * 32 * FLB_G_PITCH * 2;           // bytes per G plane:  9,216
@@ -1499,7 +1753,6 @@ template <int MI, bool MULTI, bool UV>
 __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_list, const int ntiles, const bool new_prob, float *smem,
                                                     long long *dbg_base) {
     static_assert(MI >= 1 && MI <= FLT_MAX_MI, "tile height");
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6;
@@ -1519,7 +1772,7 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
     }
     __syncthreads();
     __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x), 0, P.enc_bytes, 0x00020000);
-    struct WFrag { f32x4 f[2][2]; };                         // one K tile of this wavefront's 32 channels: [k16 half][4-float group]
+    typedef WFragB3 WFrag;
     auto load_w = [&](__amdgpu_buffer_rsrc_t rs, int kt, WFrag &dst) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -1564,15 +1817,6 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
                 gq.a[h][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, b + (unsigned)c1[c], 0, 0));
         }
     };
-    // four fp32 values -> their three bf16 terms, packed (exact: every remainder is representable in fp32)
-    auto split4 = [&](const f32x4 &x, u32x2 (&pl)[3]) {
-        const unsigned h0 = b3_pack(x[0], x[1]), h1 = b3_pack(x[2], x[3]);
-        const float r0 = x[0] - b3_lo(h0), r1 = x[1] - b3_hi(h0), r2 = x[2] - b3_lo(h1), r3 = x[3] - b3_hi(h1);
-        const unsigned m0 = b3_pack(r0, r1), m1 = b3_pack(r2, r3);
-        pl[0] = u32x2{h0, h1};
-        pl[1] = u32x2{m0, m1};
-        pl[2] = u32x2{b3_pack(r0 - b3_lo(m0), r1 - b3_hi(m0)), b3_pack(r2 - b3_lo(m1), r3 - b3_hi(m1))};
-    };
     auto commit_phase = [&](int ch, char *G) {
         if (!on) return;
 #pragma unroll
@@ -1588,58 +1832,12 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
                 v[3] = uv_to_ray(v[3], code.w, camr);
             }
             u32x2 pl[3];
-            split4(v, pl);
+            b3_split4(v, pl);
             char *d = G + (srow * FLB_G_PITCH + h * BK + a_kq) * 2;
 #pragma unroll
             for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2 *>(d + p * FLB_G_PLANE) = pl[p];
         }
     };
-    // one 32-deep K tile of matrix work: weights `w` (fp32, split here) x activations in planes at `xb` (row pitch `pitch` bf16)
-    auto mma_ktile = [&](const char *xb, const int pitch, const int plane_bytes, const WFrag &w, f32x16 (&acc)[MI]) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            bf16x8 wp[3], av[MI][3];
-            b3_split8(w.f[h][0], w.f[h][1], wp);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    av[mi][p] = *reinterpret_cast<const bf16x8 *>(xb + p * plane_bytes + ((mi * 32 + li) * pitch + h * 16 + lh * 8) * 2);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {                // smallest terms first; D[channel][row]
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[0], av[mi][2], acc[mi], 0, 0, 0);
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[1], av[mi][1], acc[mi], 0, 0, 0);
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[2], av[mi][0], acc[mi], 0, 0, 0);
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[0], av[mi][1], acc[mi], 0, 0, 0);
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[1], av[mi][0], acc[mi], 0, 0, 0);
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[0], av[mi][0], acc[mi], 0, 0, 0);
-            }
-        }
-    };
-    // activations = lrelu(acc + bias) (kept in acc), written to the H planes
-    auto activate_to_planes = [&](f32x16 (&acc)[MI], const float *bias, const float slope) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 bq = gload4(bias + ch0 + 8 * q);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = acc[mi][4 * q + e] + bq[e];
-                    t = t > 0.0f ? t : t * slope;
-                    acc[mi][4 * q + e] = t;
-                    v[e] = t;
-                }
-                u32x2 pl[3];
-                split4(v, pl);
-                char *d = Hb + ((mi * 32 + li) * FLB_H_PITCH + ch0 + 8 * q) * 2;
-#pragma unroll
-                for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2 *>(d + p * FLB_H_PLANE) = pl[p];
-            }
-        }
-    };
-
     WFrag wa, wb, wc;                                        // streaming weight fragments (three sets rotating)
     // expand_conv fragments.  One chunk: resident in (w0a, w0b).  Several chunks: the streaming sets are idle during
     // the expand phases, so the chunks alternate between (wa, wb) and (wc, w0a) and chunk 0 returns to (wa, wb) once
@@ -1691,8 +1889,8 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
                 if (ch + 1 < nch) issue_phase(row0, tap, ch + 1);
                 else if (ts < 2) issue_phase(row0, tap_of(ts + 1), 0);
                 else if (next_row0 >= 0) issue_phase(next_row0, 0, 0);
-                mma_ktile(G, FLB_G_PITCH, FLB_G_PLANE, ua, acc0);
-                if (ch * 2 + 1 < nk0) mma_ktile(G + BK * 2, FLB_G_PITCH, FLB_G_PLANE, ub, acc0);
+                b3t_mma_ktile<MI>(G, FLB_G_PITCH, FLB_G_PLANE, ua, acc0, li, lh);
+                if (ch * 2 + 1 < nk0) b3t_mma_ktile<MI>(G + BK * 2, FLB_G_PITCH, FLB_G_PLANE, ub, acc0, li, lh);
                 ++phase;
             };
             if constexpr (MULTI) {
@@ -1708,7 +1906,7 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
             // ---- activations -> H planes (the residual tap's stay in acc0, fp32, for the epilogue)
             load_w(w1rsrc, tap * tiles_per_tap, wa);
             load_w(w1rsrc, tap * tiles_per_tap + (tiles_per_tap > 1 ? 1 : 0), wb);
-            activate_to_planes(acc0, P.bias, slope0);
+            b3t_activate_to_planes<MI>(acc0, P.bias, slope0, Hb, FLB_H_PLANE, li, ch0);
             __syncthreads();
             if (ts == 0) R3D_TSTAMP(6);
             // ---- this tap's third of the 3-tap convolution
@@ -1716,7 +1914,7 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
                 const int kbase = tap * tiles_per_tap, lastk = tiles_per_tap - 1;
                 auto k_tile1 = [&](int kin, const WFrag &w_use, WFrag &w_load) {
                     load_w(w1rsrc, kbase + (kin + 2 < lastk ? kin + 2 : lastk), w_load);
-                    mma_ktile(Hb + kin * BK * 2, FLB_H_PITCH, FLB_H_PLANE, w_use, acc1);
+                    b3t_mma_ktile<MI>(Hb + kin * BK * 2, FLB_H_PITCH, FLB_H_PLANE, w_use, acc1, li, lh);
                 };
                 int kin = 0;
                 for (; kin + 2 < tiles_per_tap; kin += 3) {
@@ -1742,7 +1940,7 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
         load_w(w2rsrc, 0, wa);
         load_w(w2rsrc, nk2 > 1 ? 1 : 0, wb);
         __syncthreads();                                     // every wavefront is done reading the last tap's H
-        activate_to_planes(acc1, P.bias2, slope1);
+        b3t_activate_to_planes<MI>(acc1, P.bias2, slope1, Hb, FLB_H_PLANE, li, ch0);
         __syncthreads();
         R3D_TSTAMP(2);
 #pragma unroll
@@ -1753,7 +1951,7 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
             const int last2 = nk2 - 1;
             auto k_tile2 = [&](int kt, const WFrag &w_use, WFrag &w_load) {
                 load_w(w2rsrc, kt + 2 < last2 ? kt + 2 : last2, w_load);
-                mma_ktile(Hb + kt * BK * 2, FLB_H_PITCH, FLB_H_PLANE, w_use, acc1);
+                b3t_mma_ktile<MI>(Hb + kt * BK * 2, FLB_H_PITCH, FLB_H_PLANE, w_use, acc1, li, lh);
             };
             int kt = 0;
             for (; kt + 2 < nk2; kt += 3) {
@@ -1894,6 +2092,11 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                     case 2: enc_tile<2, UV>(P, row0, col0, new_prob, smem, dbg); break;
                     default: enc_tile<3, UV>(P, row0, col0, new_prob, smem, dbg); break;
                 }
+                continue;
+            }
+            if (P.wb3 != nullptr && P.w2 != nullptr) {   // a fused pair on the bf16 matrix cores (tiles of <= 64 rows)
+                if (mi >= 2) gemm_tile_b3t<2>(P, row0, smem, dbg);
+                else gemm_tile_b3t<1>(P, row0, smem, dbg);
                 continue;
             }
             if (P.wb3 != nullptr) {      // fp32 on the bf16 matrix cores (whole tiles of <= 128 rows)

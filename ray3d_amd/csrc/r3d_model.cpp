@@ -103,7 +103,7 @@ struct Grammar {
             // 3 taps - or, for the dense ablation (rie.py:49-53), 2 * pad + 1 with pad = the level's dilation 3^i
             const int la = layer(p + ".layers_conv." + a, m->cfg.dense ? 2 * dil + 1 : 3, C, C, false, p + ".layers_bn." + a, 0.2f, true);
             const int lb = layer(p + ".layers_conv." + b, 1, C, C, false, p + ".layers_bn." + b, 0.2f, true);
-            if (i == 1) m->layers[la].bf3_conv = m->layers[lb].bf3_conv = fl_b3;
+            m->layers[la].bf3_conv = m->layers[lb].bf3_conv = fl_b3;   // (level 1: in the fused first level; further levels: fused pairs)
         }
         layer(p + ".shrink", 1, C, m->cfg.latent, true, "", 1.0f, true);
     }
