@@ -543,6 +543,33 @@ def test_bf16x3_mode_keeps_parity(monkeypatch):
     assert np.abs(out - ref).max() <= tol_for(ref)
 
 
+def test_bf16x3_error_against_float64_is_the_fp32_paths(monkeypatch):
+    """The claim behind "fp32-equivalent": measured against a FLOAT64 evaluation of the same network (the torch port run
+    in double precision), the bf16x3 path's error is no larger than the fp32-MFMA path's - on the RF-243 network, whose
+    first level, fused pairs and 1024-wide Linears all run on the bf16 matrix cores in that mode."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    from oracle import torch_port
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3,3,3")
+    (cp, sp), (ct, st) = synth_states(mc)
+    B = 96
+    x, p = synth.synth_rays(B, cp, seed=61), synth.synth_param(B, seed=62)
+    sd64 = [{k: torch.from_numpy(np.asarray(v)).double() for k, v in s_.items() if np.asarray(v).dtype == np.float32} for s_ in (sp, st)]
+    with torch.no_grad():
+        x64, p64 = torch.from_numpy(x).double(), torch.from_numpy(p).double()
+        ref = (torch_port.forward(cp, sd64[0], x64, p64) + torch_port.forward(ct, sd64[1], x64, p64)).numpy()
+    errs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("R3D_BF16X3", mode)
+        pos, trj, _, _ = build_modules(mc)
+        with torch.no_grad():
+            out = ray3d_amd.Ray3DLifter(pos, trj).eval()(torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()).cpu().numpy()
+        errs[mode] = float(np.abs(out.astype(np.float64) - ref).max())
+    print("max abs error vs float64: fp32 MFMA %.3e, bf16x3 %.3e (|ref| max %.2f)" % (errs["0"], errs["1"], np.abs(ref).max()))
+    assert errs["0"] <= 1e-4 and errs["1"] <= 1e-4
+    assert errs["1"] <= 1.25 * errs["0"] + 1e-6
+
+
 # ---------------------------------------------------------------- per-clip error sums on the device
 
 def _metric_sums_hip(pred, gt, R, T):
