@@ -66,6 +66,7 @@ int main(int argc, char **argv) {
         for (int s = 0; s < MAX_SEG; ++s) { g.a[s] = dA[i]; g.lda[s] = K; g.kend[s] = 0x7fffffff; }
         g.w = dW[i]; g.bias = dbias; g.res = nullptr; g.c = dC[i]; g.ldr = 0; g.ldc = N;
         g.M = M; g.N = N; g.K = K; g.slope = 0.2f;
+        if (getenv("PROBE_B3")) g.wb3 = dW[i];   // timing only: the bf16x3 tile on weights that are not in its operand order
         if (enc) { g.lut = dlut; g.x = dx; g.enc_ws = 243 * 51; g.enc_rows = 81; g.enc_jf = 51; g.enc_cur = 81 * 51; g.enc_step = 3; g.enc_bytes = (unsigned)(hx.size() * 4); }
         sp.push_back({M, N, K / BK, enc ? 1 : 4, enc ? std::max(1, std::min(3, (64 * 1024) / ((K + 4) * 4 * 32))) : 0});
     }
