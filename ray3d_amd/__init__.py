@@ -13,7 +13,7 @@ ABI of include/ray3d_hip.h).  No CPU fallback exists.
 """
 from .spec import LiftConfig, config_from_dicts, default_model_config   # noqa: F401
 from .modules import (Model, RIEModel, RIETrajectoryModel, Ray3DLifter, load_checkpoint, load_weight)   # noqa: F401
-from .camera import Camera, synthetic_camera   # noqa: F401
+from .camera import Camera, augment_camera, camera_grid, synthetic_camera   # noqa: F401
 from . import dataset, evaluate, metrics, synth   # noqa: F401
 
 __version__ = "0.1.0"

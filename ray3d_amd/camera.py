@@ -144,3 +144,55 @@ def synthetic_camera(yaw_deg: float, distance: float, pitch_deg: float, height: 
     t = -R @ pos
     K = np.array([[focal, 0.0, center[0]], [0.0, focal, center[1]], [0.0, 0.0, 1.0]])
     return Camera(K, R, t, name=name)
+
+
+def _rodrigues(axis, radian: float) -> np.ndarray:
+    """Rotation by `radian` about `axis` - what data/camera_augmentation.py:433-441 computes as
+    expm(cross(I, axis / |axis| * radian))."""
+    a = np.asarray(axis, dtype=np.float64).reshape(3)
+    a = a / np.linalg.norm(a)
+    Kx = np.array([[0.0, -a[2], a[1]], [a[2], 0.0, -a[0]], [-a[1], a[0], 0.0]])
+    return np.eye(3) + math.sin(radian) * Kx + (1.0 - math.cos(radian)) * (Kx @ Kx)
+
+
+def _rotate_camera(R, T, center, axis, radian):
+    """data/camera_augmentation.py:443-466: rotate the camera (pose and position) about `axis` through `center`."""
+    Rc2w = R.T
+    Tc2w = -Rc2w @ T
+    M = _rodrigues(axis, radian)
+    new_Rc2w = M @ Rc2w
+    new_Tc2w = M @ (Tc2w - center) + center
+    new_Rw2c = new_Rc2w.T
+    return new_Rw2c, -new_Rw2c @ new_Tc2w
+
+
+def augment_camera(R, t, yaw_deg: float, dist_ratio: float, pitch_deg: float, center=(0.0, 0.0, 1.8)):
+    """One camera of the reference's synthetic camera sets (data/camera_augmentation.py:696-718) from a base camera
+    (R world->camera, t in metres): the translation scaled about the centre point ((T - c) * ratio + c, applied to
+    Tw2c exactly as the script does, :416-424), a yaw about the world z axis through the centre, then a pitch about
+    the horizontal axis perpendicular to the camera's position vector.  Returns (R, t (3,1)) of the new camera."""
+    R = np.asarray(R, dtype=np.float64).reshape(3, 3)
+    T = np.asarray(t, dtype=np.float64).reshape(3, 1)
+    c = np.asarray(center, dtype=np.float64).reshape(3, 1)
+    T1 = (T - c) * dist_ratio + c
+    R2, T2 = _rotate_camera(R, T1, c, np.array([0.0, 0.0, 1.0]), yaw_deg / 180.0 * np.pi)
+    pos = -R2.T @ T2
+    axis = np.array([-pos[1, 0], pos[0, 0], 0.0])
+    return _rotate_camera(R2, T2, c, axis, pitch_deg / 180.0 * np.pi)
+
+
+# The 'Train' set of data/camera_augmentation.py:637-642: yaw x distance ratio x pitch (degrees), 342 cameras
+AUGMENTATION_TRAIN_GRID = ((60, 180, 300), (2.0, 2.2, 2.4, 2.6, 2.8, 3.0),
+                           tuple(range(-26, 11, 2)))
+
+
+def camera_grid(K, R, t, grid=AUGMENTATION_TRAIN_GRID, center=(0.0, 0.0, 1.8)):
+    """All cameras of a (yaws, distance ratios, pitches) grid around a base camera, in the script's loop order
+    (yaw outermost, pitch innermost; :680-688)."""
+    cams = []
+    for yaw in grid[0]:
+        for dist in grid[1]:
+            for pitch in grid[2]:
+                Rn, tn = augment_camera(R, t, yaw, dist, pitch, center)
+                cams.append(Camera(K, Rn, tn, name="yaw%g_d%g_p%g" % (yaw, dist, pitch)))
+    return cams

@@ -403,6 +403,31 @@ def gen_frontends():
         blob["he/universal_in"] = kp["positions_2d"].item()["Train/S1"]["A"][0]
         blob["he/universal_out"] = upd["Train/S1"]["A"][0]
         blob["he/universal_symmetry"] = np.array(upd_meta["keypoints_symmetry"])
+    # ---------------- (c) the synthetic camera sets: data/camera_augmentation.py's own functions on the base camera
+    # the script uses (S1, camera 1), for a spread of the 'Train' grid (yaw x distance ratio x pitch)
+    sys.modules.setdefault("ipdb", types.ModuleType("ipdb"))
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+    except Exception:
+        sys.modules.setdefault("matplotlib", types.ModuleType("matplotlib"))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_camera_augmentation", os.path.join(REF, "data", "camera_augmentation.py"))
+    ca = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ca)
+    ext = h36m_cameras_extrinsic_params["S1"][1]
+    R0 = np.array(ext["R"], dtype="float32").astype(np.float64)
+    T0 = (np.array(ext["translation"], dtype="float32") / 1000).astype(np.float64).reshape(3, 1)
+    center = np.array([0, 0, 1.8]).reshape(3, 1)
+    combos = [(60, 2.0, -26), (180, 2.4, -10), (300, 3.0, 10), (60, 2.8, 0), (180, 2.0, 4), (300, 2.2, -18)]
+    blob["grid/R0"], blob["grid/T0"], blob["grid/combos"] = R0, T0, np.array(combos, dtype=np.float64)
+    for i, (yaw_d, ratio, pitch_d) in enumerate(combos):
+        T1 = ca.camera_translation(T0, center, ratio)
+        R2, T2 = ca.rotate_camera(R0, T1, center, np.array(ca.AXIS_Z), ca.convertdegree2euler(yaw_d))
+        pos = -np.dot(R2.T, T2)
+        axis = np.array([-pos[1][0], pos[0][0], 0])
+        R3, T3 = ca.rotate_camera(R2, T2, center, axis, ca.convertdegree2euler(pitch_d))
+        blob["grid/R/%d" % i], blob["grid/T/%d" % i] = R3, T3
     np.savez_compressed(os.path.join(HERE, "frontends.npz"), **blob)
     print("frontends: aug subjects", len(blob["aug/subjects_all"]), "camera_dist", list(blob["aug/camera_dist"]), "| humaneva keys", keys)
 

@@ -721,3 +721,59 @@ def test_clip_sharded_eval_over_rccl_two_gpus():
     one, two = _bench_eval(1), _bench_eval(2)
     assert two["n_gpus"] == 2
     assert two["mpjpe_mm"] == one["mpjpe_mm"]            # same clips, same kernels, fixed summation order: identical
+
+
+def test_camera_augmented_14_joint_batch_uv_mode():
+    """BASELINE configs[4] with the reference's camera grid: 14-joint layout, RF 9, 4096 windows per step, every window
+    seen by one of the 342 cameras of the 'Train' set of data/camera_augmentation.py (yaw x distance ratio x pitch around
+    H36M S1 / camera 1, restated by ray3d_amd.camera_grid and pinned to the script's own functions in tests/test_host.py),
+    pixel keypoints in (UV mode), against the oracle chain on every window."""
+    import os
+    import ray3d_amd
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "frontends.npz"))
+    K = np.array([[1145.51133842, 0, 514.968197319], [0, 1144.77392808, 501.882018537], [0, 0, 1.0]])   # H36M camera 1 intrinsics
+    cams = ray3d_amd.camera_grid(K, z["grid/R0"], z["grid/T0"])
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3", NUM_KPTS=14)
+    pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    B = 4096
+    rng = np.random.default_rng(14)
+    pick = [cams[i % len(cams)] for i in range(B)]
+    # a 14-joint skeleton near the centre point, moving a little over the 9 frames, projected by each window's camera
+    world = rng.normal(0, 0.25, (B, 1, 14, 3)) + np.array([0, 0, 1.0]) + 0.01 * np.cumsum(rng.normal(0, 1, (B, 9, 1, 3)), axis=1)
+    uv = np.stack([c.project(world[i]) for i, c in enumerate(pick)]).astype(np.float32)
+    rays = np.stack([c.rays_from_uv(uv[i].astype(np.float64)) for i, c in enumerate(pick)]).astype(np.float32)
+    rows, par = np.stack([c.cam_row() for c in pick]), np.stack([c.param() for c in pick])
+    with torch.no_grad():
+        out = lifter.forward_uv(torch.from_numpy(uv).cuda(), torch.from_numpy(rows).cuda(), torch.from_numpy(par).cuda())
+    assert out.shape == (B, 1, 14, 3) and torch.isfinite(out).all()
+    ref = _oracle_lift(((cp, sp), (ct, st)), rays, par)
+    assert np.abs(out.cpu().numpy() - ref).max() <= tol_for(ref), np.abs(out.cpu().numpy() - ref).max()
+
+
+def test_forward_captured_in_a_hip_graph_after_prepare():
+    """r3d_prepare moves the schedule build (hipMalloc + blocking copy) out of the forward, so a forward of a batch size
+    the library has not seen can be captured into a hipGraph; the replay equals the eager result."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
+    pos, trj, (cp, _), _ = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    B = 77                                                      # a batch size nothing else in this process has used
+    x = torch.from_numpy(synth.synth_rays(B, cp, seed=71)).cuda()
+    p = torch.from_numpy(synth.synth_param(B, seed=72)).cuda()
+    lifter.prepare([B])
+    out = torch.empty((B, 1, 17, 3), device="cuda")
+    lifter._ws.get(ray3d_amd._capi.workspace_bytes(lifter.pos.handle(x.device), lifter.trj.handle(x.device), B), x.device)
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.no_grad(), torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            lifter._run(ray3d_amd._capi.R3D_INPUT_RAYS, x, 27, B, p, 2, out=out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        eager = lifter(x, p)
+    assert torch.equal(out, eager)

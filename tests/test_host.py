@@ -604,3 +604,19 @@ def test_humaneva_camera_layout_and_joint_conventions():
     assert list(dataset.SYMMETRY_HUMANEVA_15[1]) == list(z["he/joints_right"])
     assert np.array_equal(z["he/universal_in"][:, list(dataset.HUMANEVA_15_TO_UNIVERSAL_14)], z["he/universal_out"])
     assert [list(v) for v in dataset.SYMMETRY_14] == z["he/universal_symmetry"].tolist()
+
+
+def test_camera_augmentation_grid_matches_the_reference_script():
+    """ray3d_amd.augment_camera vs data/camera_augmentation.py's camera_translation / rotate_camera chain (:416-466,
+    :696-718) on the script's base camera, and the size / order of the 'Train' grid (:637-642)."""
+    z = np.load(os.path.join(GOLDEN, "frontends.npz"))
+    R0, T0 = z["grid/R0"], z["grid/T0"]
+    for i, (yaw, ratio, pitch) in enumerate(z["grid/combos"]):
+        R, T = ray3d_amd.augment_camera(R0, T0, yaw, ratio, pitch)
+        assert np.abs(R - z["grid/R/%d" % i]).max() < 1e-12 and np.abs(T - z["grid/T/%d" % i]).max() < 1e-12
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-6          # (the float32 table itself is orthogonal to ~5e-8)
+    K = np.array([[1145.0, 0, 512.0], [0, 1144.0, 515.0], [0, 0, 1.0]])
+    cams = ray3d_amd.camera_grid(K, R0, T0)
+    assert len(cams) == 3 * 6 * 19 and cams[0].name == "yaw60_d2_p-26" and cams[-1].name == "yaw300_d3_p10"
+    R, T = ray3d_amd.augment_camera(R0, T0, 60, 2.0, -26)
+    assert np.array_equal(cams[0].Rw2c, R) and np.array_equal(cams[0].Tw2c, T)
