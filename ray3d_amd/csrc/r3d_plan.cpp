@@ -139,9 +139,7 @@ struct Builder {
         // all of its columns (r3d_kernels.hip, PAIR); otherwise the intermediate goes through a buffer
         // Fusing costs the level its split-K freedom (a fused tile is a whole 32-row unit through both layers), so
         // the top of the pyramid - one row per window, fewer units than CUs at the usual batch sizes - stays unfused.
-        // (experiment R3D_NOFUSE_ROWS=<n>: leave the level with n rows per window unfused - its 3-tap layer may then be split along K)
-        static const int nofuse_rows = [] { const char *e = getenv("R3D_NOFUSE_ROWS"); return e ? atoi(e) : -1; }();
-        auto fuse = [&](int level_rows) { return C <= N_ALIGN && level_rows >= 3 && level_rows != nofuse_rows; };
+        auto fuse = [&](int level_rows) { return C <= N_ALIGN && level_rows >= 3; };
         const int hb = L > 1 ? buffer(br.prefix + ".H", (int64_t)(rows / 3) * C) : -1;
         // first layer: the A operand is generated from the raw input inside the kernel (fused prologue)
         int last, i0 = 1;
