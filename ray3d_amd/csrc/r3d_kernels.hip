@@ -44,6 +44,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 gload4(const float *p) { return *(const R3D_AS1 f32x4 *)p; }
 __device__ __forceinline__ float gload1(const float *p) { return *(const R3D_AS1 float *)p; }
 __device__ __forceinline__ void gstore1(float *p, float v) { *(R3D_AS1 float *)p = v; }
+// LeakyReLU for slopes in (0, 1] (0.2, 0.01; 1 = linear layer): max(v, slope v) - a multiply and a max instead of
+// multiply, compare, select
+__device__ __forceinline__ float lrelu(const float v, const float slope) { return __builtin_fmaxf(v, v * slope); }
 
 // ------------------------------------------------------------------------------------ GEMM
 //
@@ -120,7 +123,7 @@ __device__ __forceinline__ void store_tile(ProbRef P, const f32x16 (&acc)[MI], c
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[mi][r] + bias;
-                wr[((r & 3) + 8 * (r >> 2)) * EPI_LD] = v > 0.0f ? v : v * slope;
+                wr[((r & 3) + 8 * (r >> 2)) * EPI_LD] = lrelu(v, slope);
             }
         }
         __syncthreads();
@@ -418,7 +421,7 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = acc[mi][r] + bias1;
-                wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = v > 0.0f ? v : v * slope1;
+                wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = lrelu(v, slope1);
             }
         }
         __syncthreads();
@@ -716,20 +719,35 @@ __device__ __forceinline__ void b3t_mma_ktile(const char *xb, const int pitch, c
     }
 }
 
-// acc <- lrelu(acc + bias) (kept, fp32) and, split, into the three activation planes at `Hb` (pitch B3T_H_PITCH)
+// accumulators of a D[channel][row] tile start at the layer's bias (one add per value less in the epilogues)
 template <int MI>
-__device__ __forceinline__ void b3t_activate_to_planes(f32x16 (&acc)[MI], const float *bias, const float slope, char *Hb,
+__device__ __forceinline__ void b3t_init_bias(f32x16 (&acc)[MI], const float *bias, const int ch0) {
+    int c = ch0;
+    asm volatile("" : "+v"(c));                   // (opaque: the loads stay here instead of being hoisted out of the tile loops, where
+                                                  //  the bias vectors of three layers would stay live across all matrix phases)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 bq = gload4(bias + c + 8 * q);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mi][4 * q + e] = bq[e];
+    }
+}
+
+// acc <- lrelu(acc) (kept, fp32; the bias is in the sums already) and, split, into the three activation planes at `Hb`
+// (pitch B3T_H_PITCH)
+template <int MI>
+__device__ __forceinline__ void b3t_activate_to_planes(f32x16 (&acc)[MI], const float slope, char *Hb,
                                                        const int plane_bytes, const int li, const int ch0) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4 bq = gload4(bias + ch0 + 8 * q);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float t = acc[mi][4 * q + e] + bq[e];
-                t = t > 0.0f ? t : t * slope;
+                const float t = lrelu(acc[mi][4 * q + e], slope);
                 acc[mi][4 * q + e] = t;
                 v[e] = t;
             }
@@ -811,10 +829,7 @@ __device__ __forceinline__ void gemm_tile_b3t(ProbRef P, const int row0, float *
         const_cast<float *>(P.wb3 + ((size_t)wave_u * nk) * 1024), 0, nk * 4096, 0x00020000);
     WFragB3 wa, wb, wc;
     f32x16 acc[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.0f;
+    b3t_init_bias<MI>(acc, P.bias, ch0);
     const int last = nk - 1;
     load_w(wrsrc, 0, wa);
     load_w(wrsrc, 1 < last ? 1 : last, wb);
@@ -859,13 +874,10 @@ __device__ __forceinline__ void gemm_tile_b3t(ProbRef P, const int row0, float *
     load_w(w2rsrc, 0, wa);
     load_w(w2rsrc, 1 < last2 ? 1 : last2, wb);
     char *Hb = reinterpret_cast<char *>(smem);
-    b3t_activate_to_planes<MI>(acc, P.bias, P.slope, Hb, H_PLANE, li, ch0);
+    b3t_activate_to_planes<MI>(acc, P.slope, Hb, H_PLANE, li, ch0);
     __syncthreads();
     R3D_TSTAMP(3);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.0f;
+    b3t_init_bias<MI>(acc, P.bias2, ch0);
     {
         auto k_tile2 = [&](int k2, const WFragB3 &w_use, WFragB3 &w_load) {
             load_w(w2rsrc, k2 + 2 < last2 ? k2 + 2 : last2, w_load);
@@ -888,15 +900,11 @@ __device__ __forceinline__ void gemm_tile_b3t(ProbRef P, const int row0, float *
         const float slope2 = P.slope2;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 bq = gload4(P.bias2 + ch0 + 8 * q);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = acc[mi][4 * q + e] + bq[e];
-                    v[e] = t > 0.0f ? t : t * slope2;
-                }
+                for (int e = 0; e < 4; ++e) v[e] = lrelu(acc[mi][4 * q + e], slope2);
                 *reinterpret_cast<f32x4 *>(smem + (mi * 32 + li) * PAIR_LD + ch0 + 8 * q) = v;
             }
         }
@@ -1269,7 +1277,7 @@ __device__ __forceinline__ void first_level_run(ProbRef P, const int4 *tile_list
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = acc0[mi][r] + bias0;
-                wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = v > 0.0f ? v : v * slope0;
+                wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = lrelu(v, slope0);
             }
         }
         __syncthreads();                                     // gather tile free for the next pass; H0 rows visible
@@ -1316,7 +1324,7 @@ __device__ __forceinline__ void first_level_run(ProbRef P, const int4 *tile_list
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float v = acc1[0][r] + bias1;
-            wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = v > 0.0f ? v : v * slope1;
+            wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = lrelu(v, slope1);
         }
     }
     __syncthreads();
@@ -1367,7 +1375,7 @@ __device__ __forceinline__ void first_level_run(ProbRef P, const int4 *tile_list
         for (int r = 0; r < 16; ++r) {
             const int lr = (r & 3) + 8 * (r >> 2);
             float v = acc1[0][r] + bias2;
-            v = v > 0.0f ? v : v * slope2;
+            v = lrelu(v, slope2);
             wr[lr * PAIR_LD] = v + rs[3 * lr * PAIR_LD];
         }
         __syncthreads();
@@ -1453,9 +1461,14 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
         const_cast<float *>(P.w2 + ((size_t)wave_u * nk1) * 1024), 0, nk1 * 4096, 0x00020000);
     __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(P.w3 + ((size_t)wave_u * nk2) * 1024), 0, nk2 * 4096, 0x00020000);
-    const float bias0 = gload1(P.bias + wave * 32 + li), slope0 = P.slope;
-    const float bias1 = gload1(P.bias2 + wave * 32 + li), slope1 = P.slope2;
-    const float bias2 = gload1(P.bias3 + wave * 32 + li), slope2 = P.slope3;
+    const float slope0 = P.slope, slope1 = P.slope2, slope2 = P.slope3;
+    // a layer's bias (this lane's column), loaded where its accumulators are initialised: the opaque index keeps the
+    // loads from being hoisted out of the tile loop, where three more values would be live across every matrix phase
+    auto bias_at = [&](const float *b) {
+        int c = wave * 32 + li;
+        asm volatile("" : "+v"(c));
+        return gload1(b + c);
+    };
 
     // ---- gather state of the phase whose raw values are in flight / in registers
     struct Raw { f32x4 a[2]; };                              // the two K tiles of a 64-column chunk
@@ -1523,18 +1536,20 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
         (void)dbg;
 #endif
         R3D_TSTAMP(0);
-        f32x16 acc0[MI], acc1[MI];
+        f32x16 acc0[MI], acc1[MI];                           // (accumulators start at the layer's bias)
+        const float b1v = bias_at(P.bias2);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[mi][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc1[mi][r] = b1v;
 #pragma unroll 1
         for (int ts = 0; ts < 3; ++ts) {
             const int tap = tap_of(ts);
+            const float b0v = bias_at(P.bias);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc0[mi][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) acc0[mi][r] = b0v;
             // ---- expand_conv on the rows {3r + tap}, one 64-column chunk of the operand per phase
             auto chunk = [&](int ch, f32x4 (&ua)[4], f32x4 (&ub)[4], f32x4 (&la)[4], f32x4 (&lb)[4]) {
                 float *G = G0 + (phase & 1) * FLT_G_FLOATS;
@@ -1587,8 +1602,7 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
                 float *wr = H + (mi * 32 + 4 * lh) * PAIR_LD + wave * 32 + li;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float v = acc0[mi][r] + bias0;
-                    v = v > 0.0f ? v : v * slope0;
+                    const float v = lrelu(acc0[mi][r], slope0);
                     acc0[mi][r] = v;
                     wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = v;
                 }
@@ -1643,17 +1657,15 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
         for (int mi = 0; mi < MI; ++mi) {
             float *wr = H + (mi * 32 + 4 * lh) * PAIR_LD + wave * 32 + li;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = acc1[mi][r] + bias1;
-                wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = v > 0.0f ? v : v * slope1;
-            }
+            for (int r = 0; r < 16; ++r) wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = lrelu(acc1[mi][r], slope1);
         }
         __syncthreads();
         R3D_TSTAMP(2);
+        const float b2v = bias_at(P.bias3);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[mi][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc1[mi][r] = b2v;
         {
             const float *h_frag = H + li * PAIR_LD + lh * 16;
             const int last2 = nk2 - 1;
@@ -1696,11 +1708,7 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
         for (int mi = 0; mi < MI; ++mi) {
             float *wr = H + (mi * 32 + 4 * lh) * PAIR_LD + wave * 32 + li;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc1[mi][r] + bias2;
-                v = v > 0.0f ? v : v * slope2;
-                wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = v + acc0[mi][r];
-            }
+            for (int r = 0; r < 16; ++r) wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = lrelu(acc1[mi][r], slope2) + acc0[mi][r];
         }
         __syncthreads();
         {
@@ -1864,18 +1872,12 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
         (void)dbg;
 #endif
         R3D_TSTAMP(0);
-        f32x16 acc0[MI], acc1[MI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[mi][r] = 0.0f;
+        f32x16 acc0[MI], acc1[MI];                           // (accumulators start at the layer's bias)
+        b3t_init_bias<MI>(acc1, P.bias2, ch0);
 #pragma unroll 1
         for (int ts = 0; ts < 3; ++ts) {
             const int tap = tap_of(ts);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc0[mi][r] = 0.0f;
+ b3t_init_bias<MI>(acc0, P.bias, ch0);
             auto chunk = [&](int ch, const WFrag &ua, const WFrag &ub, WFrag &la, WFrag &lb) {
                 char *G = Gb + (phase & 1) * 3 * FLB_G_PLANE;
                 commit_phase(ch, G);
@@ -1906,7 +1908,7 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
             // ---- activations -> H planes (the residual tap's stay in acc0, fp32, for the epilogue)
             load_w(w1rsrc, tap * tiles_per_tap, wa);
             load_w(w1rsrc, tap * tiles_per_tap + (tiles_per_tap > 1 ? 1 : 0), wb);
-            b3t_activate_to_planes<MI>(acc0, P.bias, slope0, Hb, FLB_H_PLANE, li, ch0);
+            b3t_activate_to_planes<MI>(acc0, slope0, Hb, FLB_H_PLANE, li, ch0);
             __syncthreads();
             if (ts == 0) R3D_TSTAMP(6);
             // ---- this tap's third of the 3-tap convolution
@@ -1940,13 +1942,10 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
         load_w(w2rsrc, 0, wa);
         load_w(w2rsrc, nk2 > 1 ? 1 : 0, wb);
         __syncthreads();                                     // every wavefront is done reading the last tap's H
-        b3t_activate_to_planes<MI>(acc1, P.bias2, slope1, Hb, FLB_H_PLANE, li, ch0);
+        b3t_activate_to_planes<MI>(acc1, slope1, Hb, FLB_H_PLANE, li, ch0);
         __syncthreads();
         R3D_TSTAMP(2);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[mi][r] = 0.0f;
+        b3t_init_bias<MI>(acc1, P.bias3, ch0);
         {
             const int last2 = nk2 - 1;
             auto k_tile2 = [&](int kt, const WFrag &w_use, WFrag &w_load) {
@@ -1977,16 +1976,11 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
             float *S = smem;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 bq = gload4(P.bias3 + ch0 + 8 * q);
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float t = acc1[mi][4 * q + e] + bq[e];
-                        t = t > 0.0f ? t : t * slope2;
-                        v[e] = t + acc0[mi][4 * q + e];
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] = lrelu(acc1[mi][4 * q + e], slope2) + acc0[mi][4 * q + e];
                     *reinterpret_cast<f32x4 *>(S + (mi * 32 + li) * PAIR_LD + ch0 + 8 * q) = v;
                 }
             }
