@@ -266,7 +266,6 @@ struct SchedProb {
     int max_units;   // per-problem cap on 32-row units per tile (0 = the launch default)
     int nk2 = 0;     // K-loop iterations of the fused further layers, in 32-row units (cost only)
     int row0 = 0;    // first row this launch computes (a multiple of 32): rows [row0, M)
-    bool pair_split = false;   // cut every unit into two 128-column split-K pieces and run them as 64-row tiles (MI = 2, KS = 2)
 };
 void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units, std::vector<int4> &tiles,
                     std::vector<int> &wgoff, StageSchedule &out, bool enc = false);

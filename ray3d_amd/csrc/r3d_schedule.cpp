@@ -64,7 +64,6 @@ struct Seg {           // one column block of a problem
     int prob, col0, units, nk, cap, max_ks;
     double c1;
     int ncols;         // columns of the problem inside this block (<= 256)
-    bool pair_split = false;
 };
 
 struct Assignment {
@@ -95,7 +94,7 @@ bool assign(const std::vector<Seg> &segs, int nbins, double T, int ksplit, Assig
         if (s.c1 != cursor_cost) { cursor = 0; cursor_cost = s.c1; }
         const int spread = s.c1 == top_c1 && segs.back().c1 != top_c1 ? top_cap : 1 << 30;
         int u = 0;
-        if (s.c1 <= T && !s.pair_split) {
+        if (s.c1 <= T) {
             while (u < s.units) {
                 while (cursor < nbins && room[cursor] + 1e-6 < s.c1) ++cursor;
                 if (cursor == nbins) break;
@@ -117,7 +116,7 @@ bool assign(const std::vector<Seg> &segs, int nbins, double T, int ksplit, Assig
     cursor_cost = -1;
     for (const Left &l : left) {
         const Seg &s = *l.s;
-        int ks = s.pair_split ? 2 : std::min(ksplit, s.max_ks);
+        int ks = std::min(ksplit, s.max_ks);
         while (ks > 1 && s.nk / ks < 2) ks /= 2;              // keep at least two K-loop iterations
         if (ks == 1) return false;
         const double ck = unit_cycles((s.nk + ks - 1) / ks, ks);
@@ -164,7 +163,7 @@ void pack(const std::vector<SchedProb> &probs, int nbins_max, int max_units, Pac
         const double c1 = unit_cycles(p.nk + p.nk2, 1);
         for (int c0 = 0; c0 < p.N; c0 += 256) {
             segs.push_back({i, c0, units, p.nk, p.max_units > 0 ? std::min(p.max_units, max_units) : max_units, p.max_ks, c1,
-                            std::min(256, p.N - c0), p.pair_split && p.max_ks >= 2});
+                            std::min(256, p.N - c0)});
             total += units * c1;
             total_units += units;
         }
@@ -265,11 +264,6 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
             sp.max_ks = 1;
             sp.max_units = 4;
             sp.nk = (sp.nk * 2 + 2) / 3;
-        }
-        {   // experiment (R3D_MB_KS2=1): the M = B MLP layers as 64-row x 128-column split-K tiles - every weight fragment
-            // a wavefront loads then feeds two row blocks (a single-row-block tile is bound by its weight stream)
-            static const bool mb_ks2 = [] { const char *e = getenv("R3D_MB_KS2"); return e && atoi(e) != 0; }();
-            if (mb_ks2 && q.layer2 < 0 && q.enc_lut < 0 && !(L.bf3) && sp.max_ks >= 2 && M <= 1024 && M >= 64 && L.N >= 512) sp.pair_split = true;
         }
         if (q.layer3 >= 0) {                       // fused first level: one 32-row tile runs three layers (three input rows per row)
             const Model *mm = pl->m[q.model];

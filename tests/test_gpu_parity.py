@@ -777,3 +777,27 @@ def test_forward_captured_in_a_hip_graph_after_prepare():
     with torch.no_grad():
         eager = lifter(x, p)
     assert torch.equal(out, eager)
+
+
+@pytest.mark.parametrize("over", [dict(ARCHITECTURE="3"), dict(ARCHITECTURE="3,3,3", CHANNELS=512),
+                                  dict(ARCHITECTURE="3,3", DENSE=True, DISABLE_OPTIMIZATIONS=True)])
+def test_forward_uv_on_the_unfused_first_layer_kernel(over):
+    """UV mode where the first level is not fused (one-level architecture, C > 256, the dense ablation): the gathers of
+    r3d_gemm_enc_uv_f32 encode the rays; bit-identical to the rays mode, and equal to the oracle chain."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    cams, ocams, _, _ = _reference_cameras()
+    mc = ray3d_amd.default_model_config(**over)
+    pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    rf, B = cp.receptive_field, 45
+    uv = (1000.0 * synth.hash_uniform("uvenc%d" % rf, (B, rf, 17, 2), 5)).astype(np.float32)
+    pick = [i % len(cams) for i in range(B)]
+    rays = np.stack([ocams[c].rays_from_uv(uv[i].astype(np.float64)) for i, c in enumerate(pick)]).astype(np.float32)
+    rows, par = np.stack([cams[c].cam_row() for c in pick]), np.stack([cams[c].param() for c in pick])
+    with torch.no_grad():
+        a = lifter.forward_uv(torch.from_numpy(uv).cuda(), torch.from_numpy(rows).cuda(), torch.from_numpy(par).cuda())
+        b = lifter(torch.from_numpy(rays).cuda(), torch.from_numpy(par).cuda())
+    assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+    ref = _oracle_lift(((cp, sp), (ct, st)), rays, par)
+    assert np.abs(a.cpu().numpy() - ref).max() <= tol_for(ref)
