@@ -764,10 +764,10 @@ __device__ __forceinline__ void b3t_activate_to_planes(f32x16 (&acc)[MI], const 
 // on the bf16 matrix cores with D[channel][row] accumulators.  First layer: A from HBM as in gemm_tile_b3 (fp32 staged
 // through a three-stage LDS ring as three bf16 planes), weights fp32 in bf16-MFMA operand order split in registers.
 // Its activations go to three [32 MI x C] bf16 planes over the dead ring, the 1x1 convolution runs on them barrier-free,
-// and the epilogue stages fp32 rows over the planes: + residual, 1 KiB stores.  N <= 256 (one column tile), MI <= 2.
+// and the epilogue stages fp32 rows over the planes: + residual, 1 KiB stores.  N <= 256 (one column tile), MI <= 3 (three planes of 96 rows: 152 KB).
 template <int MI>
 __device__ __forceinline__ void gemm_tile_b3t(ProbRef P, const int row0, float *smem, long long *dbg) {
-    static_assert(MI >= 1 && MI <= 2, "the activation planes of a pair tile hold 64 rows");
+    static_assert(MI >= 1 && MI <= 3, "the activation planes of a pair tile hold 96 rows (152 KB)");
     R3D_TSTAMP(0);
     constexpr int VR = MI * 32, NA = (VR + 63) / 64;
     constexpr int PLANE = VR * B3_LD, SFB = 3 * PLANE;      // floats per ring plane / per ring stage
@@ -2088,8 +2088,9 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                 }
                 continue;
             }
-            if (P.wb3 != nullptr && P.w2 != nullptr) {   // a fused pair on the bf16 matrix cores (tiles of <= 64 rows)
-                if (mi >= 2) gemm_tile_b3t<2>(P, row0, smem, dbg);
+            if (P.wb3 != nullptr && P.w2 != nullptr) {   // a fused pair on the bf16 matrix cores (tiles of <= 96 rows)
+                if (mi >= 3) gemm_tile_b3t<3>(P, row0, smem, dbg);
+                else if (mi == 2) gemm_tile_b3t<2>(P, row0, smem, dbg);
                 else gemm_tile_b3t<1>(P, row0, smem, dbg);
                 continue;
             }

@@ -273,15 +273,18 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
             // tile is narrow enough to hold all rows, three otherwise; 5 / 12 iterations' time by the phase stamps:
             // 45.5 us for a body-part tile, 67.5 us for the trajectory model's at 2.1 GHz)
             sp.nk2 = 2 * sp.nk + mm->layers[q.layer2].Kpad / BK + mm->layers[q.layer3].Kpad / BK + (L.Kpad <= 64 ? 5 : 12);
-            if (L.bf3_conv && !first_level_v1()) {   // on the bf16 matrix cores: 192 us against 264 us for the launch at 256 windows
+            if (L.bf3_conv && !first_level_v1()) {
+                // on the bf16 matrix cores: 0.7x for every first-level unit.  (Separate factors from the phase stamps - a
+                // body-part unit 27.5 us against 41.5 in fp32, the trajectory model's 57 against 66 - schedule WORSE:
+                // 0.560 against 0.533 ms at 256 windows, 1.70 against 1.60 at 1024; the model's errors compensate.)
                 sp.nk2 = (sp.nk2 + sp.nk) * 7 / 10 - sp.nk;
             }
         } else if (q.layer2 >= 0) {                // fused pair: whole tiles of <= 128 rows, no split
             sp.max_ks = 1;
             sp.max_units = 4;
             sp.nk2 = pl->m[q.model]->layers[q.layer2].Kpad / BK;
-            if (L.bf3_conv && pl->m[q.model]->layers[q.layer2].bf3_conv && q.nseg == 1) {   // on the bf16 matrix cores: tiles of <= 64 rows,
-                sp.max_units = 2;                                                            // ~0.55x the time per unit (measured)
+            if (L.bf3_conv && pl->m[q.model]->layers[q.layer2].bf3_conv && q.nseg == 1) {   // on the bf16 matrix cores: tiles of <= 96 rows,
+                sp.max_units = 3;                                                            // ~0.55x the time per unit (measured)
                 sp.nk = (sp.nk * 5 + 8) / 9;
                 sp.nk2 = (sp.nk2 * 5 + 8) / 9;
             }
