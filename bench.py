@@ -47,10 +47,10 @@ ARCH = "3,3,3,3,3"
 EVAL_CLIPS = 240                # 2 subjects x 15 actions x 2 sub-actions x 4 cameras (cfg 3)
 
 
-def build(device, arch=ARCH):
+def build(device, arch=ARCH, bf16x3=False):
     import ray3d_amd
     from ray3d_amd import synth
-    mc = ray3d_amd.default_model_config(ARCHITECTURE=arch)
+    mc = ray3d_amd.default_model_config(ARCHITECTURE=arch, BF16X3=bf16x3)
     fac = ray3d_amd.Model(mc, {}, is_train=False)
     pos, trj = fac.get_pos_model(), fac.get_trj_model()
     states = {}
@@ -187,41 +187,36 @@ def roofline(lifter, x, p, step_ms, reps=5):
 
 
 def bf16x3_line(dev, states, x, p, out_f32, args, barrier, cfg):
-    """The windows workload again through a second pair of handles created with R3D_BF16X3=1."""
+    """The windows workload again through a second pair of handles created with r3d_config.bf16x3 = 1
+    (model_config['BF16X3'])."""
     import ray3d_amd
     from ray3d_amd import synth
-    old = os.environ.get("R3D_BF16X3")
-    os.environ["R3D_BF16X3"] = "1"
-    try:
-        lifter3, _ = build(dev)
-        with torch.no_grad():
-            lifter3.prepare([x.shape[0]], dev)
-            o3 = lifter3(x, p)
-            torch.cuda.synchronize()
-            el, dev_s, _ = timed_steps(lambda: lifter3(x, p), args.steps, args.warmup, barrier, dev)
-            res = {"dtype": "bf16x3 (fp32-equivalent: fp32 operands split exactly into three bf16 terms, six products, fp32 accumulate)",
-                   "value": round(x.shape[0] * args.steps / el, 1), "unit": "poses/s", "ms_per_step": round(el / args.steps * 1e3, 4),
-                   "max_abs_diff_vs_f32_path_m": float((o3 - out_f32).abs().max().item()),
-                   "fp32_equivalent_TFLOPs": None}
-            rl = roofline(lifter3, x, p, dev_s / args.steps * 1e3)
-            res["fp32_equivalent_TFLOPs"] = rl["achieved"]
-            res["frac_of_fp32_mfma_peak"] = rl["frac"]
-            res["frac_of_bf16x3_peak"] = round(rl["achieved"] / (2500.0 / 6.0), 4)     # 2.5 PFLOP/s dense bf16, six products per fp32 product
-            if x.shape[0] == BATCH and not args.no_b1024:
-                xb = torch.from_numpy(synth.synth_rays(1024, cfg, seed=100)).to(dev)
-                pb = torch.from_numpy(synth.synth_param(1024, seed=0, vary=False)).to(dev)
-                lifter3.prepare([1024], dev)
-                lifter3(xb, pb)
-                nb = max(args.steps // 2, 5)
-                elb, _, _ = timed_steps(lambda: lifter3(xb, pb), nb, max(args.warmup // 2, 2), barrier, dev)
-                res["b1024"] = {"value": round(1024 * nb / elb, 1), "ms_per_step": round(elb / nb * 1e3, 4)}
-        del lifter3
-        return res
-    finally:
-        if old is None:
-            os.environ.pop("R3D_BF16X3", None)
-        else:
-            os.environ["R3D_BF16X3"] = old
+    if os.environ.get("R3D_BF16X3") == "0":
+        return {"skipped": "R3D_BF16X3=0 in the environment overrides the configuration"}
+    lifter3, _ = build(dev, bf16x3=True)
+    with torch.no_grad():
+        lifter3.prepare([x.shape[0]], dev)
+        o3 = lifter3(x, p)
+        torch.cuda.synchronize()
+        el, dev_s, _ = timed_steps(lambda: lifter3(x, p), args.steps, args.warmup, barrier, dev)
+        res = {"dtype": "bf16x3 (fp32-equivalent: fp32 operands split exactly into three bf16 terms, six products, fp32 accumulate)",
+               "value": round(x.shape[0] * args.steps / el, 1), "unit": "poses/s", "ms_per_step": round(el / args.steps * 1e3, 4),
+               "max_abs_diff_vs_f32_path_m": float((o3 - out_f32).abs().max().item()),
+               "fp32_equivalent_TFLOPs": None}
+        rl = roofline(lifter3, x, p, dev_s / args.steps * 1e3)
+        res["fp32_equivalent_TFLOPs"] = rl["achieved"]
+        res["frac_of_fp32_mfma_peak"] = rl["frac"]
+        res["frac_of_bf16x3_peak"] = round(rl["achieved"] / (2500.0 / 6.0), 4)     # 2.5 PFLOP/s dense bf16, six products per fp32 product
+        if x.shape[0] == BATCH and not args.no_b1024:
+            xb = torch.from_numpy(synth.synth_rays(1024, cfg, seed=100)).to(dev)
+            pb = torch.from_numpy(synth.synth_param(1024, seed=0, vary=False)).to(dev)
+            lifter3.prepare([1024], dev)
+            lifter3(xb, pb)
+            nb = max(args.steps // 2, 5)
+            elb, _, _ = timed_steps(lambda: lifter3(xb, pb), nb, max(args.warmup // 2, 2), barrier, dev)
+            res["b1024"] = {"value": round(1024 * nb / elb, 1), "ms_per_step": round(elb / nb * 1e3, 4)}
+    del lifter3
+    return res
 
 
 def synthetic_eval_set(n_clips, seed=0):
@@ -360,7 +355,7 @@ def main():
                 line["roofline_b1024"] = rb
                 del xb, pb
             if world == 1 and not args.no_bf16x3:
-                # secondary line: the same workload with R3D_BF16X3=1 - every big GEMM on the bf16 matrix cores with exact
+                # secondary line: the same workload with r3d_config.bf16x3 = 1 - every big GEMM on the bf16 matrix cores with exact
                 # three-term splits of both operands (fp32-equivalent results: tests/test_gpu_parity.py holds it to the
                 # fp32 path's own error against a float64 reference).  Not the headline: `dtype` above stays f32.
                 line["bf16x3"] = bf16x3_line(dev, states, x, p, out, args, barrier, cfg)

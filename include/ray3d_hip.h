@@ -63,6 +63,12 @@ typedef struct {
                             * (cost grows with RF^2: meant for the short receptive fields the
                             * ablation is run at).  DENSE without DISABLE_OPTIMIZATIONS is
                             * ignored by the reference constructor (:54-55): pass 0.          */
+    int32_t bf16x3;        /* 0: fp32 matrix cores (v_mfma_f32_32x32x2_f32).  1: the large GEMMs on the
+                            * bf16 matrix cores with every fp32 operand split exactly into three bf16
+                            * terms (six products, fp32 accumulate): fp32-equivalent results - the same
+                            * error against a float64 evaluation - at 6/16 of the matrix time.  Not a
+                            * reference key.  The environment variable R3D_BF16X3=1 / =0 at r3d_create
+                            * overrides the field.                                                     */
 } r3d_config;
 
 typedef struct r3d_model r3d_model;

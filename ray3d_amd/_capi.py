@@ -29,7 +29,7 @@ METRIC_OUT_DOUBLES = 5 * (1 + 128)                                      # R3D_ME
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("kind", "num_joints", "in_features", "num_levels",
                                          "channels", "latent", "stage", "extrinsic_dim",
-                                         "embed_dim", "causal", "dense")]
+                                         "embed_dim", "causal", "dense", "bf16x3")]
 
 
 class Input(C.Structure):
@@ -102,7 +102,7 @@ class Handle:
                    cfg.in_features, len(cfg.filter_widths), cfg.channels, cfg.latent, cfg.stage,
                    cfg.extrinsic_dim if cfg.camera_embedding else 0,
                    cfg.embed_dim if cfg.camera_embedding else 0, 1 if cfg.causal else 0,
-                   1 if cfg.dense_convs else 0)
+                   1 if cfg.dense_convs else 0, 1 if getattr(cfg, "bf16x3", False) else 0)
         self.ptr = C.c_void_p()
         check(lib.r3d_create(C.byref(c), C.byref(self.ptr)), "r3d_create")
 

@@ -155,6 +155,7 @@ Model *model_create(const r3d_config &cfg) {
     if (cfg.kind == R3D_KIND_POS && cfg.stage < 1) { set_error("stage must be >= 1"); return nullptr; }
     if (cfg.causal != 0 && cfg.causal != 1) { set_error("causal must be 0 or 1 (got %d)", cfg.causal); return nullptr; }
     if (cfg.dense != 0 && cfg.dense != 1) { set_error("dense must be 0 or 1 (got %d)", cfg.dense); return nullptr; }
+    if (cfg.bf16x3 != 0 && cfg.bf16x3 != 1) { set_error("bf16x3 must be 0 or 1 (got %d)", cfg.bf16x3); return nullptr; }
     if (cfg.dense && cfg.num_levels > 4) { set_error("dense convolutions are evaluated at every position of a window: num_levels <= 4 (RF <= 81)"); return nullptr; }
 
     Model *m = new Model();
@@ -162,8 +163,8 @@ Model *model_create(const r3d_config &cfg) {
     m->id = next_id.fetch_add(1);
     m->cfg = cfg;
     {
-        const char *e = getenv("R3D_BF16X3");
-        m->use_b3 = e && atoi(e) != 0;
+        const char *e = getenv("R3D_BF16X3");          // overrides the configuration's field when set
+        m->use_b3 = e ? atoi(e) != 0 : cfg.bf16x3 != 0;
     }
     if (!emb) m->cfg.extrinsic_dim = m->cfg.embed_dim = 0;
     m->RF = 1;

@@ -67,6 +67,8 @@ class LiftConfig:
     causal: bool = False
     dense: bool = False
     optimize1f: bool = True         # not DISABLE_OPTIMIZATIONS
+    bf16x3: bool = False            # not a reference key: model_config.get('BF16X3') - the large GEMMs on the bf16 matrix
+                                    # cores through exact three-term splits (fp32-equivalent)
 
     def __post_init__(self):
         if self.kind not in ("pos", "trj"):
@@ -247,6 +249,7 @@ def config_from_dicts(model_config: dict, kind: str) -> LiftConfig:
         extrinsic_dim=ed, embed_dim=dd,
         causal=bool(model_config["CAUSAL"]), dense=bool(model_config["DENSE"]),
         optimize1f=not bool(model_config["DISABLE_OPTIMIZATIONS"]),
+        bf16x3=bool(model_config.get("BF16X3", False)),
     )
 
 

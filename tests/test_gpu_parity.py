@@ -543,6 +543,25 @@ def test_bf16x3_mode_keeps_parity(monkeypatch):
     assert np.abs(out - ref).max() <= tol_for(ref)
 
 
+def test_bf16x3_through_the_configuration_key():
+    """model_config['BF16X3'] -> r3d_config.bf16x3: the same mode without the environment variable; a reference fixture
+    at the fp32 tolerance, and outputs that differ from the fp32 path's (so the mode is really on)."""
+    import os
+    import ray3d_amd
+    if os.environ.get("R3D_BF16X3") is not None:
+        pytest.skip("R3D_BF16X3 in the environment overrides the configuration key")
+    z, mc = load_model_fixture("j17_rf27_s3")
+    x, p = torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["param"]).cuda()
+    outs = []
+    for flag in (False, True):
+        pos, trj, _, _ = build_modules(dict(mc, BF16X3=flag))
+        with torch.no_grad():
+            outs.append(ray3d_amd.Ray3DLifter(pos, trj).eval()(x, p).cpu().numpy())
+    want = z["out_pos"] + z["out_trj"]
+    assert np.abs(outs[0] - want).max() <= tol_for(want) and np.abs(outs[1] - want).max() <= tol_for(want)
+    assert not np.array_equal(outs[0], outs[1])
+
+
 def test_bf16x3_error_against_float64_is_the_fp32_paths(monkeypatch):
     """The claim behind "fp32-equivalent": measured against a FLOAT64 evaluation of the same network (the torch port run
     in double precision), the bf16x3 path's error is no larger than the fp32-MFMA path's - on the RF-243 network, whose

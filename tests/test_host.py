@@ -84,7 +84,7 @@ def test_create_rejects_unsupported_configs():
         _capi.Handle(config_from_dicts(default_model_config(ARCHITECTURE="3,3,3,3,3", DENSE=True, DISABLE_OPTIMIZATIONS=True), "pos"))
     assert config_from_dicts(default_model_config(DISABLE_OPTIMIZATIONS=True), "pos").residual_tap == 1
     assert config_from_dicts(default_model_config(DISABLE_OPTIMIZATIONS=True, CAUSAL=True), "trj").residual_tap == 2
-    bad = _capi.Config(0, 17, 3, 2, 256, 256, 3, 2, 64, 7, 0)
+    bad = _capi.Config(0, 17, 3, 2, 256, 256, 3, 2, 64, 7, 0, 0)
     with pytest.raises(_capi.Ray3DHipError, match="causal"):
         _capi.check(_capi.load().r3d_create(_capi.C.byref(bad), _capi.C.byref(_capi.C.c_void_p())), "r3d_create")
 
