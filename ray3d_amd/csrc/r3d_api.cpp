@@ -177,7 +177,6 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
                 g.enc_cur = (a->RF / a->cfg.in_features) * JF;   // quirk Q1: "current" frame is RF // in_features
                 g.enc_bytes = (unsigned)((size_t)frames * JF * sizeof(float));
                 g.res_tap = 1 + m->cfg.causal;
-                g.fl_v1 = first_level_v1() ? 1 : 0;
             }
             g.w = m->d_arena + L.w_off;
             if (L.bf3 && q.layer2 < 0 && q.enc_lut < 0)
@@ -205,7 +204,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             if (q.layer3 >= 0) {
                 const Layer &L3 = m->layers[q.layer3];
                 const Layer &L2b = m->layers[q.layer2];
-                if (L.bf3_conv && L2b.bf3_conv && L3.bf3_conv && !first_level_v1()) {   // first_level_taps_b3
+                if (L.bf3_conv && L2b.bf3_conv && L3.bf3_conv) {   // first_level_taps_b3
                     g.wb3 = m->d_arena + L.wb3_off;
                     g.w2b3 = m->d_arena + L2b.wb3_off;
                     g.w3b3 = m->d_arena + L3.wb3_off;

@@ -62,7 +62,7 @@ struct GemmProb {
     int enc_step;             // frames between consecutive operand rows of a window: 3 (stride-3 expand_conv), 1 (dense ablation)
     unsigned enc_bytes;       // size of the raw input in bytes (buffer-descriptor bound)
     int res_tap;              // fused first level: which frame of a triple is the residual (1 centre, 2 causal)
-    int fl_v1;                // fused first level: 1 = the row-major 32-row tiles (first_level_run), 0 = tap by tap
+    int pad2_;
     // --- UV input mode (cam != nullptr): x holds pixel keypoints (frames, J, 2), `lut` is the UV variant of the
     // tables (element byte offsets into that layout, the ray component 0/1/2 in the two low bits) and every gathered
     // value is encoded on its way into LDS with the camera row of the window its operand row belongs to:
@@ -278,7 +278,6 @@ const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t
                                                         std::vector<int> &wgoff, std::vector<StageSchedule> &stages);
 Schedule *schedule_get(Plan *pl, int64_t B, int nwg);   // nullptr + set_error on failure
 int device_cu_count();
-bool first_level_v1();
 
 // kernel launchers (r3d_kernels.hip)
 enum { STAGE_BIG = 0, STAGE_ENC = 1 };   // r3d_gemm_f32 / r3d_gemm_enc_f32

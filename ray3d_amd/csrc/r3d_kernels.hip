@@ -9,15 +9,15 @@
 //                                          BatchNorm folded; split-K variants for the small launches;
 //                        gemm_tile<PAIR>   a pyramid level's 3-tap and 1x1 convolutions (rie.py:94-97), the
 //                                          intermediate tile staying in LDS;
-//                        first_level_run   expand_conv on the gathered input (window gather,
+//                        first_level_taps  expand_conv on the gathered input (window gather,
 //                                          lib/train_val/trainer.py:47-58; body-part grouping and the
 //                                          positional / temporal differences of rie.py:290-357 folded into the
-//                                          weights) + the first pyramid level, for 32 output rows.
-//  r3d_gemm_enc_f32    fallback for configurations first_level_run does not cover (one-level architectures,
+//                                          weights) + the first pyramid level, tap by tap, for 32 / 64 output rows.
+//  r3d_gemm_enc_f32    fallback for configurations first_level_taps does not cover (one-level architectures,
 //                      more than 256 channels): expand_conv / GlobalInfo.fc_1 with the gather fused.
 //  r3d_decode_f32      last Linear of the decoders + joint reassembly (rie.py:409-432) + trajectory
 //                      add (lib/train_val/trainer.py:353).
-//  UV input mode (pixel keypoints + per-window camera rows) has no kernel of its own: the gathers of first_level_run
+//  UV input mode (pixel keypoints + per-window camera rows) has no kernel of its own: the gathers of first_level_taps
 //  and enc_tile encode each value they stage - ray = ((u-cx)/fx, c*y+s, -s*y+c), float64 like the reference's NumPy
 //  (lib/camera/camera.py:423-471) - with the camera of the window the operand row belongs to.
 #include <hip/hip_runtime.h>
@@ -1101,310 +1101,14 @@ __device__ __forceinline__ void enc_tile(ProbRef P, const int row0, const int co
     R3D_TSTAMP(4);
 }
 
-// ------------------------------------------------------------------------------------ first level in one tile
-//
-// first_level_run: expand_conv (on the gathered input), the level-1 3-tap convolution and its 1x1 convolution
-// for 32 output rows, without the 96 x C intermediate ever leaving the CU (lib/model/rie.py:85-97 up to the end of
-// the first loop iteration).  As separate launches the expand_conv output - the largest activation of the network,
-// 127 MB at B = 256 - was written by a launch that did little else than write it, and read back by the next.
-//   1. gather: the raw elements of the 96 expand_conv rows -> LDS (r3d_internal.hpp: one element per column),
-//      in passes of 96 or 32 rows (whatever operand tile fits next to the intermediate);
-//   2. expand_conv: MFMA loop per pass, activations -> H0 [96 x C] in MFMA operand order;
-//   3. the 3-tap convolution: output row r reads H0 rows 3r..3r+2 as one K = 3C operand row; barrier-free loop,
-//      weights streaming; activations -> H1 [32 x C];
-//   4. the 1x1 convolution on H1; epilogue: + H0 row 3r+1 (the centre tap: rie.py:94; 3r+2 for causal models,
-//      rie.py:92), rows stored 1 KiB wide.
-constexpr int FL_H0_FLOATS = 96 * PAIR_LD;                 // 24,960
-constexpr int FL_R2_FLOATS = 32 * PAIR_LD;                 //  8,320: gather tile / H1 / epilogue rows
-constexpr int FL_LUT_OFF = FL_H0_FLOATS + FL_R2_FLOATS;
-constexpr int FL_LUT_INTS = 320;                           // K0 + K0/4, K0 <= 256
-static_assert((FL_LUT_OFF + FL_LUT_INTS) * 4 <= GEMM_LDS_BYTES, "the fused first level fits the GEMM kernel's LDS allocation");
-
-// A workgroup's consecutive tiles of one problem are handled as a run: the raw values of the NEXT tile's first
-// gather pass are requested while this tile's 3-tap loop runs and wait in registers until the gather region is free
-// again (phase stamps: a body-part tile spent 9.8 us in the expand phase for 2.9 us of MFMA work, most of it the
-// latency of the scattered loads).
-template <int MI0, bool UV>   // expand_conv rows per pass / 32: 3 (K0 <= 64) or 1; UV input mode
-__device__ __forceinline__ void first_level_run(ProbRef P, const int4 *tile_list, const int ntiles, const bool new_prob, float *smem,
-                                                long long *dbg_base) {
-    constexpr int R0 = MI0 * 32, NA = (R0 + 63) / 64;
-    constexpr int NQ = MI0 == 3 ? 2 : 8;                     // K tiles of one gather pass (K0 <= 64 / K0 <= 256)
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int w_voff = lane * 16;
-    const int srow = tid >> 3, a_kq = (tid & 7) * 4;
-    const int K0 = P.K, nk0 = K0 / BK, ldt = K0 + 4;
-    const int M0 = 3 * P.M;                                  // expand_conv rows
-    float *h0 = smem, *r2 = smem + FL_H0_FLOATS;
-    int *lut_lds = reinterpret_cast<int *>(smem + FL_LUT_OFF);
-    const int *lut1 = lut_lds, *lutk = lut_lds + K0;
-    if (new_prob) {
-        for (int i = tid; i < K0 + K0 / 4; i += GEMM_THREADS) lut_lds[i] = *(const R3D_AS1 int *)(P.lut + i);
-    }
-    __syncthreads();                                         // (also: the previous tile is done with LDS)
-    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x), 0, P.enc_bytes, 0x00020000);
-    f32x4 rb[4], rbn[4], rbn2[4];
-    auto load_frag = [&](__amdgpu_buffer_rsrc_t rs, int kt, f32x4 (&dst)[4]) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            dst[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, w_voff + q * 1024, kt * 4096, 0));
-    };
-    // ---- 1 + 2: expand_conv, 96 rows in passes of R0
-    __amdgpu_buffer_rsrc_t w0rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(P.w + ((size_t)wave_u * nk0) * 1024), 0, nk0 * 4096, 0x00020000);
-    const float bias0 = gload1(P.bias + wave * 32 + li), slope0 = P.slope;
-    unsigned b_first[NA], b_cur[NA];
-    bool on[NA];
-    CamRow camr[UV ? NA : 1];                                // camera of each staged row's window (of the pass in gq)
-    auto row_bases = [&](int prow0) {                        // prow0: first expand_conv row of a pass
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int vr = srow + 64 * i;
-            on[i] = vr < R0;
-            const int gr = prow0 + vr;
-            const int row = gr < M0 ? gr : M0 - 1;
-            const int win = row / P.enc_rows, t3 = row - win * P.enc_rows;
-            const unsigned wbase = (unsigned)win * (unsigned)P.enc_ws;
-            b_first[i] = (wbase + (unsigned)(t3 * 3 * P.enc_jf)) * 4;
-            b_cur[i] = (wbase + (unsigned)P.enc_cur) * 4;
-            if constexpr (UV) camr[i] = load_cam_row(P.cam + (long long)win * P.cam_stride);
-        }
-    };
-    struct Raw { f32x4 a[NA]; };
-    auto issue = [&](int kt, Raw &r) {
-        const int k = kt * BK + a_kq;
-        const int4 o1 = *reinterpret_cast<const int4 *>(lut1 + k);
-        const bool cur = lutk[k >> 2] != 0;
-        const int c1[4] = {o1.x & ~3, o1.y & ~3, o1.z & ~3, o1.w & ~3};   // (UV tables: ray component in the low bits)
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            if (!on[i]) continue;
-            const unsigned b = cur ? b_cur[i] : b_first[i];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                r.a[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, b + (unsigned)c1[e], 0, 0));
-        }
-    };
-    auto commit = [&](int kt, const Raw &r) {
-        int4 code = make_int4(0, 0, 0, 0);
-        if constexpr (UV) code = *reinterpret_cast<const int4 *>(lut1 + kt * BK + a_kq);
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            if (!on[i]) continue;
-            f32x4 v = r.a[i];
-            if constexpr (UV) {
-                v[0] = uv_to_ray(v[0], code.x, camr[i]);
-                v[1] = uv_to_ray(v[1], code.y, camr[i]);
-                v[2] = uv_to_ray(v[2], code.z, camr[i]);
-                v[3] = uv_to_ray(v[3], code.w, camr[i]);
-            }
-            *reinterpret_cast<f32x4 *>(r2 + (srow + 64 * i) * ldt + kt * BK + a_kq) = v;
-        }
-    };
-    Raw gq[NQ];                                              // the first pass of the coming tile
-    auto issue_pass = [&](int prow0) {
-        row_bases(prow0);
-#pragma unroll
-        for (int kt = 0; kt < NQ; ++kt)
-            if (kt < nk0) issue(kt, gq[kt]);
-    };
-    issue_pass(3 * __builtin_amdgcn_readfirstlane(tile_list[0].y));
-#pragma unroll 1
-  for (int ti = 0; ti < ntiles; ++ti) {
-    const int row0 = __builtin_amdgcn_readfirstlane(tile_list[ti].y);
-    const int next_row0 = ti + 1 < ntiles ? __builtin_amdgcn_readfirstlane(tile_list[ti + 1].y) : -1;
-#ifdef R3D_TIMING
-    long long *dbg = dbg_base && ti < 8 ? dbg_base + ti * 8 : nullptr;
-#else
-    long long *dbg = nullptr;
-    (void)dbg;
-#endif
-    R3D_TSTAMP(0);
-#pragma unroll 1
-    for (int pass = 0; pass < 3 / MI0; ++pass) {
-        if (pass > 0 || ti == 0) {                           // (a later tile's first fragments were requested before
-            load_frag(w0rsrc, 0, rb);                        //  the previous tile's epilogue)
-            load_frag(w0rsrc, 1 < nk0 - 1 ? 1 : nk0 - 1, rbn);
-        }
-        // (this pass's raw values are in registers: requested one pass - or one tile - ago)
-#pragma unroll
-        for (int kt = 0; kt < NQ; ++kt)
-            if (kt < nk0) commit(kt, gq[kt]);
-        __syncthreads();
-        // the next pass's / the next tile's raw values: requested in front of this pass's matrix work, so that no
-        // weight load queues behind them for long (loads return in order); consumed once the gather region is free
-        if (pass + 1 < 3 / MI0) issue_pass(3 * row0 + (pass + 1) * R0);
-        else if (next_row0 >= 0) issue_pass(3 * next_row0);
-        f32x16 acc0[MI0];
-#pragma unroll
-        for (int mi = 0; mi < MI0; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc0[mi][r] = 0.0f;
-        const float *a_frag = r2 + li * ldt + lh * 16;
-        const int last0 = nk0 - 1;
-        auto k_tile0 = [&](int kt, f32x4 (&w_use)[4], f32x4 (&w_load)[4]) {
-            load_frag(w0rsrc, kt + 2 < last0 ? kt + 2 : last0, w_load);
-            const float *sp = a_frag + kt * BK;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 av[MI0];
-#pragma unroll
-                for (int mi = 0; mi < MI0; ++mi) av[mi] = *reinterpret_cast<const f32x4 *>(sp + mi * 32 * ldt + q * 4);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int mi = 0; mi < MI0; ++mi)
-                        acc0[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][kk], w_use[q][kk], acc0[mi], 0, 0, 0);
-            }
-        };
-        int kt = 0;
-        for (; kt + 2 < nk0; kt += 3) {
-            k_tile0(kt, rb, rbn2);
-            k_tile0(kt + 1, rbn, rb);
-            k_tile0(kt + 2, rbn2, rbn);
-        }
-        if (kt < nk0) {
-            k_tile0(kt, rb, rbn2);
-            if (kt + 1 < nk0) k_tile0(kt + 1, rbn, rb);
-        }
-        // activations -> H0 rows [pass * R0, +R0)
-#pragma unroll
-        for (int mi = 0; mi < MI0; ++mi) {
-            float *wr = h0 + (pass * R0 + mi * 32 + 4 * lh) * PAIR_LD + wave * 32 + li;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = acc0[mi][r] + bias0;
-                wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = lrelu(v, slope0);
-            }
-        }
-        __syncthreads();                                     // gather tile free for the next pass; H0 rows visible
-    }
-    R3D_TSTAMP(1);
-    // ---- 3: the 3-tap convolution, K = 3C: output row li reads H0 rows 3 li .. 3 li + 2
-    const int nk1 = P.K2 / BK, last1 = nk1 - 1, tiles_per_tap = nk1 / 3;
-    __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(P.w2 + ((size_t)wave_u * nk1) * 1024), 0, nk1 * 4096, 0x00020000);
-    f32x16 acc1[1];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[0][r] = 0.0f;
-    {
-        const float *h_frag = h0 + (3 * li) * PAIR_LD + lh * 16;
-        int tap = 0, kin = 0;                                // K tile kt = tap * tiles_per_tap + kin
-        auto k_tile1 = [&](int kt, f32x4 (&w_use)[4], f32x4 (&w_load)[4]) {
-            load_frag(w1rsrc, kt + 2 < last1 ? kt + 2 : last1, w_load);
-            const float *sp = h_frag + tap * PAIR_LD + kin * BK;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 av = *reinterpret_cast<const f32x4 *>(sp + q * 4);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], w_use[q][kk], acc1[0], 0, 0, 0);
-            }
-            if (++kin == tiles_per_tap) { kin = 0; ++tap; }
-        };
-        load_frag(w1rsrc, 0, rb);
-        load_frag(w1rsrc, 1 < last1 ? 1 : last1, rbn);
-        int kt = 0;
-        for (; kt + 2 < nk1; kt += 3) {
-            k_tile1(kt, rb, rbn2);
-            k_tile1(kt + 1, rbn, rb);
-            k_tile1(kt + 2, rbn2, rbn);
-        }
-        if (kt < nk1) {
-            k_tile1(kt, rb, rbn2);
-            if (kt + 1 < nk1) k_tile1(kt + 1, rbn, rb);
-        }
-    }
-    // activations -> H1 (the gather tile's place)
-    {
-        const float bias1 = gload1(P.bias2 + wave * 32 + li), slope1 = P.slope2;
-        float *wr = r2 + (4 * lh) * PAIR_LD + wave * 32 + li;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float v = acc1[0][r] + bias1;
-            wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = lrelu(v, slope1);
-        }
-    }
-    __syncthreads();
-    R3D_TSTAMP(2);
-    // ---- 4: the 1x1 convolution on H1
-    const int nk2 = P.K3 / BK, last2 = nk2 - 1;
-    __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(P.w3 + ((size_t)wave_u * nk2) * 1024), 0, nk2 * 4096, 0x00020000);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[0][r] = 0.0f;
-    {
-        const float *h_frag = r2 + li * PAIR_LD + lh * 16;
-        auto k_tile2 = [&](int kt, f32x4 (&w_use)[4], f32x4 (&w_load)[4]) {
-            load_frag(w2rsrc, kt + 2 < last2 ? kt + 2 : last2, w_load);
-            const float *sp = h_frag + kt * BK;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 av = *reinterpret_cast<const f32x4 *>(sp + q * 4);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], w_use[q][kk], acc1[0], 0, 0, 0);
-            }
-        };
-        load_frag(w2rsrc, 0, rb);
-        load_frag(w2rsrc, 1 < last2 ? 1 : last2, rbn);
-        int kt = 0;
-        for (; kt + 2 < nk2; kt += 3) {
-            k_tile2(kt, rb, rbn2);
-            k_tile2(kt + 1, rbn, rb);
-            k_tile2(kt + 2, rbn2, rbn);
-        }
-        if (kt < nk2) {
-            k_tile2(kt, rb, rbn2);
-            if (kt + 1 < nk2) k_tile2(kt + 1, rbn, rb);
-        }
-    }
-    R3D_TSTAMP(3);
-    if (next_row0 >= 0) {
-        load_frag(w0rsrc, 0, rb);
-        load_frag(w0rsrc, 1 < nk0 - 1 ? 1 : nk0 - 1, rbn);
-    }
-    // ---- epilogue: + centre (causal: last) expand_conv row (still in H0), rows transposed through the second region
-    {
-        const float bias2 = gload1(P.bias3 + wave * 32 + li), slope2 = P.slope3;
-        __syncthreads();                                     // every wavefront is done reading H1
-        float *wr = r2 + (4 * lh) * PAIR_LD + wave * 32 + li;
-        const float *rs = h0 + (3 * (4 * lh) + P.res_tap) * PAIR_LD + wave * 32 + li;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int lr = (r & 3) + 8 * (r >> 2);
-            float v = acc1[0][r] + bias2;
-            v = lrelu(v, slope2);
-            wr[lr * PAIR_LD] = v + rs[3 * lr * PAIR_LD];
-        }
-        __syncthreads();
-        const int rd_row = tid >> 6, rd_c4 = (tid & 63) * 4;
-        const int N = P.N, M = P.M;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int lr = rd_row + 8 * j, row = row0 + lr;
-            if (row >= M) continue;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(r2 + lr * PAIR_LD + rd_c4);
-            if (rd_c4 + 4 <= N) {
-                __builtin_nontemporal_store(v, (R3D_AS1 f32x4 *)(P.c + (size_t)row * P.ldc + rd_c4));
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (rd_c4 + e < N) gstore1(P.c + (size_t)row * P.ldc + rd_c4 + e, v[e]);
-            }
-        }
-        __syncthreads();
-    }
-    R3D_TSTAMP(4);
-  }
-}
-
+constexpr int FL_LUT_INTS = 320;                           // first-layer tables in LDS: K0 + K0/4 ints, K0 <= 256
 
 // ------------------------------------------------------------------------------------ first level, tap by tap
 //
-// first_level_taps: the same three layers for 32 * MI output rows (MI = 1, 2), organised around the taps of the 3-tap
-// convolution instead of around the 96 expand_conv rows of a 32-row tile.  Output row r of the level reads the
+// first_level_taps: expand_conv (on the gathered input), the level-1 3-tap convolution and its 1x1 convolution
+// (lib/model/rie.py:85-97 up to the end of the first loop iteration) for 32 * MI output rows (MI = 1, 2), without the
+// expand_conv output - the largest activation of the network, 127 MB at 256 windows - ever leaving the CU.  The tile is
+// organised around the taps of the 3-tap convolution (round 1's form held the 96 expand_conv rows of a 32-row tile at once).  Output row r of the level reads the
 // expand_conv rows 3r, 3r+1, 3r+2 - one per tap - so the tile walks the taps: gather the raw elements of the rows
 // {3r + tap}, run expand_conv on them (activations -> H, one [32 MI x C] buffer in MFMA operand order), multiply H
 // with the tap's third of the 3-tap weights into the level's accumulators, next tap.  Only ONE tap's activations
@@ -2059,10 +1763,7 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
 #else
                 long long *run_dbg = nullptr;
 #endif
-                if (P.fl_v1) {           // the row-major form (one 32-row tile at a time), kept for A/B runs: R3D_FL_V1=1
-                    if (P.K <= 64) first_level_run<3, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
-                    else first_level_run<1, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
-                } else if (P.wb3 != nullptr) {   // fp32 on the bf16 matrix cores
+                if (P.wb3 != nullptr) {   // fp32 on the bf16 matrix cores
                     if (P.K <= 64) {
                         if (mi >= 2) first_level_taps_b3<2, false, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
                         else first_level_taps_b3<1, false, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);

@@ -191,7 +191,7 @@ static Plan *build_plan(const Model *a, const Model *b) {
         const Model *m = pl->m[mi];
         if (!m) continue;
         Builder B{*pl, mi, *m};
-        // the first pyramid level runs fused (r3d_kernels.hip, first_level_run) when a tile can hold it: at least two
+        // the first pyramid level runs fused (r3d_kernels.hip, first_level_taps) when a tile can hold it: at least two
         // levels, all channels in one 256-column tile, first-layer operand tile next to the intermediate
         {
             int k0max = 0;

@@ -30,11 +30,6 @@ Plan::~Plan() {
     for (auto &kv : schedules) delete kv.second;
 }
 
-bool first_level_v1() {      // R3D_FL_V1=1: the row-major 32-row first-level tiles (A/B runs against first_level_taps)
-    static const bool v1 = [] { const char *e = getenv("R3D_FL_V1"); return e && atoi(e) != 0; }();
-    return v1;
-}
-
 int device_cu_count() {
     static int cus[64] = {0};
     int dev = 0;
@@ -268,12 +263,12 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
         if (q.layer3 >= 0) {                       // fused first level: one 32-row tile runs three layers (three input rows per row)
             const Model *mm = pl->m[q.model];
             sp.max_ks = 1;
-            sp.max_units = first_level_v1() ? 1 : 2;   // tap by tap, a tile holds 64 output rows (r3d_kernels.hip, first_level_taps)
+            sp.max_units = 2;                          // tap by tap, a tile holds 64 output rows (r3d_kernels.hip, first_level_taps)
             // (+ the gather passes over the tile's 96 first-layer rows and the phase changes: one pass when the operand
             // tile is narrow enough to hold all rows, three otherwise; 5 / 12 iterations' time by the phase stamps:
             // 45.5 us for a body-part tile, 67.5 us for the trajectory model's at 2.1 GHz)
             sp.nk2 = 2 * sp.nk + mm->layers[q.layer2].Kpad / BK + mm->layers[q.layer3].Kpad / BK + (L.Kpad <= 64 ? 5 : 12);
-            if (L.bf3_conv && !first_level_v1()) {
+            if (L.bf3_conv) {
                 // on the bf16 matrix cores: 0.7x for every first-level unit.  (Separate factors from the phase stamps - a
                 // body-part unit 27.5 us against 41.5 in fp32, the trajectory model's 57 against 66 - schedule WORSE:
                 // 0.560 against 0.533 ms at 256 windows, 1.70 against 1.60 at 1024; the model's errors compensate.)
