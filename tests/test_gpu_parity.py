@@ -820,3 +820,42 @@ def test_forward_uv_on_the_unfused_first_layer_kernel(over):
     assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
     ref = _oracle_lift(((cp, sp), (ct, st)), rays, par)
     assert np.abs(a.cpu().numpy() - ref).max() <= tol_for(ref)
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_configurations_match_the_oracle_chain(seed):
+    """Seeded random configurations over everything the reference's factory reads (joints, input dimension, depth,
+    channels, latent size, stage, camera embedding, dilated / causal / dense geometry), random batch sizes, both
+    precisions: HIP path vs the torch port of the reference graph on every window."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    rng = np.random.default_rng(1000 + seed)
+    levels = int(rng.integers(1, 5))
+    over = dict(ARCHITECTURE=",".join(["3"] * levels), NUM_KPTS=int(rng.choice([14, 15, 17])),
+                INPUT_DIM=int(rng.choice([2, 3])), CHANNELS=int(rng.choice([64, 96, 128, 256, 256, 384])),
+                LATENT_FEATURES_DIM=int(rng.choice([64, 128, 256])), STAGE=int(rng.choice([1, 2, 3])),
+                CAMERA_EMBDDING=bool(rng.integers(0, 2)), EMBEDD_DIM=int(rng.choice([32, 64])),
+                BF16X3=bool(rng.integers(0, 2)))
+    geom = int(rng.integers(0, 4))                  # strided | dilated | dilated + causal | dense (short receptive fields)
+    if geom >= 1:
+        over["DISABLE_OPTIMIZATIONS"] = True
+    if geom == 2:
+        over["CAUSAL"] = True
+    if geom == 3 and levels <= 3:
+        over["DENSE"] = True
+    mc = ray3d_amd.default_model_config(**over)
+    pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    B = int(rng.choice([1, 7, 33, 100, 257]))
+    x = synth.synth_rays(B, cp, seed=seed)
+    p = synth.synth_param(B, seed=seed + 1)
+    pt = torch.from_numpy(p).cuda() if cp.camera_embedding else None
+    with torch.no_grad():
+        out = lifter(torch.from_numpy(x).cuda(), pt).cpu().numpy()
+    from oracle import torch_port
+    sds = [{k: torch.from_numpy(np.asarray(v)) for k, v in s_.items()} for s_ in (sp, st)]
+    with torch.no_grad():
+        pp = torch.from_numpy(p) if cp.camera_embedding else None
+        ref = (torch_port.forward(cp, sds[0], torch.from_numpy(x), pp) + torch_port.forward(ct, sds[1], torch.from_numpy(x), pp)).numpy()
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= tol_for(ref), (over, B, np.abs(out - ref).max())
