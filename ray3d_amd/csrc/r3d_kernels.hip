@@ -1,7 +1,8 @@
 // gfx950 (MI355X, CDNA4) kernels of the lifting forward pass.  Written for 64-lane wavefronts and
 // the fp32-input matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD, 157 TFLOP/s
 // chip peak) - the path is compute-bound, and the 1e-4 parity budget rules out
-// plain bf16 (tools/bf16x3_probe.cpp measures the three-term alternative).
+// plain bf16.  Opt-in (r3d_config.bf16x3): the same fp32 results on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16)
+// through exact three-term splits of both operands - the *_b3 tile kinds below.
 //
 //  r3d_gemm_f32        persistent grouped GEMM, one launch per level of the plan's DAG.  Tile kinds:
 //                        gemm_tile         C = res + lrelu(A W^T + b): every Conv1d / Linear of TemporalBlock /
@@ -12,9 +13,14 @@
 //                        first_level_taps  expand_conv on the gathered input (window gather,
 //                                          lib/train_val/trainer.py:47-58; body-part grouping and the
 //                                          positional / temporal differences of rie.py:290-357 folded into the
-//                                          weights) + the first pyramid level, tap by tap, for 32 / 64 output rows.
+//                                          weights) + the first pyramid level, tap by tap, for 32 / 64 output rows;
+//                        enc_tile          GlobalInfo's input (the windows' current frames) gathered the same way;
+//                        gemm_tile_b3, gemm_tile_b3t, first_level_taps_b3
+//                                          the 1024-wide Linears, the fused pairs and the first level on the bf16 matrix cores.
 //  r3d_gemm_enc_f32    fallback for configurations first_level_taps does not cover (one-level architectures,
-//                      more than 256 channels): expand_conv / GlobalInfo.fc_1 with the gather fused.
+//                      more than 256 channels, the dense ablation): expand_conv / GlobalInfo.fc_1 with the gather fused.
+//  r3d_gemm_uv_f32, r3d_gemm_enc_uv_f32
+//                      the same two kernels for launches that gather pixel keypoints (UV input mode).
 //  r3d_decode_f32      last Linear of the decoders + joint reassembly (rie.py:409-432) + trajectory
 //                      add (lib/train_val/trainer.py:353).
 //  UV input mode (pixel keypoints + per-window camera rows) has no kernel of its own: the gathers of first_level_taps
