@@ -249,6 +249,17 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             fprintf(stderr, "[timing] launch %zu: first workgroup start -> last end %.2f us; starts spread over %.2f us, ends over %.2f us; "
                     "wg 0: start -> first tile entry %.2f us\n", si, (w1 - w0) / 100.0, (s1 - w0) / 100.0, (w1 - e0) / 100.0,
                     (ht[0] - hw[2]) / 100.0);
+            {   // distribution of the workgroups' busy times (start -> end of the persistent loop)
+                std::vector<double> d;
+                for (int w = 0; w < ss.nwg && w < 1024; ++w) d.push_back((hw[w * 4 + 3] - hw[w * 4 + 2]) / 100.0);
+                std::sort(d.begin(), d.end());
+                if (!d.empty())
+                    fprintf(stderr, "[timing] launch %zu: workgroup busy time min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f us (%zu workgroups)\n", si,
+                            d.front(), d[d.size() / 10], d[d.size() / 2], d[d.size() * 9 / 10], d.back(), d.size());
+                if (getenv("R3D_TIMING_ALL"))
+                    for (int w = 0; w < ss.nwg && w < 1024; ++w)
+                        fprintf(stderr, "[timing-wg] %d start %.2f end %.2f\n", w, (hw[w * 4 + 2] - w0) / 100.0, (hw[w * 4 + 3] - w0) / 100.0);
+            }
             fprintf(stderr, "[timing] launch %zu: wg tile | phase lengths in us (100 MHz wall clock)\n", si);
             for (int w = 0; w < 16 && w < ss.nwg; ++w)
                 for (int t = 0; t < 8; ++t) {

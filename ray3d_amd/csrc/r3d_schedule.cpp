@@ -224,6 +224,17 @@ void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units,
         ++grid;
     }
     if (grid == 0) { wgoff.push_back(0); grid = 1; }
+    if (const char *e = getenv("R3D_SCHED_DUMP")) {   // development aid: the chunks of every launch, one line per workgroup
+        (void)e;
+        for (int b = 0; b < grid; ++b) {
+            fprintf(stderr, "[sched] chunk %3d:", b);
+            for (int t = wgoff[out.wgoff_off + b]; t < wgoff[out.wgoff_off + b + 1]; ++t) {
+                const int4 &tl = tiles[t0 + t];
+                fprintf(stderr, " p%d/mi%d/r%d/c%d/ks%d", tl.x & 0xff, tl.x >> 8, tl.y, tl.z, tl.w);
+            }
+            fprintf(stderr, "\n");
+        }
+    }
     out.nwg = grid;
     out.ntiles = (int)(tiles.size() - t0);
     out.imbalance = best->a.worst / std::max(best->total / grid, 1.0);
@@ -259,6 +270,13 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
             sp.max_ks = 1;
             sp.max_units = 4;
             sp.nk = (sp.nk * 2 + 2) / 3;
+        }
+        if (q.enc_lut >= 0 && q.layer3 < 0) {
+            // a gathered operand without the fused level (GlobalInfo's current frames in the first-level launch): table load,
+            // scattered gather and a three-slab epilogue around two K tiles - 4-5 us per unit by the workgroups' busy times,
+            // not the 3.3 us of a plain two-iteration unit.  Under-priced, a dozen workgroups collected all of them on top
+            // of five first-level units and ended 15-25 us after the rest of the launch.
+            sp.nk2 = 2;
         }
         if (q.layer3 >= 0) {                       // fused first level: one 32-row tile runs three layers (three input rows per row)
             const Model *mm = pl->m[q.model];
