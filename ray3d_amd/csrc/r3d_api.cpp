@@ -226,7 +226,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         // development build only (tools/build_probe.sh): phase stamps of the first tiles of launch $R3D_TIMING_STAGE
         static long long *timing_buf = nullptr;
         const char *tstage = getenv("R3D_TIMING_STAGE");
-        const bool timed = tstage && atoi(tstage) == (int)si;
+        const bool timed = tstage && (!strcmp(tstage, "all") || atoi(tstage) == (int)si);
         if (timed) {
             if (!timing_buf) (void)hipMalloc((void **)&timing_buf, (1024 + 4 * 1024) * 8 + 65536);
             (void)hipMemsetAsync(timing_buf, 0, (1024 + 4 * 1024) * 8 + 65536, stream);

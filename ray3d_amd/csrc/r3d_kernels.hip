@@ -1587,7 +1587,7 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
 #pragma unroll 1
         for (int ts = 0; ts < 3; ++ts) {
             const int tap = tap_of(ts);
- b3t_init_bias<MI>(acc0, P.bias, ch0);
+            b3t_init_bias<MI>(acc0, P.bias, ch0);
             auto chunk = [&](int ch, const WFrag &ua, const WFrag &ub, WFrag &la, WFrag &lb) {
                 char *G = Gb + (phase & 1) * 3 * FLB_G_PLANE;
                 commit_phase(ch, G);

@@ -49,7 +49,12 @@ namespace {
 // split-K piece (one unit per tile) pays 1.5 us of prologue latency, 0.4 us of reduction, 0.8 us of
 // epilogue and 0.4 us between tiles, and 1.17 us per iteration; units of the wide tiles share one
 // prologue and run at 1.0 us per iteration.
-double unit_cycles(int iters, int ks) { return ks > 1 ? iters * 2600.0 + 6800.0 : iters * 2200.0 + 2500.0; }
+// Units of one to three iterations (the camera-embedding layers, K = 2 / 32) are all prologue and epilogue: 4 us per
+// unit by the workgroups' busy times (-DR3D_TIMING, R3D_TIMING_ALL), whatever the tile height.
+double unit_cycles(int iters, int ks) {
+    if (ks > 1) return iters * 2600.0 + 6800.0;
+    return iters * 2200.0 + 2500.0 + (iters < 4 ? (4 - iters) * 1400.0 : 0.0);
+}
 
 struct Run {           // `n` consecutive row units of one column block, all in one workgroup's chunk
     int prob, col0, ks, u0, n, cap;
@@ -89,7 +94,23 @@ bool assign(const std::vector<Seg> &segs, int nbins, double T, int ksplit, Assig
         if (s.c1 != cursor_cost) { cursor = 0; cursor_cost = s.c1; }
         const int spread = s.c1 == top_c1 && segs.back().c1 != top_c1 ? top_cap : 1 << 30;
         int u = 0;
-        if (s.c1 <= T) {
+        if (s.c1 * 6.0 <= T && s.c1 != top_c1) {
+            // fillers (units far below the budget: the camera embedding, GlobalInfo's gathered first layer) go two at a
+            // time to the workgroup with the most room left, not to the first one they fit: their modelled cost is the
+            // least certain, and first-fit stacked a dozen of them on ONE full workgroup that then ended 20 us after the
+            // rest of the launch while others idled (fp32 first-level launch: 249 against 228 us; bf16x3 second launch:
+            // 57 against 48 us)
+            while (u < s.units) {
+                int best = 0;
+                for (int b = 1; b < nbins; ++b)
+                    if (room[b] > room[best]) best = b;
+                if (room[best] + 1e-6 < s.c1) break;
+                const int take = std::min(std::min(2, (int)std::floor((room[best] + 1e-6) / s.c1)), s.units - u);
+                room[best] -= take * s.c1;
+                if (out) out->bins[best].push_back({s.prob, s.col0, 1, u, take, s.cap});
+                u += take;
+            }
+        } else if (s.c1 <= T) {
             while (u < s.units) {
                 while (cursor < nbins && room[cursor] + 1e-6 < s.c1) ++cursor;
                 if (cursor == nbins) break;
@@ -226,6 +247,11 @@ void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units,
     if (grid == 0) { wgoff.push_back(0); grid = 1; }
     if (const char *e = getenv("R3D_SCHED_DUMP")) {   // development aid: the chunks of every launch, one line per workgroup
         (void)e;
+        fprintf(stderr, "[sched] launch of %zu problems: budget %.0f cycles, ideal %.0f, split-K %d\n", probs.size(), best->T,
+                best->total / std::max(grid, 1), best->ks);
+        for (size_t i = 0; i < probs.size(); ++i)
+            fprintf(stderr, "[sched]   p%zu: M %d row0 %d N %d nk %d nk2 %d max_ks %d max_units %d unit %.0f cycles\n", i, probs[i].M, probs[i].row0,
+                    probs[i].N, probs[i].nk, probs[i].nk2, probs[i].max_ks, probs[i].max_units, unit_cycles(probs[i].nk + probs[i].nk2, 1));
         for (int b = 0; b < grid; ++b) {
             fprintf(stderr, "[sched] chunk %3d:", b);
             for (int t = wgoff[out.wgoff_off + b]; t < wgoff[out.wgoff_off + b + 1]; ++t) {
