@@ -114,6 +114,11 @@ struct TensorSpec {
 };
 
 // One GEMM layer = Conv1d(k3,s3) / Conv1d(k1) / Linear, optionally followed by eval BatchNorm.
+inline bool env_on(const char *name) {      // set and not "0" (development switches)
+    const char *e = getenv(name);
+    return e && atoi(e) != 0;
+}
+
 struct Layer {
     std::string weight_key;   // "<prefix>.weight"
     std::string bias_key;     // "" when the layer has no bias
@@ -129,6 +134,13 @@ struct Layer {
     bool bf3 = false;         // also packed in bf16-MFMA operand order for gemm_tile_b3 (the FCBlocks' 1024-wide Linears)
     bool bf3_conv = false;    // ... and the three layers of a fused first level (first_level_taps_b3)
     size_t wb3_off = 0;       // offset (floats) of that copy in the arena: Npad * Kpad floats
+    // Linear layers that read a TemporalBlock's `shrink` output take the block's last activations instead: shrink is a
+    // 1x1 convolution with bias and NO activation (rie.py:105), so W (S h + s) = (W S) h + W s is folded into the
+    // consumer's weights at r3d_finalize (in double) and the shrink launch disappears.  One entry per folded input range:
+    // reference columns [ref_col0, ref_col0 + ref_width) become new_width columns of layer `shrink_layer`'s input.
+    struct Pre { int ref_col0, ref_width, new_width, shrink_layer; };
+    std::vector<Pre> pre;
+    int cin_ref = 0;          // input width of the reference layer (== cin unless `pre` is used)
 };
 
 struct Model {
@@ -152,6 +164,7 @@ struct Model {
     size_t global_lut_off = 0;        // LUT of GlobalInfo.fc_1's input (the current frame)
     size_t global_lut_uv_off = 0;
     bool use_b3 = false;              // opt-in (R3D_BF16X3=1 at r3d_create): M = B layers on the bf16 matrix cores
+    bool fold_shrink = false;         // the TemporalBlocks' shrink folded into its consumers (Layer::pre)
     std::vector<float> arena;         // packed floats (host mirror)
     std::vector<int> iarena;          // LUTs
     float *d_arena = nullptr;
@@ -216,7 +229,7 @@ struct StageSchedule {
 struct Schedule {
     int64_t B = 0;
     int spill_row0 = -1;   // rows [spill_row0, M) of Plan::spill_prob run in the following launch; -1: the plain
-                           // level assignment (Plan::stages) is in use, else Plan::stages_spill
+                           // level assignment (Plan::stages / stages_alt) is in use, else Plan::stages_spill / _alt
     const std::vector<std::vector<int>> *levels = nullptr;   // the assignment this schedule was built for
     std::vector<StageSchedule> stages;
     int4 *d_tiles = nullptr;
@@ -234,6 +247,10 @@ struct Plan {
     // nearly empty extra round of tiles.  Whether it is used, and how many rows move, is decided per batch size in
     // schedule_get (Schedule::spill_row0).  Empty when the plan has no such problem.
     std::vector<std::vector<int>> stages_spill;
+    // the spill assignment with the problem that reads the spilled one kept right behind it (instead of as late as its
+    // users allow); empty when that gives the same assignment.  schedule_get models all of them per batch size and
+    // keeps the shortest.
+    std::vector<std::vector<int>> stages_spill_alt;
     int spill_prob = -1;
     int64_t floats_per_window = 0;
     int64_t tail_floats = 0;     // slack behind the last buffer (the dense ablation's overlapping operand rows read past a window's end)

@@ -62,8 +62,11 @@ struct Grammar {
         tensor(p + ".running_var", {c});
     }
     int layer(const std::string &prefix, int taps, int cin, int n, bool bias, const std::string &bn_prefix,
-              float slope, bool conv) {
+              float slope, bool conv, const std::vector<Layer::Pre> &pre = {}) {
         Layer L;
+        L.pre = pre;
+        L.cin_ref = cin;
+        for (const auto &r : pre) cin += r.new_width - r.ref_width;
         L.weight_key = prefix + ".weight";
         L.bias_key = bias ? prefix + ".bias" : "";
         L.bn_prefix = bn_prefix;
@@ -79,7 +82,7 @@ struct Grammar {
         if (conv)
             tensor(L.weight_key, {n, cin, taps});
         else
-            tensor(L.weight_key, {n, cin});
+            tensor(L.weight_key, {n, L.cin_ref});
         if (bias) tensor(L.bias_key, {n});
         if (!bn_prefix.empty()) bn(bn_prefix, n);
         // the FCBlocks' wide Linears can also run on the bf16 matrix cores (three-term split, r3d_kernels.hip)
@@ -108,8 +111,8 @@ struct Grammar {
         layer(p + ".shrink", 1, C, m->cfg.latent, true, "", 1.0f, true);
     }
     // FCBlock, lib/model/rie.py:138-157
-    void fc_block(const std::string &p, int cin, int cout, int nblocks) {
-        layer(p + ".fc_1", 1, cin, MLP_HIDDEN, true, p + ".bn_1", 0.2f, false);
+    void fc_block(const std::string &p, int cin, int cout, int nblocks, const std::vector<Layer::Pre> &pre = {}) {
+        layer(p + ".fc_1", 1, cin, MLP_HIDDEN, true, p + ".bn_1", 0.2f, false, pre);
         for (int n = 0; n < nblocks; ++n) {
             const std::string q = p + ".layers." + std::to_string(n);
             layer(q + ".w1", 1, MLP_HIDDEN, MLP_HIDDEN, true, q + ".batch_norm1", 0.2f, false);
@@ -166,6 +169,8 @@ Model *model_create(const r3d_config &cfg) {
         const char *e = getenv("R3D_BF16X3");          // overrides the configuration's field when set
         m->use_b3 = e ? atoi(e) != 0 : cfg.bf16x3 != 0;
     }
+    // shrink folds into the Linears that read it when that does not widen them (Layer::pre)
+    m->fold_shrink = cfg.channels <= cfg.latent && !env_on("R3D_NO_SHRINK_FOLD");
     if (!emb) m->cfg.extrinsic_dim = m->cfg.embed_dim = 0;
     m->RF = 1;
     for (int i = 0; i < cfg.num_levels; ++i) m->RF *= 3;
@@ -184,12 +189,23 @@ Model *model_create(const r3d_config &cfg) {
             g.temporal_block(br.prefix, br.cin);
         }
         g.fc_block("GlobalInfo", J * F, lat, 2);
+        auto shrink_of = [&](int b) { return m->layer_index.at(m->branches[b].prefix + ".shrink"); };
+        const int C = cfg.channels;
         if (cfg.stage != 1)
-            for (int i = 0; i < 5; ++i) g.fc_block("FuseBlocks." + std::to_string(i), 4 * lat, lat, 1);
+            for (int i = 0; i < 5; ++i) {
+                // input: the other four branches' local features in branch order (rie.py:393-394)
+                std::vector<Layer::Pre> pre;
+                if (m->fold_shrink)
+                    for (int sl = 0; sl < 4; ++sl) pre.push_back({sl * lat, lat, C, shrink_of(sl < i ? sl : sl + 1)});
+                g.fc_block("FuseBlocks." + std::to_string(i), 4 * lat, lat, 1, pre);
+            }
         if (emb) g.embedding("embedder", cfg.extrinsic_dim, D);
         const int dec_in = (cfg.stage == 1 ? 2 : 3) * lat + D;
-        for (int b = 0; b < 5; ++b)
-            g.fc_block(std::string("Integration_") + kBranchNames[b], dec_in, 3 * (int)m->branches[b].joints.size(), 1);
+        for (int b = 0; b < 5; ++b) {
+            std::vector<Layer::Pre> pre;
+            if (m->fold_shrink) pre.push_back({0, lat, C, shrink_of(b)});
+            g.fc_block(std::string("Integration_") + kBranchNames[b], dec_in, 3 * (int)m->branches[b].joints.size(), 1, pre);
+        }
     } else {
         Model::Branch br;
         br.prefix = "LocalLayer";
@@ -202,7 +218,9 @@ Model *model_create(const r3d_config &cfg) {
         g.temporal_block(br.prefix, br.cin);
         g.fc_block("GlobalInfo", J * F, lat, 2);
         if (emb) g.embedding("embedder", cfg.extrinsic_dim, D);
-        g.fc_block("Integration", 2 * lat + D, 3, 1);
+        std::vector<Layer::Pre> pre;
+        if (m->fold_shrink) pre.push_back({0, lat, cfg.channels, m->layer_index.at(br.prefix + ".shrink")});
+        g.fc_block("Integration", 2 * lat + D, 3, 1, pre);
     }
     // GlobalInfo.fc_1 reads the zero-padded current-frame matrix
     m->layers[m->layer_index["GlobalInfo.fc_1"]].Kpad = CUR_LD;
@@ -364,7 +382,38 @@ int model_finalize(Model *m) {
         // torch layout (N, cin, taps) [Linear: taps == 1]; GEMM column index = tap*cin + c.
         // GEMM layers are stored in MFMA fragment order (see r3d_kernels.hip), the decoder tail row-major.
         const int nk = L.Kpad / BK;
-        if (L.colmap.empty()) {
+        if (!L.pre.empty()) {
+            // W_eff = [.. | W[:, range] S | ..],  t += s * (W[:, range] s_bias): composed in double, one output row at a time
+            std::vector<double> rowacc(L.Kpad);
+            for (int o = 0; o < L.N; ++o) {
+                std::fill(rowacc.begin(), rowacc.end(), 0.0);
+                double extra = 0.0;
+                int c = 0, k = 0;
+                size_t ri = 0;
+                while (c < L.cin_ref) {
+                    if (ri < L.pre.size() && c == L.pre[ri].ref_col0) {
+                        const Layer::Pre &r = L.pre[ri++];
+                        const Layer &S = m->layers[r.shrink_layer];           // (N = ref_width, cin = new_width, one tap)
+                        const float *sw = f.get(S.weight_key), *sb = S.bias_key.empty() ? nullptr : f.get(S.bias_key);
+                        for (int q = 0; q < r.ref_width; ++q) {
+                            const double wq = (double)w[(size_t)o * L.cin_ref + c + q];
+                            const float *srow = sw + (size_t)q * r.new_width;
+                            for (int j = 0; j < r.new_width; ++j) rowacc[k + j] += wq * (double)srow[j];
+                            if (sb) extra += wq * (double)sb[q];
+                        }
+                        c += r.ref_width;
+                        k += r.new_width;
+                    } else {
+                        rowacc[k++] = (double)w[(size_t)o * L.cin_ref + c++];
+                    }
+                }
+                for (int kk = 0; kk < L.Kpad; ++kk) {
+                    const float v = (float)(rowacc[kk] * s[o]);
+                    dst[L.frag ? frag_index(o, kk, nk) : (size_t)o * L.Kpad + kk] = v;
+                }
+                t[o] += extra * s[o];
+            }
+        } else if (L.colmap.empty()) {
             for (int o = 0; o < L.N; ++o)
                 for (int c = 0; c < L.cin; ++c)
                     for (int j = 0; j < L.taps; ++j) {

@@ -19,11 +19,6 @@ namespace r3d {
 
 namespace {
 
-bool env_on(const char *name) {      // set and not "0"
-    const char *e = getenv(name);
-    return e && atoi(e) != 0;
-}
-
 struct Builder {
     Plan &p;
     int mi;             // model index inside the plan
@@ -123,7 +118,23 @@ struct Builder {
         }
         p.tail_floats = std::max<int64_t>(p.tail_floats, (int64_t)(RF + 8) * C);
         const int fin = pp[(L - 1) & 1];
-        return problem(br.prefix + ".shrink", 1, {{fin, 0, RF * C, C, last}}, -1, 0, 0, c_buf, c_col, c_ld);
+        return finish(br, fin, RF * C, last, c_buf, c_col, c_ld);
+    }
+
+    // the block's last activations (one row of C floats per window at leading dimension `ld`) -> its `shrink`; or, when
+    // shrink is folded into the layers that read it (Layer::pre), just remembered for them
+    struct Local { int buf, ld, prob; };
+    std::vector<Local> locals;                               // per branch, in the order the blocks are built
+    int finish(const Model::Branch &br, int fin, int ld, int last, int c_buf, int c_col, int c_ld) {
+        const int C = m.cfg.channels;
+        if (m.fold_shrink) {
+            p.probs[last].flops_per_window += 2.0 * (double)C * (double)m.cfg.latent;   // (the reference's arithmetic, still counted)
+            locals.push_back({fin, ld, last});
+            return last;
+        }
+        const int q = problem(br.prefix + ".shrink", 1, {{fin, 0, ld, C, last}}, -1, 0, 0, c_buf, c_col, c_ld);
+        locals.push_back({c_buf, c_ld, q});
+        return q;
     }
 
     // TemporalBlock.forward (rie.py:85-105) for branch `bi`; returns the shrink problem id.
@@ -177,7 +188,7 @@ struct Builder {
             }
         }
         const int fin = pp[(L - 1) & 1];
-        return problem(br.prefix + ".shrink", 1, {{fin, 0, C, C, last}}, -1, 0, 0, c_buf, c_col, c_ld);
+        return finish(br, fin, C, last, c_buf, c_col, c_ld);
     }
 };
 
@@ -216,17 +227,25 @@ static Plan *build_plan(const Model *a, const Model *b) {
         const int pg = B.fc_block("GlobalInfo", {}, 2, g, 0, lat, (int)m->global_lut_off, (int)m->global_lut_uv_off);
         if (m->cfg.kind == R3D_KIND_POS) {
             pl->pos_model = mi;
-            const int tmp5 = B.buffer("tmp5", 5 * lat);
+            const bool fold = m->fold_shrink;
+            const int C = m->cfg.channels;
+            const int tmp5 = fold ? -1 : B.buffer("tmp5", 5 * lat);
             int sh[5];
             for (int bi = 0; bi < 5; ++bi) sh[bi] = B.temporal_block(bi, tmp5, bi * lat, 5 * lat);
             int mix5 = -1, pf[5] = {-1, -1, -1, -1, -1};
             if (m->cfg.stage != 1) {
                 mix5 = B.buffer("mix5", 5 * lat);
                 for (int i = 0; i < 5; ++i) {
-                    // cat of the other four local features (rie.py:393-394) = <=2 column ranges of tmp5
+                    // cat of the other four local features (rie.py:393-394) = <=2 column ranges of tmp5 - or, with
+                    // shrink folded into fc_1, the four blocks' last activations
                     std::vector<Builder::In> ins;
-                    if (i > 0) ins.push_back({tmp5, 0, 5 * lat, i * lat, sh[0]});
-                    if (i < 4) ins.push_back({tmp5, (i + 1) * lat, 5 * lat, (4 - i) * lat, sh[4]});
+                    if (fold) {
+                        for (int k = 0; k < 5; ++k)
+                            if (k != i) ins.push_back({B.locals[k].buf, 0, B.locals[k].ld, C, sh[k]});
+                    } else {
+                        if (i > 0) ins.push_back({tmp5, 0, 5 * lat, i * lat, sh[0]});
+                        if (i < 4) ins.push_back({tmp5, (i + 1) * lat, 5 * lat, (4 - i) * lat, sh[4]});
+                    }
                     // every shrink must be complete, not only the two named above
                     const int first = (int)pl->probs.size();
                     pf[i] = B.fc_block("FuseBlocks." + std::to_string(i), ins, 1, mix5, i * lat, 5 * lat);
@@ -242,7 +261,8 @@ static Plan *build_plan(const Model *a, const Model *b) {
             for (int bi = 0; bi < 5; ++bi) {
                 // cat(local, [mix], global, [embedding])  (rie.py:376-407)
                 std::vector<Builder::In> ins;
-                ins.push_back({tmp5, bi * lat, 5 * lat, lat, sh[bi]});
+                if (fold) ins.push_back({B.locals[bi].buf, 0, B.locals[bi].ld, C, sh[bi]});
+                else ins.push_back({tmp5, bi * lat, 5 * lat, lat, sh[bi]});
                 if (mix5 >= 0) ins.push_back({mix5, bi * lat, 5 * lat, lat, pf[bi]});
                 ins.push_back({g, 0, lat, lat, pg});
                 if (D > 0) ins.push_back({pl->emb_buf[mi], 0, D, D, pe});
@@ -251,10 +271,11 @@ static Plan *build_plan(const Model *a, const Model *b) {
             }
         } else {
             pl->trj_model = mi;
-            const int local = B.buffer("local", lat);
+            const int local = m->fold_shrink ? -1 : B.buffer("local", lat);
             const int sh = B.temporal_block(0, local, 0, lat);
             std::vector<Builder::In> ins;
-            ins.push_back({local, 0, lat, lat, sh});
+            if (m->fold_shrink) ins.push_back({B.locals[0].buf, 0, B.locals[0].ld, m->cfg.channels, sh});
+            else ins.push_back({local, 0, lat, lat, sh});
             ins.push_back({g, 0, lat, lat, pg});
             if (D > 0) ins.push_back({pl->emb_buf[mi], 0, D, D, pe});
             B.fc_block("Integration", ins, 1, -1, 0, 0);
@@ -269,7 +290,8 @@ static Plan *build_plan(const Model *a, const Model *b) {
     //    branches, a launch with CUs to spare; the rest of its pyramid then rides wherever a launch is as long.
     std::vector<int> asap;
     for (const auto &q : pl->probs) asap.push_back(q.depth);
-    auto levelise = [&](bool spill, std::vector<std::vector<int>> &stages) -> bool {
+    // `pin_first`: the problem that reads the spilled one stays right behind it instead of moving as late as it can
+    auto levelise = [&](bool spill, bool pin_first, std::vector<std::vector<int>> &stages) -> bool {
         const int n = (int)pl->probs.size();
         for (int i = 0; i < n; ++i) pl->probs[i].depth = asap[i];
         int deepest = 0, pt = -1;
@@ -303,6 +325,7 @@ static Plan *build_plan(const Model *a, const Model *b) {
             for (int d : pl->probs[i].deps) users[d].push_back(i);
         auto movable = [&](const ProbSpec &q) {
             const std::string &key = pl->m[q.model]->layers[q.layer].weight_key;
+            if (pin_first && pt >= 0 && std::find(q.deps.begin(), q.deps.end(), pt) != q.deps.end()) return false;
             if (spill && pl->m[q.model]->cfg.kind == R3D_KIND_TRJ && key.rfind("LocalLayer.", 0) == 0 && q.layer3 < 0) return true;
             return (key.rfind("GlobalInfo.", 0) == 0 && key.rfind("GlobalInfo.fc_1", 0) != 0) || key.rfind("Integration.", 0) == 0;
         };
@@ -353,8 +376,10 @@ static Plan *build_plan(const Model *a, const Model *b) {
         if (spill) pl->spill_prob = pt;
         return true;
     };
-    if (!(pl->m[0] && pl->m[1] && !env_on("R3D_NO_SPILL") && levelise(true, pl->stages_spill))) pl->stages_spill.clear();
-    levelise(false, pl->stages);
+    const bool can_spill = pl->m[0] && pl->m[1] && !env_on("R3D_NO_SPILL");
+    if (!(can_spill && levelise(true, false, pl->stages_spill))) pl->stages_spill.clear();
+    if (!(can_spill && levelise(true, true, pl->stages_spill_alt)) || pl->stages_spill_alt == pl->stages_spill) pl->stages_spill_alt.clear();
+    levelise(false, false, pl->stages);
     // workspace offsets
     int64_t off = 0;
     for (auto &bf : pl->buffers) {

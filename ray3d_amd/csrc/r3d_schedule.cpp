@@ -363,8 +363,9 @@ const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t
         return sum;
     };
     const double c_plain = build_all(pl->stages, -1, tiles, wgoff, stages);
-    if (pl->spill_prob >= 0 && !pl->stages_spill.empty()) {
-        const auto &lv = pl->stages_spill;
+    double c_best = c_plain;
+    auto try_spill = [&](const std::vector<std::vector<int>> &lv) {
+        if (pl->spill_prob < 0 || lv.empty()) return;
         // the launch that holds the spilling problem and the one after it
         int s0 = -1, s1 = -1;
         for (int si = 0; si < (int)lv.size(); ++si)
@@ -378,43 +379,44 @@ const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t
         long long fl_tiles = 0;
         for (int e : lv[std::max(s0, 0)])
             if (!(e & STAGE_SPILL_IN) && pl->probs[e].layer3 >= 0) fl_tiles += (B * pl->probs[e].rows_per_window + 31) / 32;
-        if (s0 >= 0 && s1 >= 0 && fl_tiles > nwg) {
-            // candidates for the tiles that run late: none, the remainder of the division of the first-level tiles by
-            // the CU count, and multiples of 32 up to half a round
-            const long long rem = fl_tiles % nwg;
-            std::vector<long long> cands{0};
-            if (rem > 0 && rem <= nwg / 2) cands.push_back(rem);
-            for (long long r = 32; r <= nwg / 2; r += 32)
-                if (r != rem) cands.push_back(r);
-            double best = 0;
-            int best_row0 = M_all;
-            for (long long r : cands) {
-                if (r >= own) continue;
-                const int row0 = r ? (int)((own - r) * 32) : M_all;
-                std::vector<int4> t;
-                std::vector<int> w;
-                StageSchedule a{}, b{};
-                build_stage(pl, lv[s0], B, nwg, row0, t, w, a);
-                build_stage(pl, lv[s1], B, nwg, row0, t, w, b);
-                const double cost = a.makespan + b.makespan;
-                if (r == 0 || cost < best * 0.995) { best = cost; best_row0 = row0; }
-            }
-            if (best_row0 < M_all) {
-                std::vector<int4> t;
-                std::vector<int> w;
-                std::vector<StageSchedule> ss;
-                const double c_spill = build_all(lv, best_row0, t, w, ss);
-                if (dump) fprintf(stderr, "[plan] B=%lld: %d rows late: modelled %.0f cycles, plain %.0f\n", (long long)B, M_all - best_row0, c_spill, c_plain);
-                if (c_spill < c_plain * 0.99) {      // (measured: modelled gains under 1 % do not materialise)
-                    levels = &lv;
-                    spill_row0 = best_row0;
-                    tiles.swap(t);
-                    wgoff.swap(w);
-                    stages.swap(ss);
-                }
-            }
+        if (!(s0 >= 0 && s1 >= 0 && fl_tiles > nwg)) return;
+        // candidates for the tiles that run late: none, the remainder of the division of the first-level tiles by
+        // the CU count, and multiples of 32 up to half a round
+        const long long rem = fl_tiles % nwg;
+        std::vector<long long> cands{0};
+        if (rem > 0 && rem <= nwg / 2) cands.push_back(rem);
+        for (long long r = 32; r <= nwg / 2; r += 32)
+            if (r != rem) cands.push_back(r);
+        double best = 0;
+        int best_row0 = M_all;
+        for (long long r : cands) {
+            if (r >= own) continue;
+            const int row0 = r ? (int)((own - r) * 32) : M_all;
+            std::vector<int4> t;
+            std::vector<int> w;
+            StageSchedule a{}, b{};
+            build_stage(pl, lv[s0], B, nwg, row0, t, w, a);
+            build_stage(pl, lv[s1], B, nwg, row0, t, w, b);
+            const double cost = a.makespan + b.makespan;
+            if (r == 0 || cost < best * 0.995) { best = cost; best_row0 = row0; }
         }
-    }
+        if (best_row0 >= M_all) return;
+        std::vector<int4> t;
+        std::vector<int> w;
+        std::vector<StageSchedule> ss;
+        const double c_spill = build_all(lv, best_row0, t, w, ss);
+        if (dump) fprintf(stderr, "[plan] B=%lld: %d rows late: modelled %.0f cycles, best so far %.0f\n", (long long)B, M_all - best_row0, c_spill, c_best);
+        if (c_spill < c_best * 0.99) {      // (measured: modelled gains under 1 % do not materialise)
+            c_best = c_spill;
+            levels = &lv;
+            spill_row0 = best_row0;
+            tiles.swap(t);
+            wgoff.swap(w);
+            stages.swap(ss);
+        }
+    };
+    try_spill(pl->stages_spill);
+    try_spill(pl->stages_spill_alt);
     return levels;
 }
 
