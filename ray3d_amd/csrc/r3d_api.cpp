@@ -179,7 +179,8 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
                 g.res_tap = 1 + m->cfg.causal;
             }
             g.w = m->d_arena + L.w_off;
-            if (L.bf3 && q.layer2 < 0 && q.enc_lut < 0)
+            const bool b3 = B >= b3_min_batch();
+            if (b3 && L.bf3 && q.layer2 < 0 && q.enc_lut < 0)
                 g.wb3 = m->d_arena + L.wb3_off;
             g.bias = m->d_arena + L.b_off;
             g.res = q.res_buf >= 0 ? buf_ptr(q.res_buf) + q.res_col : nullptr;
@@ -192,7 +193,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             g.slope = L.slope;
             if (q.layer2 >= 0) {
                 const Layer &L2 = m->layers[q.layer2];
-                if (q.layer3 < 0 && L.bf3_conv && L2.bf3_conv && q.nseg == 1) {   // gemm_tile_b3t
+                if (b3 && q.layer3 < 0 && L.bf3_conv && L2.bf3_conv && q.nseg == 1) {   // gemm_tile_b3t
                     g.wb3 = m->d_arena + L.wb3_off;
                     g.w2b3 = m->d_arena + L2.wb3_off;
                 }
@@ -204,7 +205,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             if (q.layer3 >= 0) {
                 const Layer &L3 = m->layers[q.layer3];
                 const Layer &L2b = m->layers[q.layer2];
-                if (L.bf3_conv && L2b.bf3_conv && L3.bf3_conv) {   // first_level_taps_b3
+                if (b3 && L.bf3_conv && L2b.bf3_conv && L3.bf3_conv) {   // first_level_taps_b3
                     g.wb3 = m->d_arena + L.wb3_off;
                     g.w2b3 = m->d_arena + L2b.wb3_off;
                     g.w3b3 = m->d_arena + L3.wb3_off;

@@ -114,6 +114,14 @@ struct TensorSpec {
 };
 
 // One GEMM layer = Conv1d(k3,s3) / Conv1d(k1) / Linear, optionally followed by eval BatchNorm.
+// bf16x3 mode below this many windows per call runs the fp32 tiles (both weight copies are resident): a bf16x3 tile's
+// fixed cost is the larger one, and with a handful of tiles per launch nothing else counts - 0.325 against 0.288 ms at
+// 64 windows, 0.370 against 0.386 at 128 (bench.py --batch).
+inline int64_t b3_min_batch() {
+    static const int64_t v = [] { const char *e = getenv("R3D_B3_MIN_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)96; }();
+    return v;
+}
+
 inline bool env_on(const char *name) {      // set and not "0" (development switches)
     const char *e = getenv(name);
     return e && atoi(e) != 0;

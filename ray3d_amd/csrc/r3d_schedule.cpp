@@ -292,7 +292,8 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
         }
         SchedProb sp{M, L.N, L.Kpad / BK, max_ks, enc_cap};
         if (q.nseg == 1 && q.seg[0].width < L.Kpad) sp.max_ks = 1;   // an operand narrower than its padded K: one bounded descriptor
-        if (L.bf3 && q.layer2 < 0 && q.enc_lut < 0) {   // bf16-matrix-core tiles: whole tiles of <= 128 rows, ~1.5x the iteration rate
+        const bool b3 = B >= b3_min_batch();               // (r3d_api.cpp passes the bf16x3 operands under the same condition)
+        if (b3 && L.bf3 && q.layer2 < 0 && q.enc_lut < 0) {   // bf16-matrix-core tiles: whole tiles of <= 128 rows, ~1.5x the iteration rate
             sp.max_ks = 1;
             sp.max_units = 4;
             sp.nk = (sp.nk * 2 + 2) / 3;
@@ -312,7 +313,7 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
             // tile is narrow enough to hold all rows, three otherwise; 5 / 12 iterations' time by the phase stamps:
             // 45.5 us for a body-part tile, 67.5 us for the trajectory model's at 2.1 GHz)
             sp.nk2 = 2 * sp.nk + mm->layers[q.layer2].Kpad / BK + mm->layers[q.layer3].Kpad / BK + (L.Kpad <= 64 ? 5 : 12);
-            if (L.bf3_conv) {
+            if (b3 && L.bf3_conv) {
                 // on the bf16 matrix cores: 0.7x for every first-level unit.  (Separate factors from the phase stamps - a
                 // body-part unit 27.5 us against 41.5 in fp32, the trajectory model's 57 against 66 - schedule WORSE:
                 // 0.560 against 0.533 ms at 256 windows, 1.70 against 1.60 at 1024; the model's errors compensate.)
@@ -322,7 +323,7 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
             sp.max_ks = 1;
             sp.max_units = 4;
             sp.nk2 = pl->m[q.model]->layers[q.layer2].Kpad / BK;
-            if (L.bf3_conv && pl->m[q.model]->layers[q.layer2].bf3_conv && q.nseg == 1) {   // on the bf16 matrix cores: tiles of <= 96 rows,
+            if (b3 && L.bf3_conv && pl->m[q.model]->layers[q.layer2].bf3_conv && q.nseg == 1) {   // on the bf16 matrix cores: tiles of <= 96 rows,
                 sp.max_units = 3;                                                            // ~0.55x the time per unit (measured)
                 sp.nk = (sp.nk * 5 + 8) / 9;
                 sp.nk2 = (sp.nk2 * 5 + 8) / 9;

@@ -527,9 +527,11 @@ def test_bf16x3_mode_keeps_parity(monkeypatch):
     # a reference fixture (outputs of the reference's PyTorch-CPU forward) ...
     z, mc = load_model_fixture("j17_rf27_s3")
     pos, trj, _, _ = build_modules(mc)
+    reps = -(-128 // z["x"].shape[0])                     # (below 96 windows per call the mode runs the fp32 tiles)
     with torch.no_grad():
-        got = ray3d_amd.Ray3DLifter(pos, trj).eval()(torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["param"]).cuda())
-    want = z["out_pos"] + z["out_trj"]
+        got = ray3d_amd.Ray3DLifter(pos, trj).eval()(torch.from_numpy(np.tile(z["x"], (reps, 1, 1, 1))).cuda(),
+                                                     torch.from_numpy(np.tile(z["param"], (reps, 1))).cuda())
+    want = np.tile(z["out_pos"] + z["out_trj"], (reps, 1, 1, 1))
     assert np.abs(got.cpu().numpy() - want).max() <= tol_for(want)
     # ... and a batch with multi-unit tiles against the oracle
     mc2 = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
@@ -551,13 +553,16 @@ def test_bf16x3_through_the_configuration_key():
     if os.environ.get("R3D_BF16X3") is not None:
         pytest.skip("R3D_BF16X3 in the environment overrides the configuration key")
     z, mc = load_model_fixture("j17_rf27_s3")
-    x, p = torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["param"]).cuda()
+    # (the mode switches itself off below 96 windows per call, where the fp32 tiles are the faster ones: the fixture's
+    # windows are repeated up to a batch that uses it)
+    reps = -(-128 // z["x"].shape[0])
+    x, p = torch.from_numpy(np.tile(z["x"], (reps, 1, 1, 1))).cuda(), torch.from_numpy(np.tile(z["param"], (reps, 1))).cuda()
     outs = []
     for flag in (False, True):
         pos, trj, _, _ = build_modules(dict(mc, BF16X3=flag))
         with torch.no_grad():
             outs.append(ray3d_amd.Ray3DLifter(pos, trj).eval()(x, p).cpu().numpy())
-    want = z["out_pos"] + z["out_trj"]
+    want = np.tile(z["out_pos"] + z["out_trj"], (reps, 1, 1, 1))
     assert np.abs(outs[0] - want).max() <= tol_for(want) and np.abs(outs[1] - want).max() <= tol_for(want)
     assert not np.array_equal(outs[0], outs[1])
 
