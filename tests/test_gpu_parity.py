@@ -482,6 +482,35 @@ def test_other_widths_match_oracle(over):
     assert np.abs(out - ref).max() <= tol_for(ref), np.abs(out - ref).max()
 
 
+@pytest.mark.parametrize("over", [dict(), dict(CHANNELS=128, LATENT_FEATURES_DIM=160, STAGE=2), dict(STAGE=1, CAMERA_EMBDDING=False),
+                                  dict(DENSE=True, DISABLE_OPTIMIZATIONS=True)])
+def test_shrink_folded_into_its_consumers_equals_the_separate_layer(over, monkeypatch):
+    """r3d_finalize composes the TemporalBlocks' `shrink` (1x1 convolution + bias, no activation: rie.py:105) with the
+    Linears that read it when channels <= latent size; R3D_NO_SHRINK_FOLD=1 (read at r3d_create) keeps it a layer of its
+    own.  Both must agree with the oracle, and with each other far inside the tolerance (rounding of the composed
+    weights only)."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    from oracle import torch_port
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3", **over)
+    outs = []
+    for nofold in ("0", "1"):
+        monkeypatch.setenv("R3D_NO_SHRINK_FOLD", nofold)
+        pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+        x, p = synth.synth_rays(75, cp, seed=71), synth.synth_param(75, seed=72)
+        pt = torch.from_numpy(p).cuda() if cp.camera_embedding else None
+        with torch.no_grad():
+            outs.append(ray3d_amd.Ray3DLifter(pos, trj).eval()(torch.from_numpy(x).cuda(), pt).cpu().numpy())
+    sds = [{k: torch.from_numpy(np.asarray(v)) for k, v in s_.items()} for s_ in (sp, st)]
+    with torch.no_grad():
+        pp = torch.from_numpy(p) if cp.camera_embedding else None
+        ref = (torch_port.forward(cp, sds[0], torch.from_numpy(x), pp) + torch_port.forward(ct, sds[1], torch.from_numpy(x), pp)).numpy()
+    for o in outs:
+        assert np.abs(o - ref).max() <= tol_for(ref)
+    assert np.abs(outs[0] - outs[1]).max() <= 0.2 * tol_for(ref)
+    assert not np.array_equal(outs[0], outs[1])          # (the switch really selects two different evaluations)
+
+
 def test_rccl_gather_of_clip_partials_single_rank():
     """The exchange step of the sharded evaluation on the real backend: one all_gather of device-resident
     per-clip rows through RCCL (backend "nccl"), here with a single rank (the GPU box has one device; the
