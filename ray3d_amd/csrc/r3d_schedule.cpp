@@ -13,6 +13,7 @@
 // dispatcher's "first free slot" placement, which left the second round of 128x128 tiles one-third
 // occupied (profiles/r01_v0/pmc_table.txt).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -94,8 +95,9 @@ bool assign(const std::vector<Seg> &segs, int nbins, double T, int ksplit, Assig
         if (s.c1 != cursor_cost) { cursor = 0; cursor_cost = s.c1; }
         const int spread = s.c1 == top_c1 && segs.back().c1 != top_c1 ? top_cap : 1 << 30;
         int u = 0;
-        if (s.c1 * 6.0 <= T && s.c1 != top_c1) {
-            // fillers (units far below the budget: the camera embedding, GlobalInfo's gathered first layer) go two at a
+        if (s.c1 * 6.0 <= T && s.c1 * s.units <= 2.0 * T && s.c1 != top_c1) {
+            // fillers (units far below the budget in a column block that is small change for the launch as a whole: the
+            // camera embedding, GlobalInfo's gathered first layer) go two at a
             // time to the workgroup with the most room left, not to the first one they fit: their modelled cost is the
             // least certain, and first-fit stacked a dozen of them on ONE full workgroup that then ended 20 us after the
             // rest of the launch while others idled (fp32 first-level launch: 249 against 228 us; bf16x3 second launch:
@@ -189,7 +191,10 @@ void pack(const std::vector<SchedProb> &probs, int nbins_max, int max_units, Pac
     const int nbins = (int)std::min<long long>(nbins_max, std::max<long long>(total_units * 4, 1));
     // split-K pieces of 128 and of 64 columns; wider pieces win ties
     out.ks = 0;
+    int widest_split = 1;
+    for (const Seg &sg : segs) widest_split = std::max(widest_split, sg.max_ks);
     for (int ksplit = 2; ksplit <= 4; ksplit *= 2) {
+        if (ksplit > 2 && widest_split < ksplit) break;      // (nothing in this launch can be cut that finely: same packing)
         double lo = std::max(total / nbins, biggest_fixed), top = std::max(total, lo) + 1.0;
         for (const Seg &s : segs) top = std::max(top, s.c1 * s.units + 1.0);
         // gallop up from the ideal budget (a feasible one is rarely more than a unit above it), then bisect
@@ -352,6 +357,7 @@ const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t
     spill_row0 = -1;
     const std::vector<std::vector<int>> *levels = &pl->stages;
     const bool dump = getenv("R3D_PLAN_DUMP") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     auto build_all = [&](const std::vector<std::vector<int>> &lv, int row0, std::vector<int4> &t, std::vector<int> &w,
                          std::vector<StageSchedule> &ss) {
         double sum = 0;
@@ -365,6 +371,8 @@ const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t
     };
     const double c_plain = build_all(pl->stages, -1, tiles, wgoff, stages);
     double c_best = c_plain;
+    std::vector<int> searched0, searched1;      // the two launches the last row search ran on, and what it found
+    int searched_row0 = -1;
     auto try_spill = [&](const std::vector<std::vector<int>> &lv) {
         if (pl->spill_prob < 0 || lv.empty()) return;
         // the launch that holds the spilling problem and the one after it
@@ -390,7 +398,10 @@ const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t
             if (r != rem) cands.push_back(r);
         double best = 0;
         int best_row0 = M_all;
+        const bool same_pair = lv[s0] == searched0 && lv[s1] == searched1;   // (the variants differ in later launches only)
+        if (same_pair) best_row0 = searched_row0;
         for (long long r : cands) {
+            if (same_pair) break;
             if (r >= own) continue;
             const int row0 = r ? (int)((own - r) * 32) : M_all;
             std::vector<int4> t;
@@ -401,6 +412,9 @@ const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t
             const double cost = a.makespan + b.makespan;
             if (r == 0 || cost < best * 0.995) { best = cost; best_row0 = row0; }
         }
+        searched0 = lv[s0];
+        searched1 = lv[s1];
+        searched_row0 = best_row0;
         if (best_row0 >= M_all) return;
         std::vector<int4> t;
         std::vector<int> w;
@@ -418,6 +432,9 @@ const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t
     };
     try_spill(pl->stages_spill);
     try_spill(pl->stages_spill_alt);
+    if (dump)
+        fprintf(stderr, "[plan] B=%lld: schedule built in %.2f ms\n", (long long)B,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     return levels;
 }
 
