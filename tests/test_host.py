@@ -518,6 +518,18 @@ def test_plans_do_not_outlive_a_partner_model():
     hp.close()
 
 
+def test_schedule_build_stays_cheap_at_large_batches():
+    """The host search that builds a batch size's tile lists runs inside the first forward at that size (or r3d_prepare):
+    tens of milliseconds, not seconds - a filler-placement loop once made it quadratic in the batch (1 s at 2048 windows)."""
+    import time
+    mc = default_model_config(ARCHITECTURE="3,3,3,3,3")
+    _plan_check(mc, [8])                                   # (library load, plan construction)
+    for B in (2048, 4096):
+        t0 = time.perf_counter()
+        _plan_check(mc, [B])
+        assert time.perf_counter() - t0 < 0.5, B           # schedule + the exact-cover check of every cell
+
+
 # ------------------------------------------------------------------ camera-augmented H36M and HumanEva front ends
 
 def test_h36m_aug_json_cameras_and_per_camera_fetch(tmp_path):
