@@ -698,6 +698,180 @@ __device__ __forceinline__ void b3_split4(const f32x4 &x, u32x2 (&pl)[3]) {
     pl[2] = u32x2{b3_pack(r0 - b3_lo(m0), r1 - b3_hi(m0)), b3_pack(r2 - b3_lo(m1), r3 - b3_hi(m1))};
 }
 
+// gemm_tile_b3 for single-unit tiles, software-pipelined ACROSS the per-K-tile barrier: the operand fragments of tile
+// kt+1 (weights split into their three bf16 terms, activation planes read from the ring) are prepared in registers while
+// tile kt's MFMAs run, so that the matrix pipe has work from the first instruction after a barrier.  Worth 4-5 % of a
+// single-unit tile.  What bounds that tile is elsewhere (tools/coexec_probe2.cpp): a K tile's 24 MFMAs per SIMD take
+// 0.40 us by themselves, 0.49 with 8 VALU instructions each (only ~4 per MFMA issue for free), 0.69 with the weight
+// loads (4 x b128 per wavefront), 0.79 with the LDS operand reads, 1.02 with the barrier - operand data arriving in
+// the VGPRs and the matrix pipe do not overlap, so a tile with one row block per wavefront pays ~0.4 us per K tile for
+// its 20 KB of operands per SIMD whatever the order of the instructions.
+template <int MI>
+__device__ __forceinline__ void gemm_tile_b3p(ProbRef P, const int row0, const int col0, float *smem, long long *dbg) {
+    static_assert(MI >= 1 && MI <= 2, "register budget: two sets of operand fragments");
+    R3D_TSTAMP(0);
+    constexpr int VR = MI * 32, NA = (VR + 63) / 64;
+    constexpr int PLANE = VR * B3_LD, SFB = 3 * PLANE;      // floats per plane / per ring stage
+    static_assert(3 * SFB * 4 <= GEMM_LDS_BYTES, "three stages of three planes must fit");
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int M = P.M, K = P.K;
+    const int nk = K / BK;
+    const int srow = tid >> 3, a_kq = (tid & 7) * 4;
+    const bool multi = P.kend[0] < K;
+    int seg_ld = P.lda[0], seg_k0 = 0, seg_end = P.kend[0], seg_i = 0;
+    int a_voff[NA];
+    __amdgpu_buffer_rsrc_t arsrc;
+    auto open_seg = [&]() {
+        const float *base = P.a[seg_i] + (size_t)row0 * seg_ld;
+        const long long b = ((long long)(M - 1 - row0) * seg_ld + (seg_end < K ? seg_end : K) - seg_k0) * 4;
+        arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, b < 0x7fffffffLL ? (int)b : 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int gr = row0 + srow + 64 * i;
+            a_voff[i] = (((gr < M ? gr : M - 1) - row0) * seg_ld + a_kq) * 4;
+        }
+    };
+    open_seg();
+    auto prep_seg = [&](int kt) {
+        if (!multi) return;
+        while (kt * BK >= seg_end) {
+            ++seg_i;
+            seg_k0 = seg_end;
+            seg_ld = P.lda[seg_i];
+            seg_end = P.kend[seg_i];
+            open_seg();
+        }
+    };
+    struct Staged { f32x4 a[NA]; };
+    const int last = nk - 1;
+    int a_next = 0;                                          // K tiles are requested strictly in order (the segments advance with them)
+    auto next_a = [&](Staged &R) {
+        const int kt = a_next < last ? a_next : last;
+        const int kb = kt * BK - seg_k0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff[i], kb * 4, 0));
+        ++a_next;
+        prep_seg(a_next < last ? a_next : last);
+    };
+    const int st_off = srow * B3_LD + (a_kq >> 1);
+    auto commit_a = [&](int stage, const Staged &R) {
+        float *s = smem + stage * SFB + st_off;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (srow + 64 * i >= VR) continue;
+            u32x2 pl[3];
+            b3_split4(R.a[i], pl);
+            float *d = s + i * 64 * B3_LD;
+            *reinterpret_cast<u32x2 *>(d) = pl[0];
+            *reinterpret_cast<u32x2 *>(d + PLANE) = pl[1];
+            *reinterpret_cast<u32x2 *>(d + 2 * PLANE) = pl[2];
+        }
+    };
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.wb3 + ((size_t)((col0 >> 5) + wave_u) * nk) * 1024), 0, nk * 4096, 0x00020000);
+    const int w_voff = lane * 16;
+    auto load_w = [&](int kt, WFragB3 &dst) {
+        const int k = kt < last ? kt : last;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                dst.f[h][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff + (h * 2 + j) * 1024, k * 4096, 0));
+    };
+    struct Frags { bf16x8 w[2][3]; bf16x8 a[2][MI][3]; };   // one K tile's MFMA operands: [k16 half][plane]
+    auto split_w = [&](const WFragB3 &raw, Frags &F) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) b3_split8(raw.f[h][0], raw.f[h][1], F.w[h]);
+    };
+    const int a_frag = li * B3_LD + lh * 4;
+    auto read_a = [&](int stage, Frags &F) {
+        const float *s = smem + stage * SFB + a_frag;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    F.a[h][mi][p] = *reinterpret_cast<const bf16x8 *>(s + p * PLANE + mi * 32 * B3_LD + h * 8);
+    };
+    f32x16 acc[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.0f;
+    auto mma = [&](const Frags &F) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[h][mi][2], F.w[h][0], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[h][mi][1], F.w[h][1], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[h][mi][0], F.w[h][2], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[h][mi][1], F.w[h][0], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[h][mi][0], F.w[h][1], acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[h][mi][0], F.w[h][0], acc[mi], 0, 0, 0);
+            }
+    };
+    WFragB3 raw0, raw1;                                      // fp32 weights in flight: tile kt + 1 (being split) and kt + 2
+    Staged s0, s1, s2, s3;                                   // A tiles kt + 2 .. kt + 5 on their way to the ring
+    Frags f0, f1;                                            // operands of tile kt (in use) and kt + 1 (being prepared)
+    load_w(0, raw0);
+    load_w(1, raw1);
+    {
+        Staged t0, t1;
+        next_a(t0);
+        next_a(t1);
+        next_a(s0);
+        next_a(s1);
+        next_a(s2);
+        next_a(s3);
+        commit_a(0, t0);
+        commit_a(1, t1);
+    }
+    split_w(raw0, f0);
+    load_w(2, raw0);
+    __syncthreads();
+    read_a(0, f0);
+    R3D_TSTAMP(1);
+    int st_nxt = 1;                                          // ring stage of tile kt + 1
+    // iteration kt: the MFMAs of tile kt on `cur`; meanwhile `nxt` <- tile kt + 1 (weights from `raw`, which then
+    // takes tile kt + 3; activations from the ring), stage of tile kt + 2 <- `stg`, which then takes tile kt + 6
+    auto iter = [&](int kt, const Frags &cur, Frags &nxt, WFragB3 &raw, Staged &stg) {
+        const int st_wr = st_nxt == 2 ? 0 : st_nxt + 1;
+        mma(cur);
+        split_w(raw, nxt);
+        load_w(kt + 3, raw);
+        read_a(st_nxt, nxt);
+        commit_a(st_wr, stg);
+        next_a(stg);
+        __syncthreads();
+        st_nxt = st_wr;
+    };
+    int kt = 0;
+    for (; kt + 3 < nk; kt += 4) {
+        iter(kt, f0, f1, raw1, s0);
+        iter(kt + 1, f1, f0, raw0, s1);
+        iter(kt + 2, f0, f1, raw1, s2);
+        iter(kt + 3, f1, f0, raw0, s3);
+    }
+    if (kt < nk) {
+        iter(kt, f0, f1, raw1, s0);
+        if (kt + 1 < nk) {
+            iter(kt + 1, f1, f0, raw0, s1);
+            if (kt + 2 < nk) iter(kt + 2, f0, f1, raw1, s2);
+        }
+    }
+    R3D_TSTAMP(2);
+    R3D_TSTAMP(3);
+    store_tile<MI, 1>(P, acc, row0, col0, smem);
+    R3D_TSTAMP(4);
+}
+
 // one 32-deep K tile: weights `w` (fp32, split here) x activations in three planes at `xb` (byte pointer to the K tile's
 // first column of row 0 of plane 0; `pitch` bf16 per row, `plane_bytes` between planes); six products per term pair,
 // smallest first
@@ -1803,8 +1977,8 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
             }
             if (P.wb3 != nullptr) {      // fp32 on the bf16 matrix cores (whole tiles of <= 128 rows)
                 switch (mi) {
-                    case 1: gemm_tile_b3<1>(P, row0, col0, smem, dbg); break;
-                    case 2: gemm_tile_b3<2>(P, row0, col0, smem, dbg); break;
+                    case 1: gemm_tile_b3p<1>(P, row0, col0, smem, dbg); break;   // (32.9 against 34.3 us for the M = B launch; two-unit
+                    case 2: gemm_tile_b3<2>(P, row0, col0, smem, dbg); break;    //  tiles are 2 % slower pipelined: 53.8 against 52.8)
                     case 3: gemm_tile_b3<3>(P, row0, col0, smem, dbg); break;
                     default: gemm_tile_b3<4>(P, row0, col0, smem, dbg); break;
                 }
