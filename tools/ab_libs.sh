@@ -1,4 +1,8 @@
-for i in 1 2 3; do for lib in tools/libray3d_hip_prev.so ray3d_amd/libray3d_hip.so; do echo "$lib $(R3D_BF16X3=1 python - <<PY
+#!/bin/bash
+# same-box A/B of two builds of the library through bench.py (3 alternating runs of 300 steps each):
+#   cp ray3d_amd/libray3d_hip.so tools/libray3d_hip_prev.so   (before the change), rebuild, then through gpurun:
+#   [R3D_BF16X3=1] bash tools/ab_libs.sh
+for i in 1 2 3; do for lib in tools/libray3d_hip_prev.so ray3d_amd/libray3d_hip.so; do echo "$lib $(python - <<PY
 import os,sys
 sys.path.insert(0,".")
 from ray3d_amd import _capi

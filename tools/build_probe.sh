@@ -7,6 +7,8 @@ S="tools/gemm_probe.cpp ray3d_amd/csrc/r3d_kernels.hip ray3d_amd/csrc/r3d_schedu
 /opt/rocm/bin/hipcc $F -x hip $S -o tools/gemm_probe.bin
 /opt/rocm/bin/hipcc $F -DR3D_TIMING -x hip $S -o tools/gemm_probe_timing.bin
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/bf16x3_probe.cpp -o tools/bf16x3_probe.bin
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/coexec_probe.cpp -o tools/coexec_probe.bin
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/coexec_probe2.cpp -o tools/coexec_probe2.bin
 # the library with phase stamps (R3D_TIMING_STAGE=<launch> R3D_LIB_OVERRIDE=tools/libray3d_hip_timing.so python tools/stage_times.py)
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DR3D_TIMING -Iinclude -Iray3d_amd/csrc -Wno-unused-result -x hip -shared \
   -o tools/libray3d_hip_timing.so ray3d_amd/csrc/r3d_kernels.hip ray3d_amd/csrc/r3d_metrics.hip ray3d_amd/csrc/r3d_model.cpp \
