@@ -65,8 +65,9 @@ typedef struct {
                             * ignored by the reference constructor (:54-55): pass 0.          */
     int32_t bf16x3;        /* 0: fp32 matrix cores (v_mfma_f32_32x32x2_f32).  1: the large GEMMs on the
                             * bf16 matrix cores with every fp32 operand split exactly into three bf16
-                            * terms (six products, fp32 accumulate): fp32-equivalent results - the same
-                            * error against a float64 evaluation - at 6/16 of the matrix time.  Not a
+                            * terms (six products, fp32 accumulate): fp32-equivalent results - 1.1 to 1.4
+                            * times the fp32 path's error against a float64 evaluation, both ~1e-6 of the
+                            * output magnitude - at 6/16 of the matrix time.  Not a
                             * reference key.  The environment variable R3D_BF16X3=1 / =0 at r3d_create
                             * overrides the field.                                                     */
 } r3d_config;
