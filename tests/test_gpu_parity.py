@@ -208,7 +208,7 @@ def _oracle_lift(states, windows, prm, threads=None):
 def test_h36m_shape_eval_rf243_against_the_oracle_chain():
     """BASELINE configs[2] on one GPU: the Human3.6M evaluation SHAPE (the data set is not in the image: synthetic clips,
     lengths ~ U(1000, 6000) frames, four cameras, fifteen actions) at RF 243 through evaluate_clips(forward_clip) with the
-    default chunking (2048 windows per forward, tail rounded to 128) and r3d_clip_metrics.  Against the oracle chain
+    default chunking (4096 windows per forward, tail rounded to 128) and r3d_clip_metrics.  Against the oracle chain
     (lib/train_val/trainer.py:283-405 restated: edge pad, materialised windows, CPU forward, float64 world transform,
     NumPy metrics): the per-clip partial rows of three whole clips, and 64 sampled frames of every other clip."""
     import ray3d_amd
@@ -217,7 +217,7 @@ def test_h36m_shape_eval_rf243_against_the_oracle_chain():
     mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3,3,3")
     pos, trj, (cp, sp), (ct, st) = build_modules(mc)
     lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
-    assert (lifter.CLIP_CHUNK, lifter.CLIP_ROUND) == (2048, 128)
+    assert (lifter.CLIP_CHUNK, lifter.CLIP_ROUND) == (4096, 128)
     rng = np.random.default_rng(0)
     cams = [ray3d_amd.synthetic_camera(yaw, 4.5, -12.0, name="cam%d" % i) for i, yaw in enumerate((20, 110, 200, 290))]
     clips = []
