@@ -257,6 +257,13 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
                 if (!d.empty())
                     fprintf(stderr, "[timing] launch %zu: workgroup busy time min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f us (%zu workgroups)\n", si,
                             d.front(), d[d.size() / 10], d[d.size() / 2], d[d.size() * 9 / 10], d.back(), d.size());
+                {   // shader clock during the launch: cycle counter against the 100 MHz wall clock, median over the workgroups
+                    std::vector<double> g;
+                    for (int w = 0; w < ss.nwg && w < 1024; ++w)
+                        if (hw[w * 4 + 3] > hw[w * 4 + 2]) g.push_back((double)(hw[w * 4 + 1] - hw[w * 4 + 0]) / ((hw[w * 4 + 3] - hw[w * 4 + 2]) * 10.0));
+                    std::sort(g.begin(), g.end());
+                    if (!g.empty()) fprintf(stderr, "[timing] launch %zu: shader clock %.2f GHz (median), %.2f .. %.2f\n", si, g[g.size() / 2], g.front(), g.back());
+                }
                 if (getenv("R3D_TIMING_ALL"))
                     for (int w = 0; w < ss.nwg && w < 1024; ++w)
                         fprintf(stderr, "[timing-wg] %d start %.2f end %.2f\n", w, (hw[w * 4 + 2] - w0) / 100.0, (hw[w * 4 + 3] - w0) / 100.0);
