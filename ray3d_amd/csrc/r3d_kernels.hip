@@ -33,6 +33,9 @@
 namespace r3d {
 
 // development instrumentation (tools/gemm_probe -DR3D_TIMING): wall-clock stamps of a tile's phases
+#ifndef R3D_TS
+#define R3D_TS 0          // which of a first-level tile's three tap phases gets the fine stamps (timing builds)
+#endif
 #ifdef R3D_TIMING
 #define R3D_TSTAMP(slot) do { if (dbg && threadIdx.x == 0) dbg[slot] = wall_clock64(); } while (0)
 #else
@@ -1479,7 +1482,7 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
             } else {
                 chunk(0, w0a, w0b, w0c, w0d);
             }
-            if (ts == 0) R3D_TSTAMP(5);
+            if (ts == R3D_TS) R3D_TSTAMP(5);
             // ---- activations (in place: the residual tap's stay in acc0 for the epilogue) -> H
             load_frag(w1rsrc, tap * tiles_per_tap, rb);
             load_frag(w1rsrc, tap * tiles_per_tap + (tiles_per_tap > 1 ? 1 : 0), rbn);
@@ -1494,7 +1497,7 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
                 }
             }
             __syncthreads();
-            if (ts == 0) R3D_TSTAMP(6);
+            if (ts == R3D_TS) R3D_TSTAMP(6);
             // ---- this tap's third of the 3-tap convolution: K = C, barrier-free, weights two K tiles ahead
             {
                 const float *h_frag = H + li * PAIR_LD + lh * 16;
@@ -1526,7 +1529,7 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
                 }
             }
             // (no barrier here: the next tap's first chunk phase has one between this loop and the next write of H)
-            if (ts == 0) R3D_TSTAMP(7);
+            if (ts == R3D_TS) R3D_TSTAMP(7);
             if constexpr (MULTI) {
                 if (ts < 2) {                                // chunk 0 again for the next tap (the streaming sets are dead here)
                     load_frag(w0rsrc, 0, w0a);
@@ -1790,13 +1793,13 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
             } else {
                 chunk(0, w0a, w0b, wc, wc);
             }
-            if (ts == 0) R3D_TSTAMP(5);
+            if (ts == R3D_TS) R3D_TSTAMP(5);
             // ---- activations -> H planes (the residual tap's stay in acc0, fp32, for the epilogue)
             load_w(w1rsrc, tap * tiles_per_tap, wa);
             load_w(w1rsrc, tap * tiles_per_tap + (tiles_per_tap > 1 ? 1 : 0), wb);
             b3t_activate_to_planes<MI>(acc0, slope0, Hb, FLB_H_PLANE, li, ch0);
             __syncthreads();
-            if (ts == 0) R3D_TSTAMP(6);
+            if (ts == R3D_TS) R3D_TSTAMP(6);
             // ---- this tap's third of the 3-tap convolution
             {
                 const int kbase = tap * tiles_per_tap, lastk = tiles_per_tap - 1;
@@ -1815,7 +1818,7 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
                     if (kin + 1 < tiles_per_tap) k_tile1(kin + 1, wb, wa);
                 }
             }
-            if (ts == 0) R3D_TSTAMP(7);
+            if (ts == R3D_TS) R3D_TSTAMP(7);
             if constexpr (MULTI) {
                 if (ts < 2) {
                     load_w(w0rsrc, 0, wa);
