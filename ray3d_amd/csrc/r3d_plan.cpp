@@ -34,6 +34,7 @@ struct Builder {
         return (int)p.buffers.size() - 1;
     }
     bool first_level_fused = false;
+    bool fuse_pairs = true;
     struct In { int buf, col, ld, width, dep; };
     int problem(const std::string &layer_prefix, int rows_pw, const std::vector<In> &ins, int res_buf, int res_col,
                 int res_ld, int c_buf, int c_col, int c_ld, std::vector<int> extra_deps = {}, int enc_lut = -1,
@@ -150,7 +151,7 @@ struct Builder {
         // all of its columns (r3d_kernels.hip, PAIR); otherwise the intermediate goes through a buffer
         // Fusing costs the level its split-K freedom (a fused tile is a whole 32-row unit through both layers), so
         // the top of the pyramid - one row per window, fewer units than CUs at the usual batch sizes - stays unfused.
-        auto fuse = [&](int level_rows) { return C <= N_ALIGN && level_rows >= 3; };
+        auto fuse = [&](int level_rows) { return C <= N_ALIGN && level_rows >= 3 && fuse_pairs; };
         const int hb = L > 1 ? buffer(br.prefix + ".H", (int64_t)(rows / 3) * C) : -1;
         // first layer: the A operand is generated from the raw input inside the kernel (fused prologue)
         int last, i0 = 1;
@@ -194,10 +195,11 @@ struct Builder {
 
 }  // namespace
 
-static Plan *build_plan(const Model *a, const Model *b) {
+static Plan *build_plan(const Model *a, const Model *b, bool small) {
     Plan *pl = new Plan();
     pl->m[0] = a;
     pl->m[1] = b;
+    pl->small = small;
     for (int mi = 0; mi < 2; ++mi) {
         const Model *m = pl->m[mi];
         if (!m) continue;
@@ -208,7 +210,8 @@ static Plan *build_plan(const Model *a, const Model *b) {
             int k0max = 0;
             for (const auto &br : m->branches) k0max = std::max(k0max, br.k0pad);
             B.first_level_fused = m->cfg.num_levels >= 2 && m->cfg.channels <= N_ALIGN && k0max <= 256 && !m->cfg.dense &&
-                                  !env_on("R3D_NO_FIRST_FUSE");
+                                  !small && !env_on("R3D_NO_FIRST_FUSE");
+            B.fuse_pairs = !small && !env_on("R3D_NO_PAIR_FUSE");
         }
         const int lat = m->cfg.latent, D = m->cfg.embed_dim;
         int pe = -1;
@@ -394,14 +397,23 @@ static Plan *build_plan(const Model *a, const Model *b) {
 // freed and another allocated at its address must not inherit the plan, whose layer indices and K paddings belong to
 // the old configuration), and a model's destructor / re-finalisation on another device drops every plan naming it.
 static std::mutex g_plans_mutex;
-static std::map<std::pair<uint64_t, uint64_t>, Plan *> g_plans;
+static std::map<std::pair<std::pair<uint64_t, uint64_t>, bool>, Plan *> g_plans;
 
-Plan *plan_get(Model *a, Model *b) {
+// A call of at most this many windows is one tile's latency per launch, and the fused tiles (first level tap by tap,
+// two convolutions per pyramid level) are the LONG tiles: the small plan leaves them un-fused, so that every layer is a
+// launch of split-K tiles - 17 launches instead of 13, 0.202 against 0.259 ms at one window, 0.216 against 0.266 at 16,
+// 0.242 against 0.270 at 32, 0.250 against 0.269 at 48, level at 64 (bench.py --batch).
+bool plan_is_small(int64_t B) {
+    static const int64_t limit = [] { const char *e = getenv("R3D_SMALL_PLAN_MAX"); return e ? (int64_t)atoll(e) : (int64_t)48; }();
+    return B <= limit && !env_on("R3D_NO_SMALL_PLAN");
+}
+
+Plan *plan_get(Model *a, Model *b, bool small) {
     std::lock_guard<std::mutex> lock(g_plans_mutex);
-    const auto key = std::make_pair(a->id, b ? b->id : (uint64_t)0);
+    const auto key = std::make_pair(std::make_pair(a->id, b ? b->id : (uint64_t)0), small);
     auto it = g_plans.find(key);
     if (it != g_plans.end()) return it->second;
-    Plan *p = build_plan(a, b);
+    Plan *p = build_plan(a, b, small);
     g_plans[key] = p;
     return p;
 }
@@ -409,7 +421,7 @@ Plan *plan_get(Model *a, Model *b) {
 void plans_drop(const Model *m) {
     std::lock_guard<std::mutex> lock(g_plans_mutex);
     for (auto it = g_plans.begin(); it != g_plans.end();) {
-        if (it->first.first == m->id || it->first.second == m->id) {
+        if (it->first.first.first == m->id || it->first.first.second == m->id) {
             delete it->second;
             it = g_plans.erase(it);
         } else {

@@ -27,8 +27,15 @@ def build_modules(mc, out_scale=1.0, device="cuda:0"):
     return pos, trj, (cp, sp), (ct, st)
 
 
+# Calls of <= 48 windows run the library's un-fused "small" plan (r3d_plan.cpp, plan_is_small); the fixtures' few windows
+# must hold on the fused plan too (partial first-level / pair tiles with a handful of valid rows): both are run.
+PLANS = [pytest.param(False, id="small-plan"), pytest.param(True, id="fused-plan")]
+
+
+@pytest.mark.parametrize("fused", PLANS)
 @pytest.mark.parametrize("name", MODEL_CASES)
-def test_modules_match_reference_fixture(name):
+def test_modules_match_reference_fixture(name, fused, monkeypatch):
+    monkeypatch.setenv("R3D_NO_SMALL_PLAN", "1" if fused else "0")
     z, mc = load_model_fixture(name)
     pos, trj, _, _ = build_modules(mc, case_out_scale(name))
     x = torch.from_numpy(z["x"]).cuda()
@@ -43,9 +50,11 @@ def test_modules_match_reference_fixture(name):
     assert et <= tol_for(z["out_trj"]), et
 
 
+@pytest.mark.parametrize("fused", PLANS)
 @pytest.mark.parametrize("name", MODEL_CASES)
-def test_lifter_pair_matches_reference_fixture(name):
+def test_lifter_pair_matches_reference_fixture(name, fused, monkeypatch):
     import ray3d_amd
+    monkeypatch.setenv("R3D_NO_SMALL_PLAN", "1" if fused else "0")
     z, mc = load_model_fixture(name)
     pos, trj, _, _ = build_modules(mc, case_out_scale(name))
     lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
@@ -60,12 +69,14 @@ def test_lifter_pair_matches_reference_fixture(name):
 
 # ---------------------------------------------------------------- oracle parity beyond the fixtures
 
+@pytest.mark.parametrize("fused", PLANS)
 @pytest.mark.parametrize("arch,batch", [("3,3", 1), ("3,3", 37), ("3,3,3", 100), ("3,3,3,3", 33), ("3,3,3,3,3", 5)])
-def test_lifter_matches_oracle_ragged_batches(arch, batch):
+def test_lifter_matches_oracle_ragged_batches(arch, batch, fused, monkeypatch):
     """Batch sizes that are not multiples of any tile (row masking, partial schedules)."""
     import ray3d_amd
     from ray3d_amd import synth
     from oracle import oracle
+    monkeypatch.setenv("R3D_NO_SMALL_PLAN", "1" if fused else "0")
     mc = ray3d_amd.default_model_config(ARCHITECTURE=arch)
     pos, trj, (cp, sp), (ct, st) = build_modules(mc)
     lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
