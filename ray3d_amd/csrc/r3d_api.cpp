@@ -104,7 +104,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         return R3D_ERR_ARG;
     }
 
-    Plan *pl = plan_get(a, b, plan_is_small(B));
+    Plan *pl = plan_get(a, b, plan_kind(B));
     const long long frames = (B - 1) * in->window_stride + a->RF;
     const size_t need = workspace_need(pl, B);
     if (!ws || ws_bytes < need) {
@@ -370,7 +370,7 @@ size_t r3d_workspace_bytes(const r3d_model *pos, const r3d_model *trj, int64_t B
     Model *t = const_cast<Model *>(reinterpret_cast<const Model *>(trj));
     Model *a = p ? p : t, *b = p ? t : nullptr;
     if (!a || B <= 0) return 0;
-    return workspace_need(plan_get(a, b, plan_is_small(B)), B);
+    return workspace_need(plan_get(a, b, plan_kind(B)), B);
 }
 
 int r3d_prepare(r3d_model *pos, r3d_model *trj, int64_t B) {
@@ -380,7 +380,7 @@ int r3d_prepare(r3d_model *pos, r3d_model *trj, int64_t B) {
     for (Model *m : {a, b})
         if (m && (!m->finalized || m->dirty)) { set_error("r3d_prepare called before r3d_finalize (or weights changed since)"); return R3D_ERR_STATE; }
     if (b && !same_input_shape(a, b)) { set_error("pos and trj models disagree on J / F / levels / extrinsic_dim"); return R3D_ERR_ARG; }
-    return schedule_get(plan_get(a, b, plan_is_small(B)), B, device_cu_count()) ? R3D_OK : R3D_ERR_HIP;
+    return schedule_get(plan_get(a, b, plan_kind(B)), B, device_cu_count()) ? R3D_OK : R3D_ERR_HIP;
 }
 
 int r3d_forward(r3d_model *m, const r3d_input *in, int64_t B, float *out_dev, void *ws, size_t ws_bytes, void *stream) {
@@ -467,7 +467,7 @@ int r3d_debug_schedule_check(int nprob, const int *M, const int *N, const int *n
 int r3d_debug_plan_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg, int *launches, int *spilled) {
     Model *a = reinterpret_cast<Model *>(pos ? pos : trj), *b = reinterpret_cast<Model *>(pos && trj ? trj : nullptr);
     if (!a) return -1;
-    Plan *pl = plan_get(a, b, plan_is_small(batch));
+    Plan *pl = plan_get(a, b, plan_kind(batch));
     if (!pl) return -2;
     int spill_row0 = -1;
     std::vector<int4> tiles;

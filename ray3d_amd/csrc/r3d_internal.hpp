@@ -260,7 +260,7 @@ struct Plan {
     // keeps the shortest.
     std::vector<std::vector<int>> stages_spill_alt;
     int spill_prob = -1;
-    bool small = false;          // the un-fused plan of tiny calls (plan_is_small)
+    int kind = 0;                // PLAN_FUSED, or one of the less fused plans of small calls (plan_kind)
     int64_t floats_per_window = 0;
     int64_t tail_floats = 0;     // slack behind the last buffer (the dense ablation's overlapping operand rows read past a window's end)
     int emb_buf[2] = {-1, -1};
@@ -281,8 +281,9 @@ int hip_fail(hipError_t e, const char *what);
 Model *model_create(const r3d_config &cfg);
 int model_set_weight(Model *m, const char *key, const float *host, const int64_t *shape, int rank);
 int model_finalize(Model *m);
-bool plan_is_small(int64_t B);                  // calls of this many windows use the small plan (r3d_plan.cpp)
-Plan *plan_get(Model *a, Model *b, bool small);
+enum { PLAN_FUSED = 0, PLAN_SMALL = 1, PLAN_MEDIUM = 2 };   // everything fused / nothing fused / first level only (r3d_plan.cpp)
+int plan_kind(int64_t B);                       // the plan a call of B windows runs
+Plan *plan_get(Model *a, Model *b, int kind);
 void plans_drop(const Model *m);   // delete every cached plan (and its schedules) that names `m`
 constexpr int STAGE_SPILL_IN = 1 << 30;   // flag on a Plan::stages entry: the spilled rows of that problem
 constexpr int GEMM_SCHED_MAX_UNITS = 6;   // widest tile of r3d_gemm_f32: 6 x 32 rows

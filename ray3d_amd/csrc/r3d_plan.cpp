@@ -195,11 +195,12 @@ struct Builder {
 
 }  // namespace
 
-static Plan *build_plan(const Model *a, const Model *b, bool small) {
+static Plan *build_plan(const Model *a, const Model *b, int kind) {
     Plan *pl = new Plan();
     pl->m[0] = a;
     pl->m[1] = b;
-    pl->small = small;
+    pl->kind = kind;
+    const bool small = kind == PLAN_SMALL;
     for (int mi = 0; mi < 2; ++mi) {
         const Model *m = pl->m[mi];
         if (!m) continue;
@@ -211,7 +212,7 @@ static Plan *build_plan(const Model *a, const Model *b, bool small) {
             for (const auto &br : m->branches) k0max = std::max(k0max, br.k0pad);
             B.first_level_fused = m->cfg.num_levels >= 2 && m->cfg.channels <= N_ALIGN && k0max <= 256 && !m->cfg.dense &&
                                   !small && !env_on("R3D_NO_FIRST_FUSE");
-            B.fuse_pairs = !small && !env_on("R3D_NO_PAIR_FUSE");
+            B.fuse_pairs = kind == PLAN_FUSED && !env_on("R3D_NO_PAIR_FUSE");
         }
         const int lat = m->cfg.latent, D = m->cfg.embed_dim;
         int pe = -1;
@@ -397,23 +398,27 @@ static Plan *build_plan(const Model *a, const Model *b, bool small) {
 // freed and another allocated at its address must not inherit the plan, whose layer indices and K paddings belong to
 // the old configuration), and a model's destructor / re-finalisation on another device drops every plan naming it.
 static std::mutex g_plans_mutex;
-static std::map<std::pair<std::pair<uint64_t, uint64_t>, bool>, Plan *> g_plans;
+static std::map<std::pair<std::pair<uint64_t, uint64_t>, int>, Plan *> g_plans;
 
-// A call of at most this many windows is one tile's latency per launch, and the fused tiles (first level tap by tap,
-// two convolutions per pyramid level) are the LONG tiles: the small plan leaves them un-fused, so that every layer is a
-// launch of split-K tiles - 17 launches instead of 13, 0.202 against 0.259 ms at one window, 0.216 against 0.266 at 16,
-// 0.242 against 0.270 at 32, 0.250 against 0.269 at 48, level at 64 (bench.py --batch).
-bool plan_is_small(int64_t B) {
-    static const int64_t limit = [] { const char *e = getenv("R3D_SMALL_PLAN_MAX"); return e ? (int64_t)atoll(e) : (int64_t)48; }();
-    return B <= limit && !env_on("R3D_NO_SMALL_PLAN");
+// A call of few windows is one tile's latency per launch, and the fused tiles (first level tap by tap, two convolutions
+// per pyramid level) are the LONG tiles.  Up to 48 windows the small plan leaves everything un-fused, so that every
+// layer is a launch of split-K tiles - 17 launches instead of 13, 0.202 against 0.259 ms at one window, 0.216 against
+// 0.266 at 16, 0.242 against 0.270 at 32, 0.250 against 0.269 at 48; up to 96 windows the pairs alone stay un-fused
+// (first level fused): 0.270 against 0.287 ms at 64, 0.355 against 0.360 at 96; from 128 on everything fused wins
+// (0.379 against 0.383; 0.608 against 0.627 at 256).  bench.py --batch.
+int plan_kind(int64_t B) {
+    static const int64_t small_max = [] { const char *e = getenv("R3D_SMALL_PLAN_MAX"); return e ? (int64_t)atoll(e) : (int64_t)48; }();
+    static const int64_t medium_max = [] { const char *e = getenv("R3D_MEDIUM_PLAN_MAX"); return e ? (int64_t)atoll(e) : (int64_t)96; }();
+    if (env_on("R3D_NO_SMALL_PLAN")) return PLAN_FUSED;
+    return B <= small_max ? PLAN_SMALL : B <= medium_max ? PLAN_MEDIUM : PLAN_FUSED;
 }
 
-Plan *plan_get(Model *a, Model *b, bool small) {
+Plan *plan_get(Model *a, Model *b, int kind) {
     std::lock_guard<std::mutex> lock(g_plans_mutex);
-    const auto key = std::make_pair(std::make_pair(a->id, b ? b->id : (uint64_t)0), small);
+    const auto key = std::make_pair(std::make_pair(a->id, b ? b->id : (uint64_t)0), kind);
     auto it = g_plans.find(key);
     if (it != g_plans.end()) return it->second;
-    Plan *p = build_plan(a, b, small);
+    Plan *p = build_plan(a, b, kind);
     g_plans[key] = p;
     return p;
 }
