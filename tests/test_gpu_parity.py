@@ -128,8 +128,9 @@ def _reference_cameras():
             [oracle.Camera(z[t + "/K"], z[t + "/R"], z[t + "/t"]) for t in tags], z, tags)
 
 
+@pytest.mark.parametrize("fused", PLANS)
 @pytest.mark.parametrize("arch,B", [("3,3", 24), ("3,3,3,3,3", 48)])
-def test_forward_uv_matches_oracle_on_reference_cameras(arch, B):
+def test_forward_uv_matches_oracle_on_reference_cameras(arch, B, fused, monkeypatch):
     """BASELINE configs[3] (mixed intrinsics per batch) at RF 9 and RF 243: pixel keypoints + one camera row PER WINDOW in,
     rays encoded inside the first-level gather.  Comparand: the ORACLE chain - rays from the oracle's camera restatement
     (float64, pinned to the reference's uv -> ray pairs in cameras.npz), cast as lib/train_val/trainer.py:298 does, through
@@ -138,6 +139,7 @@ def test_forward_uv_matches_oracle_on_reference_cameras(arch, B):
     import ray3d_amd
     from ray3d_amd import synth
     from oracle import oracle
+    monkeypatch.setenv("R3D_NO_SMALL_PLAN", "1" if fused else "0")     # (the gather inside the fused first level / inside r3d_gemm_enc_uv_f32)
     cams, ocams, z, tags = _reference_cameras()
     mc = ray3d_amd.default_model_config(ARCHITECTURE=arch)
     pos, trj, (cp, sp), (ct, st) = build_modules(mc)
@@ -171,12 +173,14 @@ def test_forward_uv_matches_oracle_on_reference_cameras(arch, B):
     assert counts[0] == counts[1], counts
 
 
-def test_forward_uv_overlapping_windows_each_with_its_own_camera():
+@pytest.mark.parametrize("fused", PLANS)
+def test_forward_uv_overlapping_windows_each_with_its_own_camera(fused, monkeypatch):
     """Windows that share frames but not the camera (window_stride < RF with per-window camera rows): every window's
     frames are encoded with THAT window's camera - equal to materialising the windows and encoding each on the host.
     Also the sliding-clip form (stride 1, one camera) against forward_clip on host-encoded rays."""
     import ray3d_amd
     from ray3d_amd import synth
+    monkeypatch.setenv("R3D_NO_SMALL_PLAN", "1" if fused else "0")
     cams, _, _, _ = _reference_cameras()
     mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
     pos, trj, (cp, _), _ = build_modules(mc)
