@@ -281,7 +281,7 @@ int hip_fail(hipError_t e, const char *what);
 Model *model_create(const r3d_config &cfg);
 int model_set_weight(Model *m, const char *key, const float *host, const int64_t *shape, int rank);
 int model_finalize(Model *m);
-enum { PLAN_FUSED = 0, PLAN_SMALL = 1, PLAN_MEDIUM = 2 };   // everything fused / nothing fused / first level only (r3d_plan.cpp)
+enum { PLAN_FUSED = 0, PLAN_SMALL = 1, PLAN_MEDIUM = 2, PLAN_LARGE = 3 };   // everything but the top level fused / nothing / first level only / the top level too (r3d_plan.cpp)
 int plan_kind(int64_t B);                       // the plan a call of B windows runs
 Plan *plan_get(Model *a, Model *b, int kind);
 void plans_drop(const Model *m);   // delete every cached plan (and its schedules) that names `m`

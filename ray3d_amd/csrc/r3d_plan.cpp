@@ -35,6 +35,7 @@ struct Builder {
     }
     bool first_level_fused = false;
     bool fuse_pairs = true;
+    bool fuse_top = false;       // the top pyramid level (one row per window) as a fused pair too
     struct In { int buf, col, ld, width, dep; };
     int problem(const std::string &layer_prefix, int rows_pw, const std::vector<In> &ins, int res_buf, int res_col,
                 int res_ld, int c_buf, int c_col, int c_ld, std::vector<int> extra_deps = {}, int enc_lut = -1,
@@ -151,7 +152,7 @@ struct Builder {
         // all of its columns (r3d_kernels.hip, PAIR); otherwise the intermediate goes through a buffer
         // Fusing costs the level its split-K freedom (a fused tile is a whole 32-row unit through both layers), so
         // the top of the pyramid - one row per window, fewer units than CUs at the usual batch sizes - stays unfused.
-        auto fuse = [&](int level_rows) { return C <= N_ALIGN && level_rows >= 3 && fuse_pairs; };
+        auto fuse = [&](int level_rows) { return C <= N_ALIGN && (level_rows >= 3 || fuse_top) && fuse_pairs; };
         const int hb = L > 1 ? buffer(br.prefix + ".H", (int64_t)(rows / 3) * C) : -1;
         // first layer: the A operand is generated from the raw input inside the kernel (fused prologue)
         int last, i0 = 1;
@@ -212,7 +213,8 @@ static Plan *build_plan(const Model *a, const Model *b, int kind) {
             for (const auto &br : m->branches) k0max = std::max(k0max, br.k0pad);
             B.first_level_fused = m->cfg.num_levels >= 2 && m->cfg.channels <= N_ALIGN && k0max <= 256 && !m->cfg.dense &&
                                   !small && !env_on("R3D_NO_FIRST_FUSE");
-            B.fuse_pairs = kind == PLAN_FUSED && !env_on("R3D_NO_PAIR_FUSE");
+            B.fuse_pairs = (kind == PLAN_FUSED || kind == PLAN_LARGE) && !env_on("R3D_NO_PAIR_FUSE");
+            B.fuse_top = kind == PLAN_LARGE;
         }
         const int lat = m->cfg.latent, D = m->cfg.embed_dim;
         int pe = -1;
@@ -405,10 +407,14 @@ static std::map<std::pair<std::pair<uint64_t, uint64_t>, int>, Plan *> g_plans;
 // layer is a launch of split-K tiles - 17 launches instead of 13, 0.202 against 0.259 ms at one window, 0.216 against
 // 0.266 at 16, 0.242 against 0.270 at 32, 0.250 against 0.269 at 48; up to 96 windows the pairs alone stay un-fused
 // (first level fused): 0.270 against 0.287 ms at 64, 0.355 against 0.360 at 96; from 128 on everything fused wins
-// (0.379 against 0.383; 0.608 against 0.627 at 256).  bench.py --batch.
+// (0.379 against 0.383; 0.608 against 0.627 at 256).  From 1024 windows on the top pyramid level (one row per window)
+// has enough rows to run as a fused pair too (11 launches): 1.977 against 1.986 ms at 1024, 3.765 against 3.817 at 2048,
+// 7.430 against 7.459 at 4096; at 512 it loses (1.092 against 1.083).  bench.py --batch.
 int plan_kind(int64_t B) {
     static const int64_t small_max = [] { const char *e = getenv("R3D_SMALL_PLAN_MAX"); return e ? (int64_t)atoll(e) : (int64_t)48; }();
     static const int64_t medium_max = [] { const char *e = getenv("R3D_MEDIUM_PLAN_MAX"); return e ? (int64_t)atoll(e) : (int64_t)96; }();
+    static const int64_t large_min = [] { const char *e = getenv("R3D_LARGE_PLAN_MIN"); return e ? (int64_t)atoll(e) : (int64_t)1024; }();
+    if (B >= large_min) return PLAN_LARGE;
     if (env_on("R3D_NO_SMALL_PLAN")) return PLAN_FUSED;
     return B <= small_max ? PLAN_SMALL : B <= medium_max ? PLAN_MEDIUM : PLAN_FUSED;
 }

@@ -491,7 +491,7 @@ def test_plan_tile_lists_cover_every_problem_once(monkeypatch):
     # (shrink folded into its consumers: one launch fewer than DAG levels of the reference; calls of <= 48 windows use the
     # un-fused small plan - expand_conv, every 3-tap and every 1x1 convolution a launch of its own -, calls of <= 96
     # windows the medium one: first level fused, pairs not)
-    assert [n for n, _ in res] == [16, 16, 16] + [12] * 7
+    assert [n for n, _ in res] == [16, 16, 16] + [12] * 5 + [11, 11]     # (from 1024 windows on the top level is a fused pair too)
     assert [n for n, _ in _plan_check(mc, [48, 49, 64, 96, 97])] == [16, 14, 14, 14, 12]
     assert dict(zip([1, 2, 31, 100, 255, 256, 257, 600, 1024, 2048], [s for _, s in res]))[256] == 512
     # 1296 equal-row tiles on 256 CUs: the 16 that would open a sixth round run with the next launch
