@@ -526,6 +526,24 @@ def test_shrink_folded_into_its_consumers_equals_the_separate_layer(over, monkey
     assert not np.array_equal(outs[0], outs[1])          # (the switch really selects two different evaluations)
 
 
+@pytest.mark.parametrize("b3", [False, True])
+def test_window_counts_where_the_plan_switches(b3):
+    """The library picks one of four plans per call by its window count (<= 48 nothing fused, <= 96 first level only,
+    < 1024 all but the top level, from 1024 on everything: r3d_plan.cpp, plan_kind) and, in bf16x3 mode, the fp32 tiles
+    below 96 windows: every window of calls on both sides of every switch against the torch port of the reference graph."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3", BF16X3=b3)
+    pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    for B in (48, 49, 95, 96, 97, 1023, 1024, 1025):
+        x, p = synth.synth_rays(B, cp, seed=B), synth.synth_param(B, seed=B + 1)
+        with torch.no_grad():
+            out = lifter(torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()).cpu().numpy()
+        ref = _oracle_lift(((cp, sp), (ct, st)), x, p)
+        assert np.abs(out - ref).max() <= tol_for(ref), (B, np.abs(out - ref).max())
+
+
 def test_rccl_gather_of_clip_partials_single_rank():
     """The exchange step of the sharded evaluation on the real backend: one all_gather of device-resident
     per-clip rows through RCCL (backend "nccl"), here with a single rank (the GPU box has one device; the
