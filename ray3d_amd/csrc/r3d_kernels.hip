@@ -15,10 +15,11 @@
 //                                          positional / temporal differences of rie.py:290-357 folded into the
 //                                          weights) + the first pyramid level, tap by tap, for 32 / 64 output rows;
 //                        enc_tile          GlobalInfo's input (the windows' current frames) gathered the same way;
-//                        gemm_tile_b3, gemm_tile_b3t, first_level_taps_b3
+//                        gemm_tile_b3 (gemm_tile_b3p for single-unit tiles), gemm_tile_b3t, first_level_taps_b3
 //                                          the 1024-wide Linears, the fused pairs and the first level on the bf16 matrix cores.
-//  r3d_gemm_enc_f32    fallback for configurations first_level_taps does not cover (one-level architectures,
-//                      more than 256 channels, the dense ablation): expand_conv / GlobalInfo.fc_1 with the gather fused.
+//  r3d_gemm_enc_f32    expand_conv / GlobalInfo.fc_1 with the gather fused, where first_level_taps is not used: one-level
+//                      architectures, more than 256 channels, the dense ablation - and the un-fused plan of calls of
+//                      <= 48 windows (r3d_plan.cpp, plan_kind).
 //  r3d_gemm_uv_f32, r3d_gemm_enc_uv_f32
 //                      the same two kernels for launches that gather pixel keypoints (UV input mode).
 //  r3d_decode_f32      last Linear of the decoders + joint reassembly (rie.py:409-432) + trajectory
