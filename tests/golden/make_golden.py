@@ -17,6 +17,9 @@ What is pinned:
   4. losses.npz       : mpjpe / n_mpjpe / p_mpjpe / mean_velocity_error known answers.
   6. frontends.npz    : the camera-augmented H36M front end (JSON camera list, scaled subjects, per-camera fetches) and
      HumanEva-I's camera layout / joint conventions.
+  7. cameras_3dhp.npz : the 14 MPI-INF-3DHP cameras (S1/Seq1) as CameraInfoPacket builds them, with uv -> ray pairs.
+  8. undistort.npz    : the reference's forward distortion model (data/camera_augmentation.py:502-542) on a pixel grid
+     for the four H36M coefficient sets - the known-answer side of the (otherwise cv2-only) undistortion.
   5. dataset.npz      : the reference's Data front end on a small synthetic archive pair: per-clip ground truth in
      the normalised frame and ray-encoded keypoints, the left/right index lists, the H36M joint selection.
 Only numbers leave this script; no reference source text is stored.
@@ -432,6 +435,62 @@ def gen_frontends():
     print("frontends: aug subjects", len(blob["aug/subjects_all"]), "camera_dist", list(blob["aug/camera_dist"]), "| humaneva keys", keys)
 
 
+def gen_cameras_3dhp():
+    """The 14 cameras of MPI-INF-3DHP's S1/Seq1 (lib/dataset/mpii_3dhp_dataset.py:9-251; BASELINE configs[3] draws one
+    per window): CameraInfoPacket constants and uv -> ray pairs, built exactly as Mpii3dhpDataset.__init__ builds them
+    (:309-341: float32 table values, undistort=False).  A file of its own: cameras.npz stays byte-identical."""
+    blob, tags = {}, []
+    f32 = lambda v: np.array(v, dtype="float32")
+    for i in range(14):
+        cam = dhp_camera_params["S1_Seq1_%d" % i][0]
+        fl, ce = f32(cam["focal_length"]), f32(cam["center"])
+        K = np.eye(3, dtype=np.float64)
+        K[0, 0], K[1, 1], K[0, 2], K[1, 2] = fl[0], fl[1], ce[0], ce[1]
+        R = f32(cam["R"])
+        t = np.array(f32(cam["translation"]), dtype=np.float64).reshape(3, 1)
+        pkt = CameraInfoPacket(P=None, K=K, R=R, t=t, res_w=cam["res_w"], res_h=cam["res_h"], azimuth=cam["azimuth"],
+                               dist_coeff=None, undistort=False)
+        tag = "3dhp_S1_Seq1_%d" % i
+        uv = 2048.0 * synth.hash_uniform("uv." + tag, (3, 17, 2), 9)
+        tags.append(tag)
+        blob.update({tag + "/K": K, tag + "/R": R.astype(np.float64), tag + "/t": t,
+                     tag + "/height": np.float64((-pkt.Rw2c.T @ pkt.Tw2c)[2][0]),
+                     tag + "/pitch": np.float64(pkt.cam_pitch_rad),
+                     tag + "/Rn2w": pkt.Rn2w, tag + "/Tn2w": pkt.Tn2w,
+                     tag + "/uv": uv, tag + "/rays": pkt.get_cam_ray_given_uv(uv)})
+    blob["tags"] = np.array(tags)
+    np.savez_compressed(os.path.join(HERE, "cameras_3dhp.npz"), **blob)
+    print("cameras_3dhp:", len(tags))
+
+
+def gen_undistort():
+    """What CAN be pinned of the undistortion (lib/camera/camera.py:412-421 calls cv2.undistortPoints, which is absent):
+    the reference's own FORWARD model, distortPoint (data/camera_augmentation.py:502-542), on a pixel grid for the four
+    H36M coefficient sets as lib/dataset/h36m_dataset.py:378-380 orders them.  undistort(distortPoint(p)) must return p."""
+    for name in ("ipdb", "h5py", "mat73", "cdflib"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.path.insert(0, os.path.join(REF, "data"))
+    import matplotlib
+    matplotlib.use("Agg")
+    from data.camera_augmentation import distortPoint
+    blob = {}
+    for i, intr in enumerate(h36m_cameras_intrinsic_params):
+        f32 = lambda v: np.array(v, dtype="float32")
+        fl, ce = f32(intr["focal_length"]), f32(intr["center"])
+        K = np.eye(3, dtype=np.float64)
+        K[0, 0], K[1, 1], K[0, 2], K[1, 2] = fl[0], fl[1], ce[0], ce[1]
+        rad, tan = f32(intr["radial_distortion"]), f32(intr["tangential_distortion"])
+        dist = np.concatenate((rad[:2], tan, rad[2:])).astype(np.float32).reshape(5)      # h36m_dataset.py:378-380
+        gx, gy = np.meshgrid(np.linspace(20.0, float(intr["res_w"]) - 20.0, 13), np.linspace(20.0, float(intr["res_h"]) - 20.0, 13))
+        ideal = np.stack([gx.ravel(), gy.ravel()], axis=0)                                 # (2, N) as distortPoint expects
+        distorted = distortPoint(ideal.copy(), K, dist.reshape(1, 5).astype(np.float64))
+        blob.update({"cam%d/K" % i: K, "cam%d/dist" % i: dist.astype(np.float64), "cam%d/ideal" % i: ideal.T.copy(),
+                     "cam%d/distorted" % i: distorted.T.copy()})
+    blob["n"] = np.int64(len(h36m_cameras_intrinsic_params))
+    np.savez_compressed(os.path.join(HERE, "undistort.npz"), **blob)
+    print("undistort: %d coefficient sets, %d points each" % (int(blob["n"]), ideal.shape[1]))
+
+
 def gen_losses():
     a = (synth.hash_uniform("loss.a", (6, 1, 17, 3), 5) * 2 - 1)
     b = a + 0.1 * (synth.hash_uniform("loss.b", (6, 1, 17, 3), 5) * 2 - 1)
@@ -451,9 +510,15 @@ if __name__ == "__main__":
             gen_dataset()
         if "frontends" in sys.argv[1:]:
             gen_frontends()
-        gen_models(only=set(sys.argv[1:]) - {"dataset", "frontends"} or {"-"})
+        if "cameras_3dhp" in sys.argv[1:]:
+            gen_cameras_3dhp()
+        if "undistort" in sys.argv[1:]:
+            gen_undistort()
+        gen_models(only=set(sys.argv[1:]) - {"dataset", "frontends", "cameras_3dhp", "undistort"} or {"-"})
         sys.exit(0)
     gen_cameras()
+    gen_cameras_3dhp()
+    gen_undistort()
     gen_losses()
     gen_models()
     gen_evalcore()

@@ -204,6 +204,49 @@ def test_camera_undistortion_is_unpinned_but_consistent():
     assert np.abs(cam.rays_from_uv(pts) - plain.rays_from_uv(pts)).max() > 1e-4    # ... and it is not a no-op
 
 
+def test_3dhp_cameras_match_reference():
+    """All 14 MPI-INF-3DHP cameras (BASELINE configs[3] draws one per window): product and oracle against the
+    reference's CameraInfoPacket (tests/golden/cameras_3dhp.npz)."""
+    from oracle import oracle
+    z = np.load(os.path.join(GOLDEN, "cameras_3dhp.npz"))
+    assert len(z["tags"]) == 14
+    seen = set()
+    for tag in z["tags"]:
+        for cam in (ray3d_amd.Camera(z[tag + "/K"], z[tag + "/R"], z[tag + "/t"]),
+                    oracle.Camera(z[tag + "/K"], z[tag + "/R"], z[tag + "/t"])):
+            assert abs(cam.height - float(z[tag + "/height"])) < 1e-12
+            assert abs(cam.pitch - float(z[tag + "/pitch"])) < 1e-12
+            assert np.abs(cam.Rn2w - z[tag + "/Rn2w"]).max() < 1e-12 and np.abs(cam.Tn2w - z[tag + "/Tn2w"]).max() < 1e-12
+            assert np.abs(cam.rays_from_uv(z[tag + "/uv"]) - z[tag + "/rays"]).max() < 1e-12
+        seen.add((round(float(z[tag + "/height"]), 6), round(float(z[tag + "/pitch"]), 6)))
+    assert len(seen) >= 10          # they really are different cameras (heights / pitches)
+
+
+def test_undistortion_inverts_the_references_distortion_model():
+    """The undistortion is cv2.undistortPoints in the reference (camera.py:412-421; OpenCV absent: PARITY UNPINNED vs cv2).
+    What the reference itself holds is the forward model, distortPoint (data/camera_augmentation.py:502-542): its outputs
+    on a pixel grid for the four H36M coefficient sets are in undistort.npz, and undistorting them must give the grid
+    back - for the product and for the oracle - and the product's own forward model must BE distortPoint."""
+    from oracle import oracle
+    z = np.load(os.path.join(GOLDEN, "undistort.npz"))
+    worst = 0.0
+    for i in range(int(z["n"])):
+        K, dist, ideal, distorted = z["cam%d/K" % i], z["cam%d/dist" % i], z["cam%d/ideal" % i], z["cam%d/distorted" % i]
+        cam = ray3d_amd.Camera(K, np.eye(3), np.zeros(3) + [0, 0, 4.0], dist_coeff=dist, undistort=True)
+        assert np.abs(cam.distort_points(ideal) - distorted).max() < 1e-9
+        assert np.abs(oracle.distort_points(K, dist, ideal) - distorted).max() < 1e-9
+        # the image's inner 80 %: where the fixed five iterations have converged to a centi-pixel (H36M keypoints live there)
+        w, h = 2 * K[0, 2], 2 * K[1, 2]
+        inner = (np.abs(ideal[:, 0] - K[0, 2]) < 0.4 * w) & (np.abs(ideal[:, 1] - K[1, 2]) < 0.4 * h)
+        for und in (cam.undistort_points(distorted), oracle.undistort_points(K, dist, distorted)):
+            err = np.abs(und - ideal)
+            worst = max(worst, err[inner].max())
+            assert err[inner].max() < 1e-2, (i, err[inner].max())
+            assert err.max() < 0.5, (i, err.max())              # corners: still sub-pixel after five iterations
+        assert np.abs(distorted - ideal).max() > 5.0            # ... of a distortion of many pixels
+    print("undistort(distortPoint_ref(p)) - p: worst inner-grid error %.2e px" % worst)
+
+
 def test_metrics_match_reference():
     z = np.load(os.path.join(GOLDEN, "losses.npz"))
     a, b = torch.from_numpy(z["pred"]), torch.from_numpy(z["target"])
