@@ -14,6 +14,13 @@ synthetic clips of U(1000, 6000) frames, four cameras, fifteen actions - sharded
 per-clip partial rows per pass.  A step = one pass over the whole clip set (strong scaling: the set is fixed);
 the gathered MPJPE is part of the line and must not depend on N.
 
+--workload cfg4_rf9 | cfg4_rf243 | cfg5 (windows mode): the configurations the reference SHIPS instead of configs[1] -
+BASELINE configs[3] (cfg_ray3d_3dhp_stage3: J = 17, ARCHITECTURE '3,3' = RF 9, and the same at RF 243; pixel keypoints in,
+every window with its own camera drawn from the 14 MPI-INF-3DHP cameras, rays encoded in the first-level gather; 1024
+windows per step) and configs[4] (14 joints, RF 9, 4096 windows per step - 512 per GPU under --gpus 8 -, one camera of
+the 342-camera augmentation grid of data/camera_augmentation.py:637-642 per window).  The default line carries them as
+the secondary objects `cfg4` and `cfg5`.
+
 With --gpus N > 1 and no WORLD_SIZE in the environment the script launches its own N ranks through
 torch.distributed.run (one process per GPU, RCCL) and fails loudly when fewer GPUs are visible.
 
@@ -23,6 +30,9 @@ Prints ONE JSON line (rank 0).  Besides the driver's keys it carries
                   of the timed region (HIP events around it, same stream) - bracketing every launch slows the chip's
                   clock and adds gaps, and a kernel cannot take longer than the step it is part of;
   roofline_b1024  the same at north_star's 1024-window batch (windows mode, N = 1);
+  parity_max_abs_err   the HIP path against tests/golden/model_j17_rf243_s3.npz (outputs of the REFERENCE's PyTorch-CPU
+                  forward for the very weights this bench builds), checked BEFORE anything is timed: > 1e-4 aborts;
+  cfg4, cfg5      poses/s + roofline of the shipped RF-9 configurations (see --workload);
   cpu_baseline    the PyTorch-CPU port of the same module graph (oracle/torch_port.py) and the C restatement
                   (oracle/ray3d_oracle.c) timed on this host's cores on a bounded sample of the same workload.
 """
@@ -41,16 +51,19 @@ import numpy as np   # noqa: E402
 import torch   # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+PEAK_BF16X3_TFLOPS = 2500.0 / 6.0   # dense bf16 MFMA peak / six bf16 products per fp32 product (r3d_config.bf16x3)
 PEAK_HBM_GBS = 8000.0
+PARITY_FIXTURE = os.path.join(ROOT, "tests", "golden", "model_j17_rf243_s3.npz")
+PARITY_ATOL = 1e-4              # north_star: fp32 3D joint positions within 1e-4 abs of the reference's CPU forward
 BATCH = 256
 ARCH = "3,3,3,3,3"
 EVAL_CLIPS = 240                # 2 subjects x 15 actions x 2 sub-actions x 4 cameras (cfg 3)
 
 
-def build(device, arch=ARCH, bf16x3=False):
+def build(device, arch=ARCH, bf16x3=False, **over):
     import ray3d_amd
     from ray3d_amd import synth
-    mc = ray3d_amd.default_model_config(ARCHITECTURE=arch, BF16X3=bf16x3)
+    mc = ray3d_amd.default_model_config(ARCHITECTURE=arch, BF16X3=bf16x3, **over)
     fac = ray3d_amd.Model(mc, {}, is_train=False)
     pos, trj = fac.get_pos_model(), fac.get_trj_model()
     states = {}
@@ -154,14 +167,22 @@ def timed_steps(fn, steps, warmup, barrier, dev):
     return elapsed, e0.elapsed_time(e1) * 1e-3, out
 
 
-def roofline(lifter, x, p, step_ms, reps=5):
+def roofline(lifter, x, p, step_ms, reps=5, fn=None, batch=None):
     """Per-launch HIP events (bracketing each launch on its stream) -> the dominant kernel's rate.
-    `step_ms`: device time of one step of the timed region; the launch durations are scaled to sum to it."""
+    `step_ms`: device time of one step of the timed region; the launch durations are scaled to sum to it.
+    `fn`: the forward to profile when it is not lifter(x, p) (UV mode).  The peak is the one of the arithmetic the
+    handles actually run (r3d_precision): an environment override cannot label a bf16x3 run f32."""
     agg = {}
-    lifter.profile(x, p)
+    dev = x.device
+    custom = fn is not None
+    fn = fn or (lambda: lifter(x, p))
+    batch = batch if batch is not None else x.shape[0]
+    prec = lifter.precision(dev)
+    peak = PEAK_FP32_MFMA_TFLOPS if prec == "f32" else PEAK_BF16X3_TFLOPS
+    lifter.profile_call(fn, dev)
     pair_ms = []
     for _ in range(reps):
-        for r in lifter.profile(x, p):
+        for r in lifter.profile_call(fn, dev):
             if r["kernel"] == "r3d_event_pair":        # the empty bracket: what the two event records cost
                 pair_ms.append(r["ms"])
                 continue
@@ -169,7 +190,7 @@ def roofline(lifter, x, p, step_ms, reps=5):
             a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["bytes"] += r["bytes"]; a["launches"] += 1
     pair = sorted(pair_ms)[len(pair_ms) // 2] if pair_ms else 0.0
     if os.environ.get("R3D_DUMP_LAUNCHES"):
-        for r in lifter.profile(x, p):
+        for r in lifter.profile_call(fn, dev):
             print("launch %2d %-20s blocks %5d  %8.1f us  %7.2f GFLOP  %6.1f TFLOP/s" % (
                 r["stage"], r["kernel"], r["blocks"], r["ms"] * 1e3, r["flops"] / 1e9,
                 r["flops"] / max(r["ms"], 1e-9) / 1e9), file=sys.stderr)
@@ -192,11 +213,14 @@ def roofline(lifter, x, p, step_ms, reps=5):
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
-            traffic = tj.get("batches", {}).get(str(x.shape[0]), {}).get(name)   # measured at that batch size only
+            # (PMC-measured for the RF-243 rays workload at that batch size only; other workloads: tj["workloads"][key])
+            traffic = tj.get("workloads", {}).get(custom, {}).get(name) if isinstance(custom, str) else \
+                (None if custom else tj.get("batches", {}).get(str(batch), {}).get(name))
         except Exception:
             traffic = None
-    return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+    return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
+            "peak_of": "fp32 MFMA (v_mfma_f32_32x32x2_f32)" if prec == "f32" else "bf16 MFMA / 6 products (bf16x3)",
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
             "launches_per_step": d["launches"] // reps,
             "avg_launch_us": round(ms / d["launches"] * 1e3, 2),
             "avg_launch_us_bracketed": round(d["ms"] / d["launches"] * 1e3, 2),
@@ -228,8 +252,8 @@ def bf16x3_line(dev, states, x, p, out_f32, args, barrier, cfg):
                "fp32_equivalent_TFLOPs": None}
         rl = roofline(lifter3, x, p, dev_s / args.steps * 1e3)
         res["fp32_equivalent_TFLOPs"] = rl["achieved"]
-        res["frac_of_fp32_mfma_peak"] = rl["frac"]
-        res["frac_of_bf16x3_peak"] = round(rl["achieved"] / (2500.0 / 6.0), 4)     # 2.5 PFLOP/s dense bf16, six products per fp32 product
+        res["frac_of_fp32_mfma_peak"] = round(rl["achieved"] / PEAK_FP32_MFMA_TFLOPS, 4)
+        res["frac_of_bf16x3_peak"] = rl["frac"]                    # 2.5 PFLOP/s dense bf16, six products per fp32 product
         if x.shape[0] == BATCH and not args.no_b1024:
             xb = torch.from_numpy(synth.synth_rays(1024, cfg, seed=100)).to(dev)
             pb = torch.from_numpy(synth.synth_param(1024, seed=0, vary=False)).to(dev)
@@ -240,6 +264,109 @@ def bf16x3_line(dev, states, x, p, out_f32, args, barrier, cfg):
             elb, _, _ = timed_steps(lambda: lifter3(xb, pb), nb, max(args.warmup // 2, 2), barrier, dev)
             res["b1024"] = {"value": round(1024 * nb / elb, 1), "ms_per_step": round(elb / nb * 1e3, 4)}
     del lifter3
+    return res
+
+
+def parity_gate(lifter, dev, batch):
+    """no timing counts before parity.  The reference's own outputs for the weights this bench
+    builds (seeds 1 / 2, decoder scale 1: tests/golden/model_j17_rf243_s3.npz, written by the reference's PyTorch-CPU
+    forward) against the HIP path - the fixture's windows tiled to the TIMED batch size, so that it is the timed launch
+    plan and tile schedule that is checked.  Returns (max abs error, max |reference|); exits above PARITY_ATOL."""
+    z = np.load(PARITY_FIXTURE)
+    reps = -(-batch // z["x"].shape[0])
+    x = np.tile(z["x"], (reps, 1, 1, 1))[:batch]
+    p = np.tile(z["param"], (reps, 1))[:batch]
+    ref = np.tile(z["out_pos"] + z["out_trj"], (reps, 1, 1, 1))[:batch]
+    with torch.no_grad():
+        out = lifter(torch.from_numpy(x).to(dev), torch.from_numpy(p).to(dev)).cpu().numpy()
+    err = float(np.abs(out.astype(np.float64) - ref).max())
+    if not np.isfinite(out).all() or err > PARITY_ATOL:
+        raise SystemExit("bench.py: parity gate failed: max abs error %.3e vs the reference fixture (bound %.0e) - nothing "
+                         "is timed on a path whose results differ from the reference's" % (err, PARITY_ATOL))
+    return err, float(np.abs(ref).max())
+
+
+def dhp_cameras():
+    """The 14 MPI-INF-3DHP cameras (lib/dataset/mpii_3dhp_dataset.py:9-251) from the reference-generated fixture."""
+    import ray3d_amd
+    z = np.load(os.path.join(ROOT, "tests", "golden", "cameras_3dhp.npz"))
+    return [ray3d_amd.Camera(z[t + "/K"], z[t + "/R"], z[t + "/t"], name=str(t)) for t in z["tags"]]
+
+
+def grid_cameras():
+    """The 342 cameras of the 'Train' augmentation grid (data/camera_augmentation.py:637-642) around H36M S1 / camera 1."""
+    import ray3d_amd
+    z = np.load(os.path.join(ROOT, "tests", "golden", "frontends.npz"))
+    K = np.array([[1145.51133842, 0, 514.968197319], [0, 1144.77392808, 501.882018537], [0, 0, 1.0]])
+    return ray3d_amd.camera_grid(K, z["grid/R0"], z["grid/T0"])
+
+
+WORKLOADS = {
+    # name: (ARCHITECTURE, joints, windows per step over all ranks, camera set, description)
+    "cfg4_rf9": ("3,3", 17, 1024, "3dhp",
+                 "BASELINE configs[3] as shipped (cfg_ray3d_3dhp_stage3.py:77-89: ARCHITECTURE '3,3', 9 frames, C=256): 17 joints, "
+                 "pixel keypoints in, one of the 14 MPI-INF-3DHP cameras per window, rays encoded in the first-level gather"),
+    "cfg4_rf243": ("3,3,3,3,3", 17, 1024, "3dhp",
+                   "BASELINE configs[3] at RF 243: 17 joints, pixel keypoints in, one of the 14 MPI-INF-3DHP cameras per window"),
+    "cfg5": ("3,3", 14, 4096, "grid",
+             "BASELINE configs[4]: 14-joint layout, RF 9, 4096 windows per step over all ranks, pixel keypoints in, one camera of the "
+             "342-camera augmentation grid (data/camera_augmentation.py:637-642) per window"),
+}
+
+
+def uv_workload(name, dev, world, rank, steps, warmup, barrier, want_rays_delta=True):
+    """One of WORKLOADS on this rank: build the pair, synthesise pixel windows + per-window cameras, check against the
+    rays mode (bit-identical by construction: the same float64 encode), time UV mode and rays mode, roofline of UV mode."""
+    from ray3d_amd import synth
+    arch, J, total, camset, desc = WORKLOADS[name]
+    B = max(total // world, 1)
+    lifter, states = build(dev, arch=arch, NUM_KPTS=J)
+    cfg = states["pos"][0]
+    rf = cfg.receptive_field
+    cams = dhp_cameras() if camset == "3dhp" else grid_cameras()
+    pick = [(5 * i + i // len(cams) + rank) % len(cams) for i in range(B)]
+    if camset == "3dhp":
+        uv = (2048.0 * synth.hash_uniform("bench.uv.%s.%d" % (name, rank), (B, rf, J, 2), 17)).astype(np.float32)
+    else:
+        rng = np.random.default_rng([14, rank])
+        w = rng.normal(0, 0.25, (B, 1, J, 3)) + np.array([0, 0, 1.0]) + 0.01 * np.cumsum(rng.normal(0, 1, (B, rf, 1, 3)), axis=1)
+        uv = np.stack([cams[c].project(w[i]) for i, c in enumerate(pick)]).astype(np.float32)
+    rows = np.stack([cams[c].cam_row() for c in pick])
+    par = np.stack([cams[c].param() for c in pick])
+    uvd, rowsd, pard = torch.from_numpy(uv).to(dev), torch.from_numpy(rows).to(dev), torch.from_numpy(par).to(dev)
+    run_uv = lambda: lifter.forward_uv(uvd, rowsd, pard)
+    res = {"workload": desc, "batch_per_gpu": B, "receptive_field": rf, "joints": J, "cameras": len(cams),
+           "input": "uv (pixels) + per-window camera rows"}
+    with torch.no_grad():
+        lifter.prepare([B], dev)
+        out = run_uv()
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        settle_clocks(run_uv, dev, group=10, max_groups=30)
+        el, dev_s, _ = timed_steps(run_uv, steps, warmup, barrier, dev)
+        res.update({"value": round(world * B * steps / el, 1), "unit": "poses/s", "ms_per_step": round(el / steps * 1e3, 4),
+                    "steps": steps})
+        rl = roofline(lifter, uvd, pard, dev_s / steps * 1e3, fn=run_uv, batch=B)
+        flops_step = rl["flops_per_launch"] * rl["launches_per_step"]
+        # which roof binds: the GEMMs have M = B rows (MLPs are 95 % of the FLOPs at RF 9) - matrix-bound when the
+        # weights' HBM stream (once per step) is shorter than the matrix time, weight-bandwidth-bound at small B
+        wbytes = sum(float(np.asarray(v).size) * 4 for st in (states["pos"][1], states["trj"][1]) for k, v in st.items()
+                     if k.endswith("weight") and np.asarray(v).ndim >= 2)
+        rl["binding_roof"] = {"mfma_us_at_peak": round(flops_step / (rl["peak"] * 1e12) * 1e6, 1),
+                              "weight_stream_us_at_8TBps": round(wbytes / (PEAK_HBM_GBS * 1e9) * 1e6, 1),
+                              "binds": "mfma" if flops_step / (rl["peak"] * 1e12) > wbytes / (PEAK_HBM_GBS * 1e9) else "hbm (weights)"}
+        res["roofline"] = rl
+        if want_rays_delta:
+            rays = np.stack([cams[c].rays_from_uv(uv[i].astype(np.float64)) for i, c in enumerate(pick)]).astype(np.float32)
+            rd = torch.from_numpy(rays).to(dev)
+            run_rays = lambda: lifter(rd, pard)
+            o2 = run_rays()
+            res["uv_equals_rays_mode"] = bool(torch.equal(out, o2))
+            settle_clocks(run_rays, dev, group=10, max_groups=10)
+            el2, _, _ = timed_steps(run_rays, steps, warmup, barrier, dev)
+            res["rays_mode"] = {"value": round(world * B * steps / el2, 1), "ms_per_step": round(el2 / steps * 1e3, 4)}
+            res["uv_vs_rays_ms_delta"] = round((el - el2) / steps * 1e3, 4)
+    del lifter
     return res
 
 
@@ -285,6 +412,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--mode", choices=("windows", "eval"), default="windows")
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--workload", choices=("cfg2",) + tuple(WORKLOADS), default="cfg2",
+                    help="windows mode: cfg2 = BASELINE configs[1] (the headline); cfg4_* / cfg5 = the shipped RF-9 configurations")
+    ap.add_argument("--no-shipped-cfgs", action="store_true", help="windows mode: skip the secondary cfg4 / cfg5 objects")
     ap.add_argument("--clips", type=int, default=EVAL_CLIPS, help="eval mode: number of clips in the set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b1024", action="store_true", help="windows mode: skip the roofline point at 1024 windows")
@@ -330,11 +460,44 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def all_ranks(v):
+        """[v of rank 0, v of rank 1, ...] on every rank."""
+        if dist is None:
+            return [v]
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        bucket = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(bucket, t)
+        return [float(b.item()) for b in bucket]
+
     from ray3d_amd import evaluate, synth
+    if args.mode == "windows" and args.workload != "cfg2":
+        # ---- one of the shipped configurations as the run's workload (rocprofv3 recipes use this form)
+        arch, J, total, camset, desc = WORKLOADS[args.workload]
+        res = uv_workload(args.workload, dev, world, rank, args.steps, args.warmup, barrier)
+        el = max_over_ranks(res["ms_per_step"])
+        per_rank = all_ranks(res["ms_per_step"])
+        if rank == 0:
+            B = res["batch_per_gpu"]
+            print(json.dumps({
+                "metric": "lifted poses/sec (%d-joint, %d-frame window)" % (J, res["receptive_field"]), "unit": "poses/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
+                "dtype": "f32" if "fp32" in res["roofline"]["peak_of"] else "bf16x3",
+                "data": "synthetic", "value": round(world * B / (el * 1e-3), 1), "ms_per_step": el, "scaling": "weak",
+                "config": {"workload": desc, "batch_per_gpu": B, "receptive_field": res["receptive_field"], "joints": J,
+                           "parallelism": "dp%d (independent window batches, no data-path collective)" % world,
+                           "world_size_observed": world if dist is None else dist.get_world_size(),
+                           "ms_per_step_per_rank": per_rank},
+                "roofline": res["roofline"], "rays_mode": res.get("rays_mode"), "uv_vs_rays_ms_delta": res.get("uv_vs_rays_ms_delta"),
+                "uv_equals_rays_mode": res.get("uv_equals_rays_mode")}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     lifter, states = build(dev)
     cfg = states["pos"][0]
     line = {"metric": "lifted poses/sec (17-joint, 243-frame window)", "unit": "poses/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None, "dtype": "f32",
+            "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
+            "dtype": lifter.precision(dev),    # what the handles actually compute in (r3d_precision): f32 unless R3D_BF16X3=1 / BF16X3
             "data": "synthetic"}
 
     if args.mode == "windows":
@@ -351,9 +514,13 @@ def main():
             prepare_ms = (time.perf_counter() - t0) * 1e3
             lifter(x, p)
             torch.cuda.synchronize()
+            # parity gate BEFORE the timed region (every rank: its own device runs its own copy of the weights)
+            parity_err, parity_ref = parity_gate(lifter, dev, args.batch)
             settle_steps = settle_clocks(lambda: lifter(x, p), dev)
-            elapsed, dev_s, out = timed_steps(lambda: lifter(x, p), args.steps, args.warmup, barrier, dev)
-        elapsed = max_over_ranks(elapsed)
+            elapsed_own, dev_s, out = timed_steps(lambda: lifter(x, p), args.steps, args.warmup, barrier, dev)
+        elapsed = max_over_ranks(elapsed_own)
+        per_rank_ms = all_ranks(elapsed_own / args.steps * 1e3)
+        parity_err = max_over_ranks(parity_err)
         assert torch.isfinite(out).all()
         if rank == 0:
             line.update({
@@ -364,7 +531,13 @@ def main():
                            "batch_per_gpu": args.batch, "receptive_field": 243, "joints": 17,
                            "parallelism": "dp%d (independent window batches, no data-path collective)" % world,
                            "schedule_build_ms": round(prepare_ms, 1),
-                           "clock_settle_steps": settle_steps}})
+                           "clock_settle_steps": settle_steps,
+                           "world_size_observed": world if dist is None else dist.get_world_size(),
+                           "ms_per_step_per_rank": [round(v, 4) for v in per_rank_ms]},
+                "parity_max_abs_err": parity_err,
+                "parity": {"max_abs_err_m": parity_err, "bound_m": PARITY_ATOL, "ref_max_abs_m": round(parity_ref, 3),
+                           "against": "tests/golden/model_j17_rf243_s3.npz (reference PyTorch-CPU outputs for these weights), "
+                                      "tiled to the timed batch size; checked before the timed region, on every rank (max)"}})
             # (the extras below must never cost the run its line: a failure in one of them is reported in its place)
             def guarded(key, fn):
                 try:
@@ -392,7 +565,13 @@ def main():
                     rb.update({"batch": 1024, "value": round(1024 * nb / el_b, 1), "ms_per_step": round(el_b / nb * 1e3, 4), "steps": nb})
                     return rb
                 guarded("roofline_b1024", _b1024)
-            if world == 1 and not args.no_bf16x3:
+            if world == 1 and args.batch == BATCH and not args.no_shipped_cfgs:
+                # the configurations the reference ships (every cfg file is RF 9): BASELINE configs[3] and configs[4]
+                nsh = max(args.steps // 2, 10)
+                guarded("cfg4", lambda: {"rf9": uv_workload("cfg4_rf9", dev, 1, 0, nsh, 3, barrier),
+                                         "rf243": uv_workload("cfg4_rf243", dev, 1, 0, max(nsh // 2, 5), 2, barrier)})
+                guarded("cfg5", lambda: uv_workload("cfg5", dev, 1, 0, nsh, 3, barrier))
+            if world == 1 and not args.no_bf16x3 and lifter.precision(dev) == "f32":
                 # secondary line: the same workload with r3d_config.bf16x3 = 1 - every big GEMM on the bf16 matrix cores with exact
                 # three-term splits of both operands (fp32-equivalent results: tests/test_gpu_parity.py holds it to the
                 # fp32 path's own error against a float64 reference).  Not the headline: `dtype` above stays f32.
@@ -431,8 +610,18 @@ def main():
 
         with torch.no_grad():
             one_pass()                          # first touch: workspace allocation
-            elapsed, dev_s, allrows = timed_steps(one_pass, args.steps, args.warmup, barrier, dev)
-        elapsed = max_over_ranks(elapsed)
+            elapsed_own, dev_s, allrows = timed_steps(one_pass, args.steps, args.warmup, barrier, dev)
+            # this rank's own pass (its clips, no gather, device time): what the shard costs without waiting for the others
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(dev))
+            for c, padded, prow, gt in mine:
+                evaluate.clip_partials_hip(lifter.forward_clip(padded, prow), c, aid[c.action], gt_dev=gt)
+            e1.record(torch.cuda.current_stream(dev))
+            e1.synchronize()
+            own_pass_ms = e0.elapsed_time(e1)
+        elapsed = max_over_ranks(elapsed_own)
+        per_rank_pass_ms = all_ranks(own_pass_ms)
+        shard_frames = [sum(lengths[i] for i in sh) for sh in shards]
         per = evaluate.reduce_partials(allrows)
         avg = evaluate.action_average(per)
         frames = sum(lengths)
@@ -446,6 +635,11 @@ def main():
                                        "metrics, one RCCL all_gather of the per-clip partial rows per pass" % (args.clips, frames),
                            "clips": args.clips, "frames": frames, "receptive_field": 243, "joints": 17,
                            "batch_sizes": sizes if world == 1 else None,
+                           "world_size_observed": world if dist is None else dist.get_world_size(),
+                           "shard_frames": shard_frames,
+                           "shard_imbalance": round(max(shard_frames) / (sum(shard_frames) / world), 4),   # max / mean frames per rank
+                           "pass_ms_per_rank": [round(v, 3) for v in per_rank_pass_ms],                    # device time of each rank's own clips
+                           "pass_ms_imbalance": round(max(per_rank_pass_ms) / (sum(per_rank_pass_ms) / world), 4),
                            "parallelism": "clips sharded over %d rank(s); collective = all_gather of %d x %d float64"
                                           % (world, args.clips, evaluate.PARTIAL_COLS)},
                 "mpjpe_mm": {"action_average": avg[0], "p_mpjpe": avg[1], "n_mpjpe": avg[2], "mpjve": avg[3], "mrpe": avg[4],

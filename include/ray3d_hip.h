@@ -41,7 +41,13 @@ extern "C" {
 
 /* Mirrors the constructor arguments the reference factory passes
  * (lib/model/__init__.py:23-46 -> lib/model/rie.py:178-181 / :443-446). */
+#define R3D_ABI_VERSION 3 /* bumped whenever a struct below changes size or layout: r3d_abi_version() returns the
+                           * library's; a binding compares it with the header it was written against       */
+
 typedef struct {
+    int32_t struct_size;   /* sizeof(r3d_config) of the CALLER's header: r3d_create rejects any other size, so a
+                            * binding built against an older (shorter) struct fails loudly instead of having
+                            * r3d_create read past its buffer                                             */
     int32_t kind;          /* R3D_KIND_POS | R3D_KIND_TRJ                               */
     int32_t num_joints;    /* NUM_KPTS: 14, 15 or 17                                    */
     int32_t in_features;   /* INPUT_DIM: 3 (rays) or 2                                  */
@@ -120,13 +126,21 @@ typedef struct {
     int64_t cam_stride;    /* doubles between consecutive windows' rows: 8, or 0 = broadcast */
 } r3d_input;
 
-/* Bytes of scratch HBM a forward of B windows needs (either model may be NULL). */
+/* Bytes of scratch HBM that suffice for every forward of AT MOST B windows (either model may be NULL): the maximum over
+ * the launch plans calls of 1..B windows can select (small calls run less fused plans with larger intermediates), so a
+ * caller may size its workspace once for its largest batch. */
 size_t r3d_workspace_bytes(const r3d_model *pos, const r3d_model *trj, int64_t B);
 
 /* Everything a forward of B windows needs besides its arguments - the launch plan of the pair and the tile schedule
  * of this batch size, uploaded - so that the forward itself only enqueues kernels (hipGraph capture, latency).
- * Either model may be NULL.  The library keeps the schedules of the 64 most recently used batch sizes per pair. */
+ * Either model may be NULL.
+ * Lifetime rule: the library caches the tile schedules (device memory) of the 64 most recently used batch sizes per
+ * pair and frees the least recently used one beyond that - EXCEPT sizes named in r3d_prepare, which stay resident
+ * until r3d_release (or until either model is destroyed): a hipGraph that captured a forward holds pointers into its
+ * size's schedule and never calls the library again, so prepare every size you capture and release it only after the
+ * graph is destroyed.  Never call r3d_prepare / a first forward of a new size while a stream is capturing. */
 int r3d_prepare(r3d_model *pos, r3d_model *trj, int64_t B);
+int r3d_release(r3d_model *pos, r3d_model *trj, int64_t B);   /* un-pins the size; R3D_ERR_ARG if it was never prepared */
 
 /* One network, exactly the reference module's forward:
  *   pos: out_dev (B,1,J,3)   lib/model/rie.py:284-434
@@ -183,6 +197,10 @@ int r3d_clip_metrics(const float *pred_dev, const float *gt_dev, int64_t n_frame
 
 const char *r3d_last_error(void);
 const char *r3d_version(void);
+int r3d_abi_version(void);                 /* R3D_ABI_VERSION the library was built with */
+/* The arithmetic the handle's large GEMMs actually run in: 0 = fp32 matrix cores, 1 = bf16x3 (r3d_config.bf16x3, or
+ * the R3D_BF16X3 environment override read at r3d_create).  bench.py labels its line with this, not with the field. */
+int r3d_precision(const r3d_model *m);
 
 /* ---- test hooks (tests/test_host.py; host only, no device needed) ---- */
 

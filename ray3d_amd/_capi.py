@@ -20,14 +20,15 @@ EXPORTS = (
     "r3d_create", "r3d_destroy", "r3d_num_weights", "r3d_weight_key", "r3d_weight_shape",
     "r3d_set_weight", "r3d_finalize", "r3d_workspace_bytes", "r3d_forward", "r3d_forward_pair",
     "r3d_profile_enable", "r3d_profile_read", "r3d_clip_metrics", "r3d_last_error", "r3d_version",
-    "r3d_prepare", "r3d_debug_schedule_check", "r3d_debug_plan_check",
+    "r3d_prepare", "r3d_release", "r3d_abi_version", "r3d_precision", "r3d_debug_schedule_check", "r3d_debug_plan_check",
 )
+ABI_VERSION = 3                                                          # R3D_ABI_VERSION of the header this binding follows
 METRIC_NAMES = ("mpjpe", "p_mpjpe", "n_mpjpe", "velocity", "root")     # R3D_METRIC_* order
 METRIC_OUT_DOUBLES = 5 * (1 + 128)                                      # R3D_METRIC_OUT_DOUBLES
 
 
 class Config(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("kind", "num_joints", "in_features", "num_levels",
+    _fields_ = [(n, C.c_int32) for n in ("struct_size", "kind", "num_joints", "in_features", "num_levels",
                                          "channels", "latent", "stage", "extrinsic_dim",
                                          "embed_dim", "causal", "dense", "bf16x3")]
 
@@ -74,6 +75,8 @@ def load():
     lib.r3d_forward.argtypes = [vp, C.POINTER(Input), C.c_int64, vp, vp, C.c_size_t, vp]
     lib.r3d_forward_pair.argtypes = [vp, vp, C.POINTER(Input), C.c_int64, vp, vp, vp, C.c_size_t, vp]
     lib.r3d_prepare.argtypes = [vp, vp, C.c_int64]
+    lib.r3d_release.argtypes = [vp, vp, C.c_int64]
+    lib.r3d_precision.argtypes = [vp]
     lib.r3d_profile_enable.argtypes = [vp, C.c_int]
     lib.r3d_profile_read.argtypes = [vp, C.POINTER(LaunchRecord), C.c_int]
     lib.r3d_clip_metrics.argtypes = [vp, vp, C.c_int64, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp, vp]
@@ -83,6 +86,9 @@ def load():
         fn = getattr(lib, name)
         if fn.restype is C.c_int or fn.restype is None:
             fn.restype = C.c_int
+    if lib.r3d_abi_version() != ABI_VERSION:
+        raise Ray3DHipError("%s has ABI version %d, this binding was written for %d: rebuild the library"
+                            % (LIB_PATH, lib.r3d_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 
@@ -98,7 +104,7 @@ class Handle:
 
     def __init__(self, cfg):
         lib = load()
-        c = Config(R3D_KIND_POS if cfg.kind == "pos" else R3D_KIND_TRJ, cfg.num_joints,
+        c = Config(C.sizeof(Config), R3D_KIND_POS if cfg.kind == "pos" else R3D_KIND_TRJ, cfg.num_joints,
                    cfg.in_features, len(cfg.filter_widths), cfg.channels, cfg.latent, cfg.stage,
                    cfg.extrinsic_dim if cfg.camera_embedding else 0,
                    cfg.embed_dim if cfg.camera_embedding else 0, 1 if cfg.causal else 0,
@@ -124,6 +130,10 @@ class Handle:
 
     def finalize(self):
         check(load().r3d_finalize(self.ptr), "r3d_finalize")
+
+    def precision(self) -> str:
+        """'f32' or 'bf16x3': what the handle's large GEMMs run in (r3d_config.bf16x3 or the R3D_BF16X3 override)."""
+        return "bf16x3" if check(load().r3d_precision(self.ptr), "r3d_precision") == 1 else "f32"
 
     def profile_enable(self, on: bool):
         check(load().r3d_profile_enable(self.ptr, 1 if on else 0), "r3d_profile_enable")
@@ -154,6 +164,11 @@ def workspace_bytes(pos: Optional[Handle], trj: Optional[Handle], batch: int) ->
 def prepare(pos: Optional[Handle], trj: Optional[Handle], batch: int):
     """r3d_prepare: plan + tile schedule of this batch size, uploaded (outside of any stream capture)."""
     check(load().r3d_prepare(pos.ptr if pos else None, trj.ptr if trj else None, batch), "r3d_prepare")
+
+
+def release(pos: Optional[Handle], trj: Optional[Handle], batch: int):
+    """r3d_release: un-pin a batch size named in prepare() (after the hipGraph that captured it is gone)."""
+    check(load().r3d_release(pos.ptr if pos else None, trj.ptr if trj else None, batch), "r3d_release")
 
 
 def make_input(mode, x_ptr, window_stride, param_ptr, param_stride, cam_ptr=None, cam_stride=0) -> Input:

@@ -330,6 +330,11 @@ extern "C" {
 
 int r3d_create(const r3d_config *cfg, r3d_model **out) {
     if (!cfg || !out) { set_error("r3d_create: null argument"); return R3D_ERR_ARG; }
+    if (cfg->struct_size != (int32_t)sizeof(r3d_config)) {
+        set_error("r3d_create: r3d_config.struct_size is %d, this library's r3d_config has %d bytes (ABI version %d): the "
+                  "binding was written against another include/ray3d_hip.h", cfg->struct_size, (int)sizeof(r3d_config), R3D_ABI_VERSION);
+        return R3D_ERR_ARG;
+    }
     Model *m = model_create(*cfg);
     if (!m) return R3D_ERR_ARG;
     *out = reinterpret_cast<r3d_model *>(m);
@@ -370,7 +375,12 @@ size_t r3d_workspace_bytes(const r3d_model *pos, const r3d_model *trj, int64_t B
     Model *t = const_cast<Model *>(reinterpret_cast<const Model *>(trj));
     Model *a = p ? p : t, *b = p ? t : nullptr;
     if (!a || B <= 0) return 0;
-    return workspace_need(plan_get(a, b, plan_kind(B)), B);
+    // monotonic in B: the plan kind switches with the window count and the less fused plans of small calls keep larger
+    // intermediates, so a call of fewer windows may need MORE bytes than one of B - the answer covers every size <= B
+    size_t need = workspace_need(plan_get(a, b, plan_kind(B)), B);
+    for (int64_t edge : plan_kind_edges())
+        if (edge < B) need = std::max(need, workspace_need(plan_get(a, b, plan_kind(edge)), edge));
+    return need;
 }
 
 int r3d_prepare(r3d_model *pos, r3d_model *trj, int64_t B) {
@@ -380,7 +390,18 @@ int r3d_prepare(r3d_model *pos, r3d_model *trj, int64_t B) {
     for (Model *m : {a, b})
         if (m && (!m->finalized || m->dirty)) { set_error("r3d_prepare called before r3d_finalize (or weights changed since)"); return R3D_ERR_STATE; }
     if (b && !same_input_shape(a, b)) { set_error("pos and trj models disagree on J / F / levels / extrinsic_dim"); return R3D_ERR_ARG; }
-    return schedule_get(plan_get(a, b, plan_kind(B)), B, device_cu_count()) ? R3D_OK : R3D_ERR_HIP;
+    return schedule_get(plan_get(a, b, plan_kind(B)), B, device_cu_count(), /*pin=*/true) ? R3D_OK : R3D_ERR_HIP;
+}
+
+int r3d_release(r3d_model *pos, r3d_model *trj, int64_t B) {
+    Model *p = reinterpret_cast<Model *>(pos), *t = reinterpret_cast<Model *>(trj);
+    Model *a = p ? p : t, *b = p ? t : nullptr;
+    if (!a || B <= 0) { set_error("r3d_release: no model given or B <= 0"); return R3D_ERR_ARG; }
+    Plan *pl = plan_get(a, b, plan_kind(B));
+    auto it = pl->schedules.find(B);
+    if (it == pl->schedules.end() || !it->second->pinned) { set_error("r3d_release: %lld windows were never prepared for this pair", (long long)B); return R3D_ERR_ARG; }
+    it->second->pinned = false;
+    return R3D_OK;
 }
 
 int r3d_forward(r3d_model *m, const r3d_input *in, int64_t B, float *out_dev, void *ws, size_t ws_bytes, void *stream) {
@@ -488,6 +509,12 @@ int r3d_debug_plan_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg,
         const StageSchedule &ss = stages[si];
         const auto &st = levels[si];
         if (ss.nwg < 1 || ss.nwg > 2 * nwg) return -3;
+        {   // a launch runs ONE kernel: its problems are all r3d_gemm_enc_f32's or none is
+            int n_enc = 0;
+            for (int e : st) n_enc += pl->probs[e & ~STAGE_SPILL_IN].enc_kernel ? 1 : 0;
+            if (n_enc != 0 && n_enc != (int)st.size()) return -11;
+            if ((n_enc != 0) != (ss.kind == STAGE_ENC)) return -12;
+        }
         for (int t = 0; t < ss.ntiles; ++t) {
             const int4 &tl = tiles[ss.tiles_off + t];
             const int slot = tl.x & 0xff, mi = tl.x >> 8, ks = tl.w;
@@ -532,6 +559,11 @@ int r3d_clip_metrics(const float *pred_dev, const float *gt_dev, int64_t n_frame
 }
 
 const char *r3d_last_error(void) { return r3d::last_error(); }
-const char *r3d_version(void) { return "ray3d_hip 0.1 (gfx950)"; }
+const char *r3d_version(void) { return "ray3d_hip 0.3 (gfx950, ABI 3)"; }
+int r3d_abi_version(void) { return R3D_ABI_VERSION; }
+int r3d_precision(const r3d_model *m) {
+    if (!m) { r3d::set_error("r3d_precision: null model"); return R3D_ERR_ARG; }
+    return reinterpret_cast<const Model *>(m)->use_b3 ? 1 : 0;
+}
 
 }  // extern "C"

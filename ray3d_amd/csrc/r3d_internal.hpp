@@ -236,6 +236,7 @@ struct StageSchedule {
 
 struct Schedule {
     int64_t B = 0;
+    bool pinned = false;   // named in r3d_prepare: never evicted (a captured hipGraph holds its device pointers) until r3d_release
     int spill_row0 = -1;   // rows [spill_row0, M) of Plan::spill_prob run in the following launch; -1: the plain
                            // level assignment (Plan::stages / stages_alt) is in use, else Plan::stages_spill / _alt
     const std::vector<std::vector<int>> *levels = nullptr;   // the assignment this schedule was built for
@@ -283,6 +284,7 @@ int model_set_weight(Model *m, const char *key, const float *host, const int64_t
 int model_finalize(Model *m);
 enum { PLAN_FUSED = 0, PLAN_SMALL = 1, PLAN_MEDIUM = 2, PLAN_LARGE = 3 };   // everything but the top level fused / nothing / first level only / the top level too (r3d_plan.cpp)
 int plan_kind(int64_t B);                       // the plan a call of B windows runs
+std::vector<int64_t> plan_kind_edges();         // the largest window count of every plan kind that has one (r3d_workspace_bytes)
 Plan *plan_get(Model *a, Model *b, int kind);
 void plans_drop(const Model *m);   // delete every cached plan (and its schedules) that names `m`
 constexpr int STAGE_SPILL_IN = 1 << 30;   // flag on a Plan::stages entry: the spilled rows of that problem
@@ -304,7 +306,7 @@ inline size_t frag_index(int o, int k, int nk) {
 }
 const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t B, int nwg, int &spill_row0, std::vector<int4> &tiles,
                                                         std::vector<int> &wgoff, std::vector<StageSchedule> &stages);
-Schedule *schedule_get(Plan *pl, int64_t B, int nwg);   // nullptr + set_error on failure
+Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin = false);   // nullptr + set_error on failure
 int device_cu_count();
 
 // kernel launchers (r3d_kernels.hip)

@@ -207,12 +207,19 @@ static Plan *build_plan(const Model *a, const Model *b, int kind) {
         if (!m) continue;
         Builder B{*pl, mi, *m};
         // the first pyramid level runs fused (r3d_kernels.hip, first_level_taps) when a tile can hold it: at least two
-        // levels, all channels in one 256-column tile, first-layer operand tile next to the intermediate
+        // levels, all channels in one 256-column tile, first-layer operand tile next to the intermediate.  Decided once
+        // for the PAIR (both models or neither): a launch is shared by the two models, and one that mixed the fused
+        // kernel's problems with r3d_gemm_enc_f32's could not be launched (pos and trj may differ in CHANNELS).
         {
-            int k0max = 0;
-            for (const auto &br : m->branches) k0max = std::max(k0max, br.k0pad);
-            B.first_level_fused = m->cfg.num_levels >= 2 && m->cfg.channels <= N_ALIGN && k0max <= 256 && !m->cfg.dense &&
-                                  !small && !env_on("R3D_NO_FIRST_FUSE");
+            auto can_fuse = [&](const Model *mm) {
+                int k0max = 0;
+                for (const auto &br : mm->branches) k0max = std::max(k0max, br.k0pad);
+                return mm->cfg.num_levels >= 2 && mm->cfg.channels <= N_ALIGN && k0max <= 256 && !mm->cfg.dense;
+            };
+            bool all = true;
+            for (const Model *mm : pl->m)
+                if (mm) all = all && can_fuse(mm);
+            B.first_level_fused = all && !small && !env_on("R3D_NO_FIRST_FUSE");
             B.fuse_pairs = (kind == PLAN_FUSED || kind == PLAN_LARGE) && !env_on("R3D_NO_PAIR_FUSE");
             B.fuse_top = kind == PLAN_LARGE;
         }
@@ -410,6 +417,14 @@ static std::map<std::pair<std::pair<uint64_t, uint64_t>, int>, Plan *> g_plans;
 // (0.379 against 0.383; 0.608 against 0.627 at 256).  From 1024 windows on the top pyramid level (one row per window)
 // has enough rows to run as a fused pair too (11 launches): 1.977 against 1.986 ms at 1024, 3.765 against 3.817 at 2048,
 // 7.430 against 7.459 at 4096; at 512 it loses (1.092 against 1.083).  bench.py --batch.
+static int64_t plan_env(const char *name, int64_t dflt) { const char *e = getenv(name); return e ? (int64_t)atoll(e) : dflt; }
+
+std::vector<int64_t> plan_kind_edges() {
+    std::vector<int64_t> e{plan_env("R3D_SMALL_PLAN_MAX", 48), plan_env("R3D_MEDIUM_PLAN_MAX", 96), plan_env("R3D_LARGE_PLAN_MIN", 1024) - 1};
+    e.erase(std::remove_if(e.begin(), e.end(), [](int64_t v) { return v < 1; }), e.end());
+    return e;
+}
+
 int plan_kind(int64_t B) {
     static const int64_t small_max = [] { const char *e = getenv("R3D_SMALL_PLAN_MAX"); return e ? (int64_t)atoll(e) : (int64_t)48; }();
     static const int64_t medium_max = [] { const char *e = getenv("R3D_MEDIUM_PLAN_MAX"); return e ? (int64_t)atoll(e) : (int64_t)96; }();

@@ -438,22 +438,34 @@ const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t
     return levels;
 }
 
-Schedule *schedule_get(Plan *pl, int64_t B, int nwg) {
+Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
     auto it = pl->schedules.find(B);
     if (it != pl->schedules.end()) {
         // least recently USED goes first: a hit moves the size to the back of the queue
         auto pos = std::find(pl->schedule_lru.begin(), pl->schedule_lru.end(), B);
         if (pos != pl->schedule_lru.end() && pos + 1 != pl->schedule_lru.end()) std::rotate(pos, pos + 1, pl->schedule_lru.end());
+        if (pin) it->second->pinned = true;
         return it->second;
     }
-    // bound the cache at 64 batch sizes: the least recently used one goes; its launches may still be in flight on
-    // any stream, hence the device-wide synchronisation before its tile lists are freed
-    if (pl->schedule_lru.size() >= 64) {
-        const int64_t old = pl->schedule_lru.front();
-        pl->schedule_lru.erase(pl->schedule_lru.begin());
-        (void)hipDeviceSynchronize();
-        delete pl->schedules[old];
-        pl->schedules.erase(old);
+    // The cache is bounded at 64 UNPINNED batch sizes: the least recently used one goes.  Sizes named in r3d_prepare are
+    // pinned - a captured hipGraph replays kernels whose arguments point into the schedule and never comes back here -
+    // and do not count.  The victim's launches may still be in flight on any stream, hence the device-wide
+    // synchronisation before its tile lists are freed; when that fails (another stream is capturing, a sticky error)
+    // nothing is freed and the cache grows by one instead.
+    {
+        size_t unpinned = 0;
+        for (int64_t b : pl->schedule_lru) unpinned += pl->schedules[b]->pinned ? 0 : 1;
+        if (unpinned >= 64) {
+            auto victim = std::find_if(pl->schedule_lru.begin(), pl->schedule_lru.end(), [&](int64_t b) { return !pl->schedules[b]->pinned; });
+            if (victim != pl->schedule_lru.end() && hipDeviceSynchronize() == hipSuccess) {
+                const int64_t old = *victim;
+                pl->schedule_lru.erase(victim);
+                delete pl->schedules[old];
+                pl->schedules.erase(old);
+            } else {
+                (void)hipGetLastError();       // (the failed synchronisation is not this call's error)
+            }
+        }
     }
     Schedule *s = new Schedule();
     s->B = B;
@@ -469,6 +481,7 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg) {
         delete s;
         return nullptr;
     }
+    s->pinned = pin;
     pl->schedules[B] = s;
     pl->schedule_lru.push_back(B);
     return s;

@@ -405,19 +405,49 @@ class Ray3DLifter(nn.Module):
         if cam.dim() == 2 and cam.shape != (B, 8) or cam.dim() == 1 and cam.shape != (8,):
             raise RuntimeError("cam_rows must be (%d, 8) or (8,), got %s" % (B, tuple(cam.shape)))
         p = param.detach().to(uv.device, torch.float32).contiguous() if self.pos.camera_embedding else None
-        return self._run(_capi.R3D_INPUT_UV, uv, ws_, B, p,
-                         0 if (p is None or p.dim() == 1) else self.pos.extrinsic_dim,
-                         cam, 0 if cam.dim() == 1 else 8)
+        pstride = 0 if (p is None or p.dim() == 1) else self.pos.extrinsic_dim
+        cstride = 0 if cam.dim() == 1 else 8
+        if uv.dim() == 4:
+            return self._run(_capi.R3D_INPUT_UV, uv, ws_, B, p, pstride, cam, cstride)
+        # a frame sequence: every clip has its own length, and the library keeps one tile schedule per batch size - the
+        # windows are lifted in the batch sizes of clip_batch_sizes (as forward_clip does), the surplus ones sliding over
+        # repeated last frames with the last window's camera, their poses cut off
+        sizes = self.clip_batch_sizes(B)
+        total = sum(sizes)
+        if total == B and len(sizes) == 1:
+            return self._run(_capi.R3D_INPUT_UV, uv, ws_, B, p, pstride, cam, cstride)
+        if total > B:
+            uv = torch.cat([uv, uv[-1:].expand((total - B) * ws_, -1, -1)], dim=0)
+            if cstride:
+                cam = torch.cat([cam, cam[-1:].expand(total - B, -1)], dim=0).contiguous()
+            if pstride:
+                p = torch.cat([p, p[-1:].expand(total - B, -1)], dim=0).contiguous()
+        out = torch.empty((total, 1, self.pos.num_joints_in, 3), dtype=torch.float32, device=uv.device)
+        start = 0
+        for b in sizes:
+            self._run(_capi.R3D_INPUT_UV, uv[start * ws_:], ws_, b, p[start:] if pstride else p, pstride,
+                      cam[start:] if cstride else cam, cstride, out=out[start:start + b])
+            start += b
+        return out[:B]
 
     def profile(self, x, param):
         """One forward with per-launch HIP events; returns the launch records."""
-        h = self.pos.handle(x.device)
+        return self.profile_call(lambda: self.forward(x, param), x.device)
+
+    def profile_call(self, fn, device):
+        """`fn()` (one forward through this lifter, any entry point) with per-launch HIP events; the launch records."""
+        h = self.pos.handle(torch.device(device))
         h.profile_enable(True)
         try:
-            self.forward(x, param)
+            fn()
             return h.profile_read()
         finally:
             h.profile_enable(False)
+
+    def precision(self, device) -> str:
+        """'f32' or 'bf16x3': the arithmetic the large GEMMs of this pair run in on `device` (r3d_precision)."""
+        kinds = {self.pos.handle(torch.device(device)).precision(), self.trj.handle(torch.device(device)).precision()}
+        return "f32" if kinds == {"f32"} else "bf16x3"
 
 
 def load_weight(model, pretrained: Dict[str, torch.Tensor]):

@@ -14,6 +14,55 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Measured parity errors, one line per checked configuration: tests call record_parity(); the terminal summary prints
+# them (so a run's tail shows numbers, not dots) and gpurun_out/parity_errors.json keeps them when that directory exists.
+PARITY = []
+
+
+def record_parity(label, err, tol, ref_max=None):
+    PARITY.append((str(label), float(err), float(tol), None if ref_max is None else float(ref_max)))
+
+
+def check_parity(got, ref, what="", tol=None, atol=1e-4):
+    """max |got - ref| <= tol, recorded under the running test's name (+ `what`).  Default bound: north_star's 1e-4 abs
+    for outputs of up to 10 m (the literal bound), the same relative to 10 m for the deliberately over-scaled cases."""
+    label = os.environ.get("PYTEST_CURRENT_TEST", "?").split("::", 1)[-1].split(" (")[0] + ((" " + what) if what else "")
+    if hasattr(got, "detach"):
+        got = got.detach().cpu().numpy()
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape, (label, got.shape, ref.shape)
+    ref_max = float(np.abs(ref).max()) if ref.size else 0.0
+    if tol is None:
+        tol = atol * max(1.0, ref_max / 10.0)
+    err = float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()) if ref.size else 0.0
+    record_parity(label, err, tol, ref_max)
+    assert np.isfinite(got).all(), label
+    assert err <= tol, "%s: max abs err %.3e > %.3e (|ref| max %.2f)" % (label, err, tol, ref_max)
+    return err
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if not PARITY:
+        return
+    tr = terminalreporter
+    tr.section("parity: measured max abs error per configuration (bound 1e-4 abs up to 10 m)")
+    worst = {}
+    for label, err, tol, ref_max in PARITY:
+        w = worst.get(label)
+        if w is None or err > w[0]:
+            worst[label] = (err, tol, ref_max)
+    for label, (err, tol, ref_max) in worst.items():
+        tr.write_line("parity %-88s err %.2e  bound %.2e%s" % (label, err, tol, "" if ref_max is None else "  |ref|max %.2f" % ref_max))
+    lit = [e for (e, t, r) in worst.values() if r is not None and r <= 10.0]
+    tr.write_line("parity summary: %d configurations, worst err %.2e; %d at the literal 1e-4 bound (|ref| <= 10 m), worst %.2e"
+                  % (len(worst), max(e for e, _, _ in worst.values()), len(lit), max(lit) if lit else 0.0))
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+        with open(os.path.join(out_dir, "parity_errors.json"), "w") as f:
+            json.dump([{"config": k, "max_abs_err": v[0], "bound": v[1], "ref_max": v[2]} for k, v in worst.items()], f, indent=1)
+
+
 def _parse(v):
     if v in ("True", "False"):
         return v == "True"

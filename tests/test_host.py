@@ -84,9 +84,14 @@ def test_create_rejects_unsupported_configs():
         _capi.Handle(config_from_dicts(default_model_config(ARCHITECTURE="3,3,3,3,3", DENSE=True, DISABLE_OPTIMIZATIONS=True), "pos"))
     assert config_from_dicts(default_model_config(DISABLE_OPTIMIZATIONS=True), "pos").residual_tap == 1
     assert config_from_dicts(default_model_config(DISABLE_OPTIMIZATIONS=True, CAUSAL=True), "trj").residual_tap == 2
-    bad = _capi.Config(0, 17, 3, 2, 256, 256, 3, 2, 64, 7, 0, 0)
+    bad = _capi.Config(_capi.C.sizeof(_capi.Config), 0, 17, 3, 2, 256, 256, 3, 2, 64, 7, 0, 0)
     with pytest.raises(_capi.Ray3DHipError, match="causal"):
         _capi.check(_capi.load().r3d_create(_capi.C.byref(bad), _capi.C.byref(_capi.C.c_void_p())), "r3d_create")
+    # a binding built against an older, shorter r3d_config (no struct_size / fewer fields) is refused, not mis-read
+    old = _capi.Config(0, 17, 3, 2, 256, 256, 3, 2, 64, 0, 0, 0, 0)
+    with pytest.raises(_capi.Ray3DHipError, match="struct_size"):
+        _capi.check(_capi.load().r3d_create(_capi.C.byref(old), _capi.C.byref(_capi.C.c_void_p())), "r3d_create")
+    assert _capi.load().r3d_abi_version() == _capi.ABI_VERSION and b"ABI 3" in _capi.load().r3d_version()
 
 
 def test_forward_before_finalize_fails():
@@ -545,6 +550,40 @@ def test_plan_tile_lists_cover_every_problem_once(monkeypatch):
     _plan_check(default_model_config(ARCHITECTURE="3,3,3", DENSE=True, DISABLE_OPTIMIZATIONS=True), [1, 50, 256])
     monkeypatch.setenv("R3D_NO_SPILL", "1")
     assert all(s == 0 for _, s in _plan_check(mc, [100, 256, 1024]))
+
+
+def test_workspace_bytes_is_monotonic_in_the_batch():
+    """A C caller sizes its workspace once for its largest batch: r3d_workspace_bytes(B) must cover every call of fewer
+    windows too, although those select less fused plans with larger intermediates (the plan switches at 48 / 96 / 1024)."""
+    for mc in (default_model_config(ARCHITECTURE="3,3,3,3,3"), default_model_config(ARCHITECTURE="3,3", NUM_KPTS=14),
+               default_model_config(ARCHITECTURE="3,3,3", CHANNELS=512)):
+        hp, ht = _capi.Handle(config_from_dicts(mc, "pos")), _capi.Handle(config_from_dicts(mc, "trj"))
+        for pair in ((hp, ht), (hp, None), (None, ht)):
+            prev = 0
+            for B in list(range(1, 130)) + [255, 256, 511, 1000, 1023, 1024, 1025, 4096]:
+                need = _capi.workspace_bytes(pair[0], pair[1], B)
+                assert need >= prev > -1, (mc["ARCHITECTURE"], B, need, prev)
+                prev = need
+        hp.close()
+        ht.close()
+
+
+def test_pairs_with_different_channel_counts_get_one_first_level_kind():
+    """The first level is fused for the pair or for neither model: pos with 256 channels (fusable) next to a trajectory
+    model with 512 (not) must not put r3d_gemm_f32 and r3d_gemm_enc_f32 problems into one launch."""
+    lib = _capi.load()
+    fn = lib.r3d_debug_plan_check
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    fn.restype = ctypes.c_int
+    mc = default_model_config(ARCHITECTURE="3,3,3")
+    n, sp = ctypes.c_int(), ctypes.c_int()
+    for cp, ct in ((256, 512), (512, 256), (128, 256)):
+        hp = _capi.Handle(config_from_dicts(dict(mc, CHANNELS=cp), "pos"))
+        ht = _capi.Handle(config_from_dicts(dict(mc, CHANNELS=ct), "trj"))
+        for B in (8, 64, 200, 1024):
+            assert fn(hp.ptr, ht.ptr, B, 256, ctypes.byref(n), ctypes.byref(sp)) == 0, (cp, ct, B)
+        hp.close()
+        ht.close()
 
 
 def test_plans_do_not_outlive_a_partner_model():
