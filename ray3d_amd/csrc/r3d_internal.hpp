@@ -82,6 +82,39 @@ struct LaunchArgs {
     GemmProb p[MAX_PROB];
 };
 
+// ---- the whole forward as ONE persistent launch (r3d_forward_f32): tiles of every DAG level in one list per workgroup,
+// ordered by tile-level dependencies instead of kernel boundaries.  The network is row-local - a tile of rows R of layer L
+// reads rows of layer L-1 that belong to the same windows - so a tile waits for exactly the producer tiles of its
+// windows: one ready counter per (problem, 32-row unit) in the caller's workspace counts finished 64-column granules.
+constexpr int FWD_TILE_INT4 = 6;        // a tile descriptor: 24 ints (below)
+constexpr int FWD_MAX_DEP = 8;
+// ints of a descriptor: [0] problem | units << 8   [1] first row   [2] first column   [3] split-K factor
+//                       [4] number of dependency ranges   [5] index of the first unit's ready counter
+//                       [6] granules (64 columns) this tile adds to each of its units' counters   [7] unused
+//                       [8 + 2d] first counter of range d   [9 + 2d] counters in the range | granules required << 16
+struct FwdArgs {
+    const int4 *tiles;        // FWD_TILE_INT4 int4 per tile
+    const int *wg_off;        // [grid + 1]: workgroup b executes tiles [wg_off[b], wg_off[b+1])
+    const GemmProb *probs;    // the call's problem table (absolute pointers; written by r3d_bind_f32 ahead of the launch)
+    unsigned *cnt;            // ready counters, zeroed by r3d_bind_f32; cnt[ncnt] is the abort flag (a spin gave up)
+    int ncnt;
+    int pad_;
+    long long *dbg;
+};
+constexpr int BIND_NPTR = 18;  // pointer fields of a GemmProb, in the order r3d_bind_f32 walks them
+enum { BIND_NULL = 0, BIND_WS, BIND_ARENA0, BIND_ARENA1, BIND_IARENA0, BIND_IARENA1, BIND_X, BIND_PARAM, BIND_CAM, BIND_NBASE };
+struct BindArgs {
+    const GemmProb *rel;           // problems with byte OFFSETS in their pointer fields
+    const unsigned char *tags;     // [nprob][BIND_NPTR]: which base each pointer field is relative to (BIND_*)
+    GemmProb *out;
+    unsigned *cnt;
+    int nprob, ncnt;
+    const void *base[BIND_NBASE];
+    long long enc_ws, cam_stride;  // per call: window stride in elements, doubles between camera rows
+    unsigned enc_bytes;
+    int param_stride;
+};
+
 constexpr int MAX_DEC = 6;     // 5 body-part decoders + the trajectory decoder
 // Fused decoder tail: the last Linear (1024 -> 3*n_g) of every Integration block, the joint
 // reassembly (rie.py:415-432) and the trajectory add (trainer.py:353) in one pass.
@@ -97,6 +130,7 @@ struct DecodeArgs {
     long long B;
     float *out;                // pos: (B, J, 3);  trj-only: (B, 3)
     float *out_trj;            // optional (B, 3)
+    const unsigned *abort_flag;   // single-launch forward: nonzero when a dependency spin gave up - the outputs become NaN
     int slot[5 * 16];          // flat pos output index -> element of (J,3) it lands in
 };
 
@@ -243,6 +277,18 @@ struct Schedule {
     std::vector<StageSchedule> stages;
     int4 *d_tiles = nullptr;
     int *d_wgoff = nullptr;
+    // single-launch form (empty / null when the plan has launches it cannot hold: r3d_gemm_enc_f32 stages)
+    struct Fwd {
+        int grid = 0, ntiles = 0, ncnt = 0, nprob = 0;
+        std::vector<int> prob_of_slot;        // table index -> Plan::probs index
+        std::vector<int> cnt_base;            // per table index: first ready counter
+        int4 *d_tiles = nullptr;              // FWD_TILE_INT4 int4 per tile
+        int *d_wgoff = nullptr;
+        GemmProb *d_rel[2] = {nullptr, nullptr};        // relative problem tables: rays mode / UV mode (built on first use)
+        unsigned char *d_tags[2] = {nullptr, nullptr};
+        double flops = 0, bytes = 0;
+        bool uses_gather = false;             // some problem gathers from the input (UV mode selects the _uv kernel)
+    } fwd;
     ~Schedule();
 };
 
@@ -313,6 +359,10 @@ int device_cu_count();
 enum { STAGE_BIG = 0, STAGE_ENC = 1 };   // r3d_gemm_f32 / r3d_gemm_enc_f32
 hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, int kind, bool uv, hipStream_t stream);   // uv: the launch gathers pixel keypoints
 hipError_t launch_decode(const DecodeArgs &args, hipStream_t stream);
+hipError_t launch_forward(const FwdArgs &args, int nwg, bool uv, hipStream_t stream);
+hipError_t launch_bind(const BindArgs &args, hipStream_t stream);
+bool forward_single_launch();   // the single-launch form is in use (R3D_STAGED=1 turns it off)
+size_t fwd_ctrl_bytes(const Plan *pl, int64_t B);   // workspace bytes behind the activations: counters + problem table
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 

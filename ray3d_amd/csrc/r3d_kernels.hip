@@ -29,6 +29,9 @@
 //  (lib/camera/camera.py:423-471) - with the camera of the window the operand row belongs to.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <type_traits>
+
 #include "r3d_internal.hpp"
 
 namespace r3d {
@@ -54,6 +57,36 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 gload4(const float *p) { return *(const R3D_AS1 f32x4 *)p; }
 __device__ __forceinline__ float gload1(const float *p) { return *(const R3D_AS1 float *)p; }
 __device__ __forceinline__ void gstore1(float *p, float v) { *(R3D_AS1 float *)p = v; }
+// Activations are handed from tile to tile INSIDE a launch (r3d_forward_f32: the whole forward is one launch, tiles
+// ordered by ready counters), possibly across XCDs whose L2s are not coherent with each other and always across CUs
+// whose L1s are never refreshed: every activation store is write-through (sc1) and every activation load bypasses the
+// L1 (sc1) - MI355X_MICROARCH.md, inter-workgroup visibility: "sc1 payload, every storing wave drains, one flag".
+// Weights, biases, tables and the raw input are read-only for the whole launch: plain loads.
+constexpr int ACT_AUX = 16;                  // aux bits of the buffer builtins: sc1
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned R3D_AS1 *gu32;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t act_rsrc(const float *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 act_load4(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, ACT_AUX));
+}
+__device__ __forceinline__ float act_load1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, ACT_AUX));
+}
+__device__ __forceinline__ void act_store4(__amdgpu_buffer_rsrc_t r, int byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, ACT_AUX);
+}
+__device__ __forceinline__ void act_store1(__amdgpu_buffer_rsrc_t r, int byte_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, ACT_AUX);
+}
+// A tile is finished when its write-through stores have left the CU: every storing wavefront drains, a barrier, then
+// one relaxed agent-scope add per 32-row unit on the unit's ready counter (granules of 64 columns).  The callers'
+// barrier is the one that ends the tile anyway.
+__device__ __forceinline__ void tile_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void tile_signal(const gu32 cnt, const int sig_base, const int sig_add, const int units) {
+    if ((int)threadIdx.x < units) __hip_atomic_fetch_add(cnt + sig_base + threadIdx.x, (unsigned)sig_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // LeakyReLU for slopes in (0, 1] (0.2, 0.01; 1 = linear layer): max(v, slope v) - a multiply and a max instead of
 // multiply, compare, select
 __device__ __forceinline__ float lrelu(const float v, const float slope) { return __builtin_fmaxf(v, v * slope); }
@@ -119,8 +152,10 @@ __device__ __forceinline__ void store_tile(ProbRef P, const f32x16 (&acc)[MI], c
     const int M = P.M, N = P.N;
     const float slope = second ? P.slope2 : P.slope;
     const float *res = P.res;
-    float *c = P.c;
     const int ldc = P.ldc, ldr = P.ldr;
+    // (descriptors based at the tile's first element: per-lane offsets stay small and the accesses carry sc1)
+    const __amdgpu_buffer_rsrc_t crs = act_rsrc(P.c + (size_t)row0 * ldc + col0);
+    const __amdgpu_buffer_rsrc_t rrs = act_rsrc(res ? res + (size_t)row0 * ldr + col0 : P.c);
     const bool writer = wave < WN;                // the wavefronts of K phase 0 hold the sums
     const float bias = writer ? gload1((second ? P.bias2 : P.bias) + col0 + wave * 32 + li) : 0.0f;
     float *wr = lds + (4 * lh) * EPI_LD + wave * 32 + li;
@@ -144,14 +179,15 @@ __device__ __forceinline__ void store_tile(ProbRef P, const f32x16 (&acc)[MI], c
             if (row >= M) continue;
             f32x4 v = *reinterpret_cast<const f32x4 *>(lds + lr * EPI_LD + rd_c4);
             const int col = col0 + rd_c4;
+            const int lrow = mi * 32 + lr;
             if (vec) {
-                if (res) v += gload4(res + (size_t)row * ldr + col);
-                // (streaming store: the consumer is the next launch, mostly on other XCDs - no use for the line in this L2)
-                __builtin_nontemporal_store(v, (R3D_AS1 f32x4 *)(c + (size_t)row * ldc + col));
+                if (res) v += act_load4(rrs, (lrow * ldr + rd_c4) * 4);
+                // (write-through: the consumer is another workgroup, mostly on another XCD - no use for the line in this L2)
+                act_store4(crs, (lrow * ldc + rd_c4) * 4, v);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (col + e < N) gstore1(c + (size_t)row * ldc + col + e, v[e] + (res ? gload1(res + (size_t)row * ldr + col + e) : 0.0f));
+                    if (col + e < N) act_store1(crs, (lrow * ldc + rd_c4 + e) * 4, v[e] + (res ? act_load1(rrs, (lrow * ldr + rd_c4 + e) * 4) : 0.0f));
             }
         }
     }
@@ -254,7 +290,7 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
         const int kb = kt * (BK * KS) - seg_k0;
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff[i], kb * 4, 0));
+            R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff[i], kb * 4, ACT_AUX));
     };
     const int st_off = srow * LDS_LD + a_kq;
     auto commit_a = [&](int stage, const Staged &R) {
@@ -576,7 +612,7 @@ __device__ __forceinline__ void gemm_tile_b3(ProbRef P, const int row0, const in
         const int kb = kt * BK - seg_k0;
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff[i], kb * 4, 0));
+            R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff[i], kb * 4, ACT_AUX));
     };
     // registers -> ring stage: split into three bf16 planes (exact: each remainder is representable in fp32)
     const int st_off = srow * B3_LD + (a_kq >> 1);
@@ -759,7 +795,7 @@ __device__ __forceinline__ void gemm_tile_b3p(ProbRef P, const int row0, const i
         const int kb = kt * BK - seg_k0;
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff[i], kb * 4, 0));
+            R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff[i], kb * 4, ACT_AUX));
         ++a_next;
         prep_seg(a_next < last ? a_next : last);
     };
@@ -986,7 +1022,7 @@ __device__ __forceinline__ void gemm_tile_b3t(ProbRef P, const int row0, float *
     auto issue_a = [&](int kt, Staged &R) {
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff[i], kt * BK * 4, 0));
+            R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff[i], kt * BK * 4, ACT_AUX));
     };
     const int st_off = srow * B3_LD + (a_kq >> 1);
     auto commit_a = [&](int stage, const Staged &R) {
@@ -1100,18 +1136,21 @@ __device__ __forceinline__ void gemm_tile_b3t(ProbRef P, const int row0, float *
         const int rd_row = tid >> 6, rd_c4 = (tid & 63) * 4;
         const int N = P.N;
         const float *res = P.res;
+        const int ldc = P.ldc, ldr = P.ldr;
+        const __amdgpu_buffer_rsrc_t crs = act_rsrc(P.c + (size_t)row0 * ldc);
+        const __amdgpu_buffer_rsrc_t rrs = act_rsrc(res ? res + (size_t)row0 * ldr : P.c);
 #pragma unroll
         for (int j = 0; j < 4 * MI; ++j) {
             const int lr = rd_row + 8 * j, row = row0 + lr;
             if (row >= M) continue;
             f32x4 v = *reinterpret_cast<const f32x4 *>(smem + lr * PAIR_LD + rd_c4);
             if (rd_c4 + 4 <= N) {
-                if (res) v += gload4(res + (size_t)row * P.ldr + rd_c4);
-                __builtin_nontemporal_store(v, (R3D_AS1 f32x4 *)(P.c + (size_t)row * P.ldc + rd_c4));
+                if (res) v += act_load4(rrs, (lr * ldr + rd_c4) * 4);
+                act_store4(crs, (lr * ldc + rd_c4) * 4, v);
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if (rd_c4 + c < N) gstore1(P.c + (size_t)row * P.ldc + rd_c4 + c, v[c] + (res ? gload1(res + (size_t)row * P.ldr + rd_c4 + c) : 0.0f));
+                    if (rd_c4 + c < N) act_store1(crs, (lr * ldc + rd_c4 + c) * 4, v[c] + (res ? act_load1(rrs, (lr * ldr + rd_c4 + c) * 4) : 0.0f));
             }
         }
     }
@@ -1318,7 +1357,7 @@ constexpr int FLT_LUT_OFF = FLT_H_FLOATS + 2 * FLT_G_FLOATS;
 static_assert((FLT_LUT_OFF + FL_LUT_INTS) * 4 <= GEMM_LDS_BYTES, "the tap-wise first level fits the GEMM kernel's LDS allocation");
 
 template <int MI, bool MULTI, bool UV>   // MULTI: K0 > 64 (several 64-column chunks per tap: the trajectory model)
-__device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_list, const int ntiles, const bool new_prob, float *smem,
+__device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_list, const int tstride, const int ntiles, const bool new_prob, float *smem, const gu32 cnt,
                                                  long long *dbg_base) {
     static_assert(MI >= 1 && MI <= FLT_MAX_MI, "tile height");
     int tid = threadIdx.x;
@@ -1417,8 +1456,8 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
     issue_phase(__builtin_amdgcn_readfirstlane(tile_list[0].y), 0, 0);
 #pragma unroll 1
     for (int ti = 0; ti < ntiles; ++ti) {
-        const int row0 = __builtin_amdgcn_readfirstlane(tile_list[ti].y);
-        const int next_row0 = ti + 1 < ntiles ? __builtin_amdgcn_readfirstlane(tile_list[ti + 1].y) : -1;
+        const int row0 = __builtin_amdgcn_readfirstlane(tile_list[ti * tstride].y);
+        const int next_row0 = ti + 1 < ntiles ? __builtin_amdgcn_readfirstlane(tile_list[(ti + 1) * tstride].y) : -1;
 #ifdef R3D_TIMING
         long long *dbg = dbg_base && ti < 8 ? dbg_base + ti * 8 : nullptr;
 #else
@@ -1603,22 +1642,28 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
         __syncthreads();
         {
             const int rd_row = tid >> 6, rd_c4 = (tid & 63) * 4;
-            const int N = P.N;
+            const int N = P.N, ldc = P.ldc;
+            const __amdgpu_buffer_rsrc_t crs = act_rsrc(P.c + (size_t)row0 * ldc);
 #pragma unroll
             for (int j = 0; j < 4 * MI; ++j) {
                 const int lr = rd_row + 8 * j, row = row0 + lr;
                 if (row >= M) continue;
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(H + lr * PAIR_LD + rd_c4);
                 if (rd_c4 + 4 <= N) {
-                    __builtin_nontemporal_store(v, (R3D_AS1 f32x4 *)(P.c + (size_t)row * P.ldc + rd_c4));
+                    act_store4(crs, (lr * ldc + rd_c4) * 4, v);
                 } else {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        if (rd_c4 + c < N) gstore1(P.c + (size_t)row * P.ldc + rd_c4 + c, v[c]);
+                        if (rd_c4 + c < N) act_store1(crs, (lr * ldc + rd_c4 + c) * 4, v[c]);
                 }
             }
         }
+        if (cnt) tile_drain();
         __syncthreads();                                     // H is free for the next tile's activations
+        if (cnt) {
+            const int4 te = tile_list[ti * tstride + 1];     // {dependencies (none), first ready counter, granules, -}
+            tile_signal(cnt, __builtin_amdgcn_readfirstlane(te.y), __builtin_amdgcn_readfirstlane(te.z), MI);
+        }
         R3D_TSTAMP(4);
     }
     (void)M0;
@@ -1648,7 +1693,7 @@ static_assert(FLB_LUT_OFF + FL_LUT_INTS * 4 <= GEMM_LDS_BYTES, "the bf16x3 first
 static_assert(FLT_MAX_MI * 32 * PAIR_LD * 4 <= FLB_G_OFF, "the fp32 output rows are staged over the H planes");
 
 template <int MI, bool MULTI, bool UV>
-__device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_list, const int ntiles, const bool new_prob, float *smem,
+__device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_list, const int tstride, const int ntiles, const bool new_prob, float *smem, const gu32 cnt,
                                                     long long *dbg_base) {
     static_assert(MI >= 1 && MI <= FLT_MAX_MI, "tile height");
     int tid = threadIdx.x;
@@ -1753,8 +1798,8 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
     issue_phase(__builtin_amdgcn_readfirstlane(tile_list[0].y), 0, 0);
 #pragma unroll 1
     for (int ti = 0; ti < ntiles; ++ti) {
-        const int row0 = __builtin_amdgcn_readfirstlane(tile_list[ti].y);
-        const int next_row0 = ti + 1 < ntiles ? __builtin_amdgcn_readfirstlane(tile_list[ti + 1].y) : -1;
+        const int row0 = __builtin_amdgcn_readfirstlane(tile_list[ti * tstride].y);
+        const int next_row0 = ti + 1 < ntiles ? __builtin_amdgcn_readfirstlane(tile_list[(ti + 1) * tstride].y) : -1;
 #ifdef R3D_TIMING
         long long *dbg = dbg_base && ti < 8 ? dbg_base + ti * 8 : nullptr;
 #else
@@ -1879,49 +1924,108 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
         {
             const float *S = smem;
             const int rd_row = tid >> 6, rd_c4 = (tid & 63) * 4;
-            const int N = P.N;
+            const int N = P.N, ldc = P.ldc;
+            const __amdgpu_buffer_rsrc_t crs = act_rsrc(P.c + (size_t)row0 * ldc);
 #pragma unroll
             for (int j = 0; j < 4 * MI; ++j) {
                 const int lr = rd_row + 8 * j, row = row0 + lr;
                 if (row >= M) continue;
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(S + lr * PAIR_LD + rd_c4);
                 if (rd_c4 + 4 <= N) {
-                    __builtin_nontemporal_store(v, (R3D_AS1 f32x4 *)(P.c + (size_t)row * P.ldc + rd_c4));
+                    act_store4(crs, (lr * ldc + rd_c4) * 4, v);
                 } else {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        if (rd_c4 + c < N) gstore1(P.c + (size_t)row * P.ldc + rd_c4 + c, v[c]);
+                        if (rd_c4 + c < N) act_store1(crs, (lr * ldc + rd_c4 + c) * 4, v[c]);
                 }
             }
         }
+        if (cnt) tile_drain();
         __syncthreads();
+        if (cnt) {
+            const int4 te = tile_list[ti * tstride + 1];
+            tile_signal(cnt, __builtin_amdgcn_readfirstlane(te.y), __builtin_amdgcn_readfirstlane(te.z), MI);
+        }
         R3D_TSTAMP(4);
     }
 }
 
-template <bool ENC, bool UV>
+// ------------------------------------------------------------------------------------ tile-level dependencies
+//
+// r3d_forward_f32 runs the tiles of EVERY level of the network in one launch.  What orders them is data: a tile's
+// descriptor lists, per producer problem, the range of 32-row units its windows need (the network is row-local) and how
+// many 64-column granules each of them must have finished; one wavefront polls those ready counters - one counter per
+// lane, relaxed agent-scope loads, s_sleep between polls - and a barrier releases the workgroup.  No acquire fence
+// follows: producers store activations write-through (sc1) and consumers load them with sc1 (ACT_AUX above).
+// Spins are bounded: after ~1 s without progress the wavefront raises the launch's abort flag and goes on; every later
+// wait sees the flag and returns at once, the decoder kernel turns the outputs into NaN, nothing hangs.
+typedef const FwdArgs __attribute__((address_space(4))) *FwdArgsPtr;
+__device__ __forceinline__ void wait_deps(const int4 *tile, const int ndep, const gu32 cnt, const gu32 abort_flag) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const int *ti = reinterpret_cast<const int *>(tile);
+        int total = 0;
+        for (int d = 0; d < ndep; ++d) total += __builtin_amdgcn_readfirstlane(ti[9 + 2 * d]) & 0xffff;
+        for (int off = 0; off < total; off += 64) {          // (one pass unless a tile needs more than 64 counters)
+            int idx = -1, acc = 0;
+            unsigned need = 0;
+            for (int d = 0; d < ndep; ++d) {
+                const int base = __builtin_amdgcn_readfirstlane(ti[8 + 2 * d]), nw = __builtin_amdgcn_readfirstlane(ti[9 + 2 * d]);
+                const int n = nw & 0xffff, l = lane + off - acc;
+                if (l >= 0 && l < n) { idx = base + l; need = (unsigned)nw >> 16; }
+                acc += n;
+            }
+            long long t_first = 0;
+            for (unsigned spins = 1;; ++spins) {
+                const unsigned v = idx >= 0 ? __hip_atomic_load(cnt + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
+                if (__all(v >= need)) break;
+                __builtin_amdgcn_s_sleep(4);
+                if ((spins & 31) == 0) {
+                    if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    const long long now = wall_clock64();                       // 100 MHz
+                    if (t_first == 0) t_first = now;
+                    else if (now - t_first > 100000000LL) {
+                        if (lane == 0) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <bool ENC, bool UV, bool DEP = false>
 __device__ __forceinline__ void gemm_persistent(float *smem) {
     LaunchArgsPtr args = (LaunchArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    FwdArgsPtr fargs = (FwdArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();      // (DEP: the same segment holds a FwdArgs)
+    constexpr int TS = DEP ? FWD_TILE_INT4 : 1;                                  // int4s per tile descriptor
     // XCD-aware chunk order: workgroup b runs on XCD b % 8 (observed; speed only), so give each XCD a
     // contiguous run of chunks - neighbouring chunks share weights (and A rows) through that XCD's L2.
+    // (Single-launch form: the host has applied that order per level when it concatenated the workgroups' lists.)
     int wg = blockIdx.x;
-    {
+    if constexpr (!DEP) {
         const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = wg & 7, idx = wg >> 3;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int t0 = __builtin_amdgcn_readfirstlane(args->wg_off[wg]);
-    const int t1 = __builtin_amdgcn_readfirstlane(args->wg_off[wg + 1]);
+    const int4 *tiles = DEP ? fargs->tiles : args->tiles;
+    const int *wg_off = DEP ? fargs->wg_off : args->wg_off;
+    const gu32 cnt = DEP ? (gu32)fargs->cnt : (gu32) nullptr;
+    const gu32 abort_flag = DEP ? (gu32)(fargs->cnt + fargs->ncnt) : (gu32) nullptr;
+    const int t0 = __builtin_amdgcn_readfirstlane(wg_off[wg]);
+    const int t1 = __builtin_amdgcn_readfirstlane(wg_off[wg + 1]);
     long long *dbg = nullptr;
 #ifdef R3D_TIMING
-    long long *dbg_base = args->dbg && wg < 16 ? args->dbg + 6144 + wg * 64 : nullptr;   // 8 tiles x 8 stamps
-    if (args->dbg && threadIdx.x == 0) {
-        args->dbg[1024 + wg * 4 + 0] = __builtin_readcyclecounter();
-        args->dbg[1024 + wg * 4 + 2] = wall_clock64();
+    long long *dbg_arg = DEP ? fargs->dbg : args->dbg;
+    long long *dbg_base = dbg_arg && wg < 16 ? dbg_arg + 6144 + wg * 64 : nullptr;   // 8 tiles x 8 stamps
+    if (dbg_arg && threadIdx.x == 0) {
+        dbg_arg[1024 + wg * 4 + 0] = __builtin_readcyclecounter();
+        dbg_arg[1024 + wg * 4 + 2] = wall_clock64();
     }
 #endif
     int prev_pi = -1;
     for (int t = t0; t < t1; ++t) {
-        const int4 td = args->tiles[t];
+        const int4 td = tiles[t * TS];
         const int pi = __builtin_amdgcn_readfirstlane(td.x & 0xff);
         const bool new_prob = pi != prev_pi;
         prev_pi = pi;
@@ -1929,10 +2033,20 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
         const int row0 = __builtin_amdgcn_readfirstlane(td.y);
         const int col0 = __builtin_amdgcn_readfirstlane(td.z);
         const int ks = __builtin_amdgcn_readfirstlane(td.w);      // split-K factor of this tile (1, 2 or 4)
-        ProbRef P = args->p[pi];
+        int sig_base = 0, sig_add = 0;
+        if constexpr (DEP) {
+            const int4 te = tiles[t * TS + 1];
+            const int ndep = __builtin_amdgcn_readfirstlane(te.x);
+            sig_base = __builtin_amdgcn_readfirstlane(te.y);
+            sig_add = __builtin_amdgcn_readfirstlane(te.z);
+            if (ndep > 0) wait_deps(tiles + t * TS, ndep, cnt, abort_flag);
+        }
+        ProbRef P = DEP ? *((const GemmProb __attribute__((address_space(4))) *)fargs->probs + pi) : args->p[pi];
 #ifdef R3D_TIMING
         dbg = dbg_base && t - t0 < 8 ? dbg_base + (t - t0) * 8 : nullptr;
 #endif
+        bool signalled = false;
+        do {
         if constexpr (ENC) {
             (void)ks;
             switch (mi) {
@@ -1943,29 +2057,31 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
         } else {
             if (P.w3 != nullptr) {       // first level of the pyramid, fused (32 output rows per tile): this
                 int n = 1;               // workgroup's consecutive tiles of the problem as one run
-                while (t + n < t1 && __builtin_amdgcn_readfirstlane(args->tiles[t + n].x) == __builtin_amdgcn_readfirstlane(td.x)) ++n;   // same problem, same height
+                while (t + n < t1 && __builtin_amdgcn_readfirstlane(tiles[(t + n) * TS].x) == __builtin_amdgcn_readfirstlane(td.x)) ++n;   // same problem, same height
 #ifdef R3D_TIMING
                 long long *run_dbg = dbg_base && t - t0 < 8 ? dbg_base + (t - t0) * 8 : nullptr;
 #else
                 long long *run_dbg = nullptr;
 #endif
+                const int4 *tl = tiles + t * TS;
                 if (P.wb3 != nullptr) {   // fp32 on the bf16 matrix cores
                     if (P.K <= 64) {
-                        if (mi >= 2) first_level_taps_b3<2, false, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
-                        else first_level_taps_b3<1, false, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                        if (mi >= 2) first_level_taps_b3<2, false, UV>(P, tl, TS, n, new_prob, smem, cnt, run_dbg);
+                        else first_level_taps_b3<1, false, UV>(P, tl, TS, n, new_prob, smem, cnt, run_dbg);
                     } else {
-                        if (mi >= 2) first_level_taps_b3<2, true, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
-                        else first_level_taps_b3<1, true, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                        if (mi >= 2) first_level_taps_b3<2, true, UV>(P, tl, TS, n, new_prob, smem, cnt, run_dbg);
+                        else first_level_taps_b3<1, true, UV>(P, tl, TS, n, new_prob, smem, cnt, run_dbg);
                     }
                 } else if (P.K <= 64) {
-                    if (mi >= 2) first_level_taps<2, false, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
-                    else first_level_taps<1, false, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                    if (mi >= 2) first_level_taps<2, false, UV>(P, tl, TS, n, new_prob, smem, cnt, run_dbg);
+                    else first_level_taps<1, false, UV>(P, tl, TS, n, new_prob, smem, cnt, run_dbg);
                 } else {
-                    if (mi >= 2) first_level_taps<2, true, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
-                    else first_level_taps<1, true, UV>(P, args->tiles + t, n, new_prob, smem, run_dbg);
+                    if (mi >= 2) first_level_taps<2, true, UV>(P, tl, TS, n, new_prob, smem, cnt, run_dbg);
+                    else first_level_taps<1, true, UV>(P, tl, TS, n, new_prob, smem, cnt, run_dbg);
                 }
                 t += n - 1;
-                continue;
+                signalled = true;        // (every tile of the run has raised its own counters)
+                break;
             }
             if (P.lut != nullptr) {      // gathered operand without the fused level: GlobalInfo.fc_1's current frames
                 switch (mi) {
@@ -1973,13 +2089,13 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                     case 2: enc_tile<2, UV>(P, row0, col0, new_prob, smem, dbg); break;
                     default: enc_tile<3, UV>(P, row0, col0, new_prob, smem, dbg); break;
                 }
-                continue;
+                break;
             }
             if (P.wb3 != nullptr && P.w2 != nullptr) {   // a fused pair on the bf16 matrix cores (tiles of <= 96 rows)
                 if (mi >= 3) gemm_tile_b3t<3>(P, row0, smem, dbg);
                 else if (mi == 2) gemm_tile_b3t<2>(P, row0, smem, dbg);
                 else gemm_tile_b3t<1>(P, row0, smem, dbg);
-                continue;
+                break;
             }
             if (P.wb3 != nullptr) {      // fp32 on the bf16 matrix cores (whole tiles of <= 128 rows)
                 switch (mi) {
@@ -1988,13 +2104,13 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                     case 3: gemm_tile_b3<3>(P, row0, col0, smem, dbg); break;
                     default: gemm_tile_b3<4>(P, row0, col0, smem, dbg); break;
                 }
-                continue;
+                break;
             }
             if (ks > 1) {
                 if (ks == 4) gemm_tile<1, 4>(P, row0, col0, smem, dbg);
                 else if (mi == 1) gemm_tile<1, 2>(P, row0, col0, smem, dbg);
                 else gemm_tile<2, 2>(P, row0, col0, smem, dbg);
-                continue;
+                break;
             }
             if (P.w2 != nullptr) {       // fused pair (the scheduler caps these tiles at PAIR_MAX_MI units)
                 switch (mi) {
@@ -2003,7 +2119,7 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                     case 3: gemm_tile<3, 1, true>(P, row0, col0, smem, dbg); break;
                     default: gemm_tile<4, 1, true>(P, row0, col0, smem, dbg); break;
                 }
-                continue;
+                break;
             }
             switch (mi) {
                 case 1: gemm_tile<1, 1>(P, row0, col0, smem, dbg); break;
@@ -2014,11 +2130,19 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                 default: gemm_tile<6, 1>(P, row0, col0, smem, dbg); break;
             }
         }
+        } while (false);
+        if constexpr (DEP) {
+            if (!signalled) {            // (the tile functions end on a barrier: drain, one more barrier, raise the counters)
+                tile_drain();
+                __syncthreads();
+                tile_signal(cnt, sig_base, sig_add, mi);
+            }
+        }
     }
 #ifdef R3D_TIMING
-    if (args->dbg && threadIdx.x == 0) {
-        args->dbg[1024 + wg * 4 + 1] = __builtin_readcyclecounter();
-        args->dbg[1024 + wg * 4 + 3] = wall_clock64();
+    if (dbg_arg && threadIdx.x == 0) {
+        dbg_arg[1024 + wg * 4 + 1] = __builtin_readcyclecounter();
+        dbg_arg[1024 + wg * 4 + 3] = wall_clock64();
     }
 #endif
 }
@@ -2034,6 +2158,48 @@ extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_uv_f32(const
     extern __shared__ __attribute__((aligned(16))) float smem[];
     (void)args_;
     gemm_persistent<false, true>(smem);
+}
+
+// The whole forward in one launch: every level's tiles, ordered by ready counters (wait_deps above).  One workgroup per
+// CU, all of them resident (grid <= CU count: a waiting workgroup can only wait for tiles of resident workgroups or of
+// its own past).
+extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_forward_f32(const FwdArgs args_) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    (void)args_;
+    gemm_persistent<false, false, true>(smem);
+}
+extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_forward_uv_f32(const FwdArgs args_) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    (void)args_;
+    gemm_persistent<false, true, true>(smem);
+}
+
+// Ahead of r3d_forward_f32 on the same stream: zero the call's ready counters and abort flag, and turn the schedule's
+// relative problem table (pointer fields = byte offsets, one base tag per field) into this call's absolute one - the
+// table is too large for a kernarg segment (84 problems at RF 243), and it names the caller's buffers.
+extern "C" __global__ __launch_bounds__(256) void r3d_bind_f32(const BindArgs b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, total = gridDim.x * blockDim.x;
+    for (int j = i; j < b.ncnt + 4; j += total) b.cnt[j] = 0u;
+    if (i >= b.nprob) return;
+    GemmProb g = b.rel[i];
+    const unsigned char *tg = b.tags + (size_t)i * BIND_NPTR;
+    auto fix = [&](auto &ptr, int k) {
+        const int tag = tg[k];
+        typedef typename std::remove_reference<decltype(ptr)>::type PT;
+        ptr = tag == BIND_NULL ? (PT) nullptr : (PT)((const char *)b.base[tag] + (size_t)ptr);
+    };
+    for (int sgi = 0; sgi < MAX_SEG; ++sgi) {
+        if (tg[sgi] == BIND_PARAM) g.lda[sgi] = b.param_stride;
+        fix(g.a[sgi], sgi);
+    }
+    fix(g.w, 4); fix(g.bias, 5); fix(g.res, 6); fix(g.c, 7); fix(g.w2, 8); fix(g.bias2, 9); fix(g.wb3, 10); fix(g.w2b3, 11);
+    fix(g.w3b3, 12); fix(g.w3, 13); fix(g.bias3, 14); fix(g.lut, 15); fix(g.x, 16); fix(g.cam, 17);
+    if (g.lut != nullptr) {
+        g.enc_ws = b.enc_ws;
+        g.enc_bytes = b.enc_bytes;
+        g.cam_stride = b.cam_stride;
+    }
+    b.out[i] = g;
 }
 
 // first layers with the input encoding fused in: two workgroups per CU (4 wavefronts per SIMD)
@@ -2071,6 +2237,28 @@ hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, int kind, bool uv,
         if (uv) r3d_gemm_uv_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
         else r3d_gemm_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_forward(const FwdArgs &args, int nwg, bool uv, hipStream_t stream) {
+    static bool attr_done_dev[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_done_dev[dev]) {
+        for (const void *f : {reinterpret_cast<const void *>(r3d_forward_f32), reinterpret_cast<const void *>(r3d_forward_uv_f32)}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+            if (e != hipSuccess) return e;
+        }
+        attr_done_dev[dev] = true;
+    }
+    if (uv) r3d_forward_uv_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
+    else r3d_forward_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
+    return hipGetLastError();
+}
+
+hipError_t launch_bind(const BindArgs &args, hipStream_t stream) {
+    const int threads = std::max(args.nprob, std::min(args.ncnt + 4, 64 * 256));
+    r3d_bind_f32<<<dim3((threads + 255) / 256), dim3(256), 0, stream>>>(args);
     return hipGetLastError();
 }
 
@@ -2114,6 +2302,8 @@ extern "C" __global__ __launch_bounds__(256) void r3d_decode_f32(const DecodeArg
     const int per_win = a.has_pos ? a.J : 1;
     const long long b = gw / per_win;
     if (b >= a.B) return;
+    // (single-launch forward: a dependency spin that gave up leaves garbage behind - make it loud)
+    const bool poisoned = a.abort_flag != nullptr && __hip_atomic_load((gu32)a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     const int jf = (int)(gw - b * per_win);          // joint in flat decoder order
     const int ts = a.nsrc - 1;
     int s = 0, o = 0;
@@ -2138,7 +2328,7 @@ extern "C" __global__ __launch_bounds__(256) void r3d_decode_f32(const DecodeArg
     if (a.has_trj) {
         rt.dot(ht, trj);
 #pragma unroll
-        for (int n = 0; n < 3; ++n) trj[n] += a.bias[ts][n];
+        for (int n = 0; n < 3; ++n) trj[n] += a.bias[ts][n] + (poisoned ? __builtin_nanf("") : 0.0f);
         if (lane == 0 && jf == 0) {
 #pragma unroll
             for (int n = 0; n < 3; ++n) {
@@ -2153,7 +2343,7 @@ extern "C" __global__ __launch_bounds__(256) void r3d_decode_f32(const DecodeArg
     if (lane == 0) {
         const int e = a.slot[a.first[s] + o];     // (x, y, z) of a joint are consecutive in the output
 #pragma unroll
-        for (int n = 0; n < 3; ++n) a.out[b * (a.J * 3) + e + n] = v[n] + a.bias[s][o + n] + trj[n];
+        for (int n = 0; n < 3; ++n) a.out[b * (a.J * 3) + e + n] = v[n] + a.bias[s][o + n] + trj[n] + (poisoned ? __builtin_nanf("") : 0.0f);
     }
 }
 

@@ -145,21 +145,27 @@ struct Builder {
         const Model::Branch &br = m.branches[bi];
         const int C = m.cfg.channels, L = m.cfg.num_levels;
         int rows = m.RF / 3;
-        // (with the first level fused the expand_conv output never exists in memory: P0 only serves level >= 2)
-        const int pp[2] = {buffer(br.prefix + ".P0", first_level_fused ? (int64_t)std::max(rows / 9, 1) * C : (int64_t)rows * C),
-                           L > 1 ? buffer(br.prefix + ".P1", (int64_t)(rows / 3) * C) : -1};
+        // One buffer per level (and one per un-fused level's intermediate): level i's output has rows / 3^(i-1) rows per
+        // window.  Never ping-pong: in the single-launch forward a level-(i+1) tile may run while level-i tiles of OTHER
+        // windows still read level i-1's output, and the only ordering between tiles is producer -> consumer of the same
+        // windows.  (With the first level fused the expand_conv output never exists in memory.)
+        std::vector<int> lvl(L + 1, -1);             // lvl[i]: output of level i (0 = expand_conv)
+        {
+            int r = rows;
+            for (int i = 0; i < L; ++i, r = std::max(r / 3, 1))
+                if (!(i == 0 && first_level_fused)) lvl[i] = buffer(br.prefix + ".L" + std::to_string(i), (int64_t)r * C);
+        }
         // a level's 1x1 convolution is applied to the 3-tap one's output tile inside the kernel when a tile holds
         // all of its columns (r3d_kernels.hip, PAIR); otherwise the intermediate goes through a buffer
         // Fusing costs the level its split-K freedom (a fused tile is a whole 32-row unit through both layers), so
         // the top of the pyramid - one row per window, fewer units than CUs at the usual batch sizes - stays unfused.
         auto fuse = [&](int level_rows) { return C <= N_ALIGN && (level_rows >= 3 || fuse_top) && fuse_pairs; };
-        const int hb = L > 1 ? buffer(br.prefix + ".H", (int64_t)(rows / 3) * C) : -1;
         // first layer: the A operand is generated from the raw input inside the kernel (fused prologue)
         int last, i0 = 1;
         if (first_level_fused) {
             // expand_conv + level 1 (3-tap and 1x1 convolutions) as one problem of rows/3 output rows per window
             const std::string a = br.prefix + ".layers_conv.0", b = br.prefix + ".layers_conv.1";
-            last = problem(br.prefix + ".expand_conv", rows / 3, {}, -1, 0, 0, pp[1], 0, C, {}, (int)br.lut_off, (int)br.lut_uv_off);
+            last = problem(br.prefix + ".expand_conv", rows / 3, {}, -1, 0, 0, lvl[1], 0, C, {}, (int)br.lut_off, (int)br.lut_uv_off);
             ProbSpec &q = p.probs[last];
             q.enc_rows = rows;
             q.layer2 = m.layer_index.at(a);
@@ -168,10 +174,10 @@ struct Builder {
             rows /= 3;
             i0 = 2;
         } else {
-            last = problem(br.prefix + ".expand_conv", rows, {}, -1, 0, 0, pp[0], 0, C, {}, (int)br.lut_off, (int)br.lut_uv_off);
+            last = problem(br.prefix + ".expand_conv", rows, {}, -1, 0, 0, lvl[0], 0, C, {}, (int)br.lut_off, (int)br.lut_uv_off);
         }
         for (int i = i0; i < L; ++i) {
-            const int src = pp[(i - 1) & 1], dst = pp[i & 1];
+            const int src = lvl[i - 1], dst = lvl[i];
             rows /= 3;
             const std::string a = br.prefix + ".layers_conv." + std::to_string(2 * (i - 1));
             const std::string b = br.prefix + ".layers_conv." + std::to_string(2 * (i - 1) + 1);
@@ -185,11 +191,12 @@ struct Builder {
                 q.layer2 = m.layer_index.at(b);
                 q.flops_per_window += 2.0 * rows * (double)C * (double)C;
             } else {
+                const int hb = buffer(br.prefix + ".H" + std::to_string(i), (int64_t)rows * C);
                 const int pa = problem(a, rows, {{src, 0, 3 * C, 3 * C, last}}, -1, 0, 0, hb, 0, C);
                 last = problem(b, rows, {{hb, 0, C, C, pa}}, src, rc, 3 * C, dst, 0, C, {last});
             }
         }
-        const int fin = pp[(L - 1) & 1];
+        const int fin = lvl[L - 1];
         return finish(br, fin, C, last, c_buf, c_col, c_ld);
     }
 };

@@ -376,8 +376,9 @@ def test_rf243_flip_tta_and_uv_clip_mode_against_the_oracle_chain():
     with torch.no_grad():
         named, avg, rows = evaluate.evaluate_clips(lifter.forward_clip, clips, 243, dev, flip=True, kps_left=kl, kps_right=kr)
         preds = [evaluate.predict_clip(lifter.forward_clip, c, 243, dev, True, kl, kr).cpu().numpy() for c in clips]
-    rows = rows.cpu().numpy()
-    for c, pred, row in zip(clips, preds, rows):
+    by_id = {int(r[0]): r for r in rows.cpu().numpy()}           # (rows come in shard order: longest clip first)
+    for c, pred in zip(clips, preds):
+        row = by_id[c.clip_id]
         n = c.rays.shape[0]
         padded = evaluate.pad_clip(c.rays, 121)
         windows = np.stack([padded[i:i + 243] for i in range(n)])
