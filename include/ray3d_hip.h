@@ -217,6 +217,12 @@ int r3d_debug_schedule_check(int nprob, const int *M, const int *N, const int *n
  * run one launch late (row spill).  Returns 0 or a negative code. */
 int r3d_debug_plan_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg, int *launches, int *spilled);
 
+/* The single-launch form of the forward (one persistent kernel for all levels, tiles ordered by ready counters), built
+ * and executed on the host as a dependency machine: every tile gets to run, every counter ends full, and whenever a tile
+ * runs every earlier problem that touches the same buffer columns is complete for the tile's windows.  Returns 0, 1 when
+ * the plan of this batch size runs launch by launch (nothing to check), or a negative code. */
+int r3d_debug_forward_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg, int *tiles, int *counters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,7 @@ EXPORTS = (
     "r3d_set_weight", "r3d_finalize", "r3d_workspace_bytes", "r3d_forward", "r3d_forward_pair",
     "r3d_profile_enable", "r3d_profile_read", "r3d_clip_metrics", "r3d_last_error", "r3d_version",
     "r3d_prepare", "r3d_release", "r3d_abi_version", "r3d_precision", "r3d_debug_schedule_check", "r3d_debug_plan_check",
+    "r3d_debug_forward_check",
 )
 ABI_VERSION = 3                                                          # R3D_ABI_VERSION of the header this binding follows
 METRIC_NAMES = ("mpjpe", "p_mpjpe", "n_mpjpe", "velocity", "root")     # R3D_METRIC_* order

@@ -46,10 +46,13 @@ static bool same_input_shape(const Model *a, const Model *b) {
            a->cfg.num_levels == b->cfg.num_levels && a->cfg.extrinsic_dim == b->cfg.extrinsic_dim;
 }
 
-static size_t workspace_need(const Plan *pl, int64_t B) {
-    // activations only: the input is read in place in both modes (UV mode encodes the rays inside the gather)
-    return ((size_t)pl->floats_per_window * (size_t)B + (size_t)pl->tail_floats + 64) * sizeof(float);
+// activations (the input is read in place in both modes: UV mode encodes the rays inside the gather), then - 256-byte
+// aligned - the single-launch forward's control region: ready counters + abort flag, the call's problem table
+static size_t workspace_act_bytes(const Plan *pl, int64_t B) {
+    const size_t act = ((size_t)pl->floats_per_window * (size_t)B + (size_t)pl->tail_floats + 64) * sizeof(float);
+    return (act + 255) / 256 * 256;
 }
+static size_t workspace_need(const Plan *pl, int64_t B) { return workspace_act_bytes(pl, B) + fwd_ctrl_bytes(pl, B); }
 
 struct Recorder {
     Model *m;
@@ -79,6 +82,106 @@ struct Recorder {
         return hipEventRecord(m->recs[n++].e1, stream);
     }
 };
+
+// One GEMM problem of the plan for a call of B windows.  `tags` (optional, BIND_NPTR entries): the base of every pointer field.
+int fill_prob(const Plan *pl, const ProbSpec &q, int64_t B, const Model *a, const Bases &bs, const CallShape &cs, GemmProb &g,
+              unsigned char *tags) {
+    memset(&g, 0, sizeof g);
+    unsigned char tg[BIND_NPTR] = {0};
+    const Model *m = pl->m[q.model];
+    const Layer &L = m->layers[q.layer];
+    const int JF = a->cfg.num_joints * (cs.uv ? 2 : a->cfg.in_features);   // floats per input frame
+    auto ws_ptr = [&](int buf, int col) {
+        return reinterpret_cast<float *>(const_cast<char *>(bs.ws) + ((size_t)pl->buffers[buf].offset_per_window * (size_t)B + (size_t)col) * sizeof(float));
+    };
+    auto arena_ptr = [&](size_t off) { return reinterpret_cast<const float *>(bs.arena[q.model] + off * sizeof(float)); };
+    const unsigned char TA = (unsigned char)(BIND_ARENA0 + q.model), TI = (unsigned char)(BIND_IARENA0 + q.model);
+    int kend = 0;
+    for (int s = 0; s < MAX_SEG; ++s) {
+        if (s < q.nseg) {
+            if (pl->buffers[q.seg[s].buf].external == 3) {      // the caller's camera-parameter rows
+                g.a[s] = reinterpret_cast<const float *>(bs.param);
+                g.lda[s] = (int)cs.param_stride;
+                tg[s] = BIND_PARAM;
+            } else {
+                g.a[s] = ws_ptr(q.seg[s].buf, q.seg[s].col);
+                g.lda[s] = q.seg[s].ld;
+                tg[s] = BIND_WS;
+            }
+            kend += q.seg[s].width;
+        } else {
+            g.a[s] = g.a[0];
+            g.lda[s] = g.lda[0];
+            tg[s] = tg[0];
+        }
+        g.kend[s] = s < q.nseg ? kend : 0x7fffffff;
+    }
+    // the last real segment absorbs the rest - unless it is narrower than the padded K (embedder.w1 on
+    // the 2-wide parameter rows): its true width bounds the buffer descriptor, the rest reads as zeros
+    if (q.nseg > 0 && !(q.nseg == 1 && kend < L.Kpad)) g.kend[q.nseg - 1] = 0x7fffffff;
+    if (q.enc_lut >= 0) {
+        if (cs.uv && q.enc_lut_uv < 0) { set_error("internal: no UV tables for an encoded operand"); return R3D_ERR_STATE; }
+        g.lut = reinterpret_cast<const int *>(bs.iarena[q.model] + (size_t)(cs.uv ? q.enc_lut_uv : q.enc_lut) * sizeof(int));
+        tg[15] = TI;
+        g.x = reinterpret_cast<const float *>(bs.x);
+        tg[16] = BIND_X;
+        g.cam = cs.uv ? reinterpret_cast<const double *>(bs.cam) : nullptr;
+        tg[17] = cs.uv ? BIND_CAM : BIND_NULL;
+        g.cam_stride = cs.cam_stride;
+        g.enc_ws = cs.window_stride * JF;
+        g.enc_rows = q.enc_rows;
+        g.enc_step = q.enc_step;
+        g.enc_jf = JF;
+        g.enc_cur = (a->RF / a->cfg.in_features) * JF;   // quirk Q1: "current" frame is RF // in_features
+        g.enc_bytes = (unsigned)((size_t)cs.frames * JF * sizeof(float));
+        g.res_tap = 1 + m->cfg.causal;
+    }
+    g.w = arena_ptr(L.w_off);
+    tg[4] = TA;
+    const bool b3 = B >= b3_min_batch();
+    if (b3 && L.bf3 && q.layer2 < 0 && q.enc_lut < 0) { g.wb3 = arena_ptr(L.wb3_off); tg[10] = TA; }
+    g.bias = arena_ptr(L.b_off);
+    tg[5] = TA;
+    if (q.res_buf >= 0) { g.res = ws_ptr(q.res_buf, q.res_col); tg[6] = BIND_WS; }
+    g.ldr = q.res_ld;
+    g.c = ws_ptr(q.c_buf, q.c_col);
+    tg[7] = BIND_WS;
+    g.ldc = q.c_ld;
+    g.M = (int)(B * q.rows_per_window);
+    g.N = L.N;
+    g.K = L.Kpad;
+    g.slope = L.slope;
+    if (q.layer2 >= 0) {
+        const Layer &L2 = m->layers[q.layer2];
+        if (b3 && q.layer3 < 0 && L.bf3_conv && L2.bf3_conv && q.nseg == 1) {   // gemm_tile_b3t
+            g.wb3 = arena_ptr(L.wb3_off);
+            g.w2b3 = arena_ptr(L2.wb3_off);
+            tg[10] = tg[11] = TA;
+        }
+        g.w2 = arena_ptr(L2.w_off);
+        g.bias2 = arena_ptr(L2.b_off);
+        tg[8] = tg[9] = TA;
+        g.K2 = L2.Kpad;
+        g.slope2 = L2.slope;
+    }
+    if (q.layer3 >= 0) {
+        const Layer &L3 = m->layers[q.layer3];
+        const Layer &L2b = m->layers[q.layer2];
+        if (b3 && L.bf3_conv && L2b.bf3_conv && L3.bf3_conv) {   // first_level_taps_b3
+            g.wb3 = arena_ptr(L.wb3_off);
+            g.w2b3 = arena_ptr(L2b.wb3_off);
+            g.w3b3 = arena_ptr(L3.wb3_off);
+            tg[10] = tg[11] = tg[12] = TA;
+        }
+        g.w3 = arena_ptr(L3.w_off);
+        g.bias3 = arena_ptr(L3.b_off);
+        tg[13] = tg[14] = TA;
+        g.K3 = L3.Kpad;
+        g.slope3 = L3.slope;
+    }
+    if (tags) memcpy(tags, tg, sizeof tg);
+    return R3D_OK;
+}
 
 static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *out, float *out_trj, void *ws,
                size_t ws_bytes, void *stream_v) {
@@ -123,12 +226,102 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
 
     // UV mode: the kernels read pixel keypoints (frames, J, 2) and encode the rays while gathering them
     const bool uv = in->mode == R3D_INPUT_UV;
-    const int JF = a->cfg.num_joints * (uv ? 2 : a->cfg.in_features);   // floats per input frame
+    Bases bases;
+    bases.ws = reinterpret_cast<const char *>(ws);
+    for (int mi = 0; mi < 2; ++mi)
+        if (pl->m[mi]) {
+            bases.arena[mi] = reinterpret_cast<const char *>(pl->m[mi]->d_arena);
+            bases.iarena[mi] = reinterpret_cast<const char *>(pl->m[mi]->d_iarena);
+        }
+    bases.x = reinterpret_cast<const char *>(in->x_dev);
+    bases.param = reinterpret_cast<const char *>(in->param_dev);
+    bases.cam = reinterpret_cast<const char *>(in->cam_dev);
+    CallShape shape;
+    shape.uv = uv;
+    shape.window_stride = in->window_stride;
+    shape.param_stride = in->param_stride;
+    shape.cam_stride = in->cam_stride;
+    shape.frames = frames;
 
-    // ---- persistent GEMM launches, one per DAG level
     Schedule *sched = schedule_get(pl, B, device_cu_count());
     if (!sched) return R3D_ERR_HIP;
-    for (size_t si = 0; si < sched->levels->size(); ++si) {
+    const unsigned *abort_flag = nullptr;
+    const bool single = forward_single_launch() && sched->fwd.grid > 0 && !(uv && !sched->fwd.d_rel[1]);
+    if (single) {
+        // ---- the whole forward as ONE persistent launch: bind (zero the ready counters, resolve the problem table), run
+        const Schedule::Fwd &fw = sched->fwd;
+        char *ctrl = reinterpret_cast<char *>(ws) + workspace_act_bytes(pl, B);
+        unsigned *cnt = reinterpret_cast<unsigned *>(ctrl);
+        GemmProb *table = reinterpret_cast<GemmProb *>(ctrl + ((size_t)(fw.ncnt + 4) * sizeof(unsigned) + 255) / 256 * 256);
+        BindArgs ba;
+        memset(&ba, 0, sizeof ba);
+        ba.rel = fw.d_rel[uv ? 1 : 0];
+        ba.tags = fw.d_tags[uv ? 1 : 0];
+        ba.out = table;
+        ba.cnt = cnt;
+        ba.nprob = fw.nprob;
+        ba.ncnt = fw.ncnt;
+        ba.base[BIND_WS] = ws;
+        ba.base[BIND_ARENA0] = bases.arena[0];
+        ba.base[BIND_ARENA1] = bases.arena[1];
+        ba.base[BIND_IARENA0] = bases.iarena[0];
+        ba.base[BIND_IARENA1] = bases.iarena[1];
+        ba.base[BIND_X] = in->x_dev;
+        ba.base[BIND_PARAM] = in->param_dev;
+        ba.base[BIND_CAM] = in->cam_dev;
+        const int JF = a->cfg.num_joints * (uv ? 2 : a->cfg.in_features);
+        ba.enc_ws = in->window_stride * JF;
+        ba.cam_stride = in->cam_stride;
+        ba.enc_bytes = (unsigned)((size_t)frames * JF * sizeof(float));
+        ba.param_stride = (int)in->param_stride;
+        if ((e = rec.begin("r3d_bind_f32", stage_no, 1, 0.0, 0.0)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        if ((e = launch_bind(ba, stream)) != hipSuccess) return hip_fail(e, "launch r3d_bind_f32");
+        if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        ++stage_no;
+        FwdArgs fa;
+        memset(&fa, 0, sizeof fa);
+        fa.tiles = fw.d_tiles;
+        fa.wg_off = fw.d_wgoff;
+        fa.probs = table;
+        fa.cnt = cnt;
+        fa.ncnt = fw.ncnt;
+        const bool uv_launch = uv && fw.uses_gather;
+        if ((e = rec.begin(uv_launch ? "r3d_forward_uv_f32" : "r3d_forward_f32", stage_no, fw.grid, fw.flops, fw.bytes)) != hipSuccess)
+            return hip_fail(e, "hipEventRecord");
+#ifdef R3D_TIMING
+        static long long *timing_buf1 = nullptr;
+        if (getenv("R3D_TIMING_STAGE")) {
+            if (!timing_buf1) (void)hipMalloc((void **)&timing_buf1, (1024 + 4 * 1024) * 8 + 65536);
+            (void)hipMemsetAsync(timing_buf1, 0, (1024 + 4 * 1024) * 8 + 65536, stream);
+            fa.dbg = timing_buf1;
+        }
+#endif
+        if ((e = launch_forward(fa, fw.grid, uv_launch, stream)) != hipSuccess) return hip_fail(e, "launch r3d_forward_f32");
+#ifdef R3D_TIMING
+        if (fa.dbg) {
+            (void)hipStreamSynchronize(stream);
+            std::vector<long long> hw(4 * 1024);
+            (void)hipMemcpy(hw.data(), timing_buf1 + 1024, hw.size() * 8, hipMemcpyDeviceToHost);
+            long long w0 = 1LL << 62, w1 = 0, e0 = 1LL << 62;
+            std::vector<double> d;
+            for (int w = 0; w < fw.grid && w < 1024; ++w) {
+                w0 = std::min(w0, hw[w * 4 + 2]); w1 = std::max(w1, hw[w * 4 + 3]); e0 = std::min(e0, hw[w * 4 + 3]);
+                d.push_back((hw[w * 4 + 3] - hw[w * 4 + 2]) / 100.0);
+            }
+            std::sort(d.begin(), d.end());
+            fprintf(stderr, "[timing] forward: first workgroup start -> last end %.2f us; ends spread over %.2f us; busy min %.1f median %.1f max %.1f us\n",
+                    (w1 - w0) / 100.0, (w1 - e0) / 100.0, d.front(), d[d.size() / 2], d.back());
+            if (getenv("R3D_TIMING_ALL"))
+                for (int w = 0; w < fw.grid && w < 1024; ++w)
+                    fprintf(stderr, "[timing-wg] %d start %.2f end %.2f\n", w, (hw[w * 4 + 2] - w0) / 100.0, (hw[w * 4 + 3] - w0) / 100.0);
+        }
+#endif
+        if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        ++stage_no;
+        abort_flag = cnt + fw.ncnt;
+    }
+    // ---- (staged form) persistent GEMM launches, one per DAG level
+    for (size_t si = 0; !single && si < sched->levels->size(); ++si) {
         const auto &st = (*sched->levels)[si];
         const StageSchedule &ss = sched->stages[si];
         LaunchArgs la;
@@ -139,82 +332,10 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         la.ks = ss.ks;
         int n_enc = 0;
         for (int i = 0; i < la.nprob; ++i) {
-            const ProbSpec &q = pl->probs[st[i] & ~STAGE_SPILL_IN];      // (a spilled tail uses the problem as it is:
-            const Model *m = pl->m[q.model];                             //  tiles carry absolute rows)
-            const Layer &L = m->layers[q.layer];
-            GemmProb &g = la.p[i];
-            int kend = 0;
-            for (int s = 0; s < MAX_SEG; ++s) {
-                if (s < q.nseg) {
-                    if (pl->buffers[q.seg[s].buf].external == 3) {      // the caller's camera-parameter rows
-                        g.a[s] = in->param_dev;
-                        g.lda[s] = (int)in->param_stride;
-                    } else {
-                        g.a[s] = buf_ptr(q.seg[s].buf) + q.seg[s].col;
-                        g.lda[s] = q.seg[s].ld;
-                    }
-                    kend += q.seg[s].width;
-                } else {
-                    g.a[s] = g.a[0];
-                    g.lda[s] = g.lda[0];
-                }
-                g.kend[s] = s < q.nseg ? kend : 0x7fffffff;
-            }
-            // the last real segment absorbs the rest - unless it is narrower than the padded K (embedder.w1 on
-            // the 2-wide parameter rows): its true width bounds the buffer descriptor, the rest reads as zeros
-            if (q.nseg > 0 && !(q.nseg == 1 && kend < L.Kpad)) g.kend[q.nseg - 1] = 0x7fffffff;
-            if (q.enc_lut >= 0) {
-                if (q.enc_kernel) ++n_enc;                  // (with a fused first level these run in the GEMM kernel)
-                if (uv && q.enc_lut_uv < 0) { set_error("internal: no UV tables for an encoded operand"); return R3D_ERR_STATE; }
-                g.lut = m->d_iarena + (uv ? q.enc_lut_uv : q.enc_lut);
-                g.x = in->x_dev;
-                g.cam = uv ? in->cam_dev : nullptr;
-                g.cam_stride = in->cam_stride;
-                g.enc_ws = in->window_stride * JF;
-                g.enc_rows = q.enc_rows;
-                g.enc_step = q.enc_step;
-                g.enc_jf = JF;
-                g.enc_cur = (a->RF / a->cfg.in_features) * JF;   // quirk Q1: "current" frame is RF // in_features
-                g.enc_bytes = (unsigned)((size_t)frames * JF * sizeof(float));
-                g.res_tap = 1 + m->cfg.causal;
-            }
-            g.w = m->d_arena + L.w_off;
-            const bool b3 = B >= b3_min_batch();
-            if (b3 && L.bf3 && q.layer2 < 0 && q.enc_lut < 0)
-                g.wb3 = m->d_arena + L.wb3_off;
-            g.bias = m->d_arena + L.b_off;
-            g.res = q.res_buf >= 0 ? buf_ptr(q.res_buf) + q.res_col : nullptr;
-            g.ldr = q.res_ld;
-            g.c = buf_ptr(q.c_buf) + q.c_col;
-            g.ldc = q.c_ld;
-            g.M = (int)(B * q.rows_per_window);
-            g.N = L.N;
-            g.K = L.Kpad;
-            g.slope = L.slope;
-            if (q.layer2 >= 0) {
-                const Layer &L2 = m->layers[q.layer2];
-                if (b3 && q.layer3 < 0 && L.bf3_conv && L2.bf3_conv && q.nseg == 1) {   // gemm_tile_b3t
-                    g.wb3 = m->d_arena + L.wb3_off;
-                    g.w2b3 = m->d_arena + L2.wb3_off;
-                }
-                g.w2 = m->d_arena + L2.w_off;
-                g.bias2 = m->d_arena + L2.b_off;
-                g.K2 = L2.Kpad;
-                g.slope2 = L2.slope;
-            }
-            if (q.layer3 >= 0) {
-                const Layer &L3 = m->layers[q.layer3];
-                const Layer &L2b = m->layers[q.layer2];
-                if (b3 && L.bf3_conv && L2b.bf3_conv && L3.bf3_conv) {   // first_level_taps_b3
-                    g.wb3 = m->d_arena + L.wb3_off;
-                    g.w2b3 = m->d_arena + L2b.wb3_off;
-                    g.w3b3 = m->d_arena + L3.wb3_off;
-                }
-                g.w3 = m->d_arena + L3.w_off;
-                g.bias3 = m->d_arena + L3.b_off;
-                g.K3 = L3.Kpad;
-                g.slope3 = L3.slope;
-            }
+            const ProbSpec &q = pl->probs[st[i] & ~STAGE_SPILL_IN];      // (a spilled tail uses the problem as it is: tiles carry absolute rows)
+            if (q.enc_lut >= 0 && q.enc_kernel) ++n_enc;                 // (with a fused first level these run in the GEMM kernel)
+            const int rc = fill_prob(pl, q, B, a, bases, shape, la.p[i], nullptr);
+            if (rc != R3D_OK) return rc;
         }
         if (n_enc != 0 && n_enc != la.nprob) { set_error("internal: launch mixes encoded and plain operands"); return R3D_ERR_STATE; }
         if ((n_enc != 0) != (ss.kind == STAGE_ENC)) { set_error("internal: schedule and plan disagree on the launch kind"); return R3D_ERR_STATE; }
@@ -294,6 +415,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
     da.has_trj = pl->trj_model >= 0;
     da.out = out;
     da.out_trj = da.has_pos ? out_trj : nullptr;
+    da.abort_flag = abort_flag;
     double dec_flops = 0;
     int first = 0;
     // plan.decs lists the pos parts (Torso, LArm, RArm, LLeg, RLeg) then the trajectory decoder
@@ -543,6 +665,99 @@ int r3d_debug_plan_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg,
         for (int d : pl->probs[i].deps)
             if (last_launch[d] >= first_launch[i]) return -9;
     }
+    return 0;
+}
+
+// Test hook: the single-launch form of the forward for `batch` windows on `nwg` CUs, built and EXECUTED on the host as a
+// dependency machine: a workgroup's next tile runs when the ready counters it waits for are full; every tile must get to
+// run (no waiting cycle), every counter must end full, and - independently of the dependency ranges the scheduler wrote -
+// at the moment a tile runs, every earlier problem that writes what the tile reads, or reads / writes what the tile
+// writes (same buffer, overlapping columns), must be complete for the tile's windows.
+// Returns 0 (or 1: this plan runs launch by launch, nothing to check), or a negative code.
+int r3d_debug_forward_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg, int *out_tiles, int *out_counters) {
+    Model *a = reinterpret_cast<Model *>(pos ? pos : trj), *b = reinterpret_cast<Model *>(pos && trj ? trj : nullptr);
+    if (!a) return -1;
+    Plan *pl = plan_get(a, b, plan_kind(batch));
+    int spill_row0 = -1;
+    std::vector<int4> tiles;
+    std::vector<int> wgoff;
+    std::vector<StageSchedule> stages;
+    const std::vector<std::vector<int>> &levels = *schedule_build_host(pl, batch, nwg, spill_row0, tiles, wgoff, stages);
+    Schedule::Fwd fw;
+    std::vector<int> ft, fo;
+    if (!schedule_build_fwd(pl, batch, nwg, levels, stages, tiles, wgoff, fw, ft, fo)) return 1;
+    if (out_tiles) *out_tiles = fw.ntiles;
+    if (out_counters) *out_counters = fw.ncnt;
+    const int np = (int)pl->probs.size(), TI = FWD_TILE_INT4 * 4;
+    std::vector<int> gcols(np);
+    for (int i = 0; i < np; ++i) gcols[i] = (pl->m[pl->probs[i].model]->layers[pl->probs[i].layer].N + 63) / 64;
+    std::vector<unsigned> cnt(fw.ncnt, 0);
+    // column range a problem reads / writes in a workspace buffer
+    struct Acc { int buf, c0, c1; };
+    auto reads = [&](const ProbSpec &q) {
+        std::vector<Acc> v;
+        for (int sgi = 0; sgi < q.nseg; ++sgi)
+            if (pl->buffers[q.seg[sgi].buf].external == 0) v.push_back({q.seg[sgi].buf, q.seg[sgi].col, q.seg[sgi].col + q.seg[sgi].width});
+        if (q.res_buf >= 0) v.push_back({q.res_buf, q.res_col, q.res_col + pl->m[q.model]->layers[q.layer2 >= 0 && q.layer3 < 0 ? q.layer2 : q.layer].N});
+        return v;
+    };
+    auto writes = [&](const ProbSpec &q) {
+        const int N = pl->m[q.model]->layers[q.layer3 >= 0 ? q.layer3 : q.layer2 >= 0 ? q.layer2 : q.layer].N;
+        return Acc{q.c_buf, q.c_col, q.c_col + N};
+    };
+    auto overlap = [](const Acc &x, const Acc &y) { return x.buf == y.buf && x.c0 < y.c1 && y.c0 < x.c1; };
+    auto complete = [&](int prob, int w0, int w1) {           // every unit of `prob` that holds rows of windows [w0, w1)
+        const ProbSpec &q = pl->probs[prob];
+        const int M = (int)(batch * q.rows_per_window);
+        const int a0 = w0 * q.rows_per_window, a1 = std::min(w1 * q.rows_per_window, M);
+        for (int u = a0 / 32; u < (a1 + 31) / 32; ++u)
+            if (cnt[fw.cnt_base[prob] + u] != (unsigned)gcols[prob]) return false;
+        return true;
+    };
+    std::vector<int> next(fw.grid);
+    for (int w = 0; w < fw.grid; ++w) next[w] = fo[w];
+    int done = 0;
+    for (bool progress = true; progress;) {
+        progress = false;
+        for (int w = 0; w < fw.grid; ++w) {
+            while (next[w] < fo[w + 1]) {
+                const int *d = &ft[(size_t)next[w] * TI];
+                bool ready = true;
+                for (int k = 0; k < d[4] && ready; ++k) {
+                    const int base = d[8 + 2 * k], n = d[9 + 2 * k] & 0xffff;
+                    const unsigned need = (unsigned)d[9 + 2 * k] >> 16;
+                    for (int u = 0; u < n && ready; ++u) ready = cnt[base + u] >= need;
+                }
+                if (!ready) break;
+                const int id = d[0] & 0xff, mi = d[0] >> 8;
+                const ProbSpec &q = pl->probs[id];
+                const int M = (int)(batch * q.rows_per_window);
+                const int r1 = std::min(d[1] + mi * 32, M);
+                const int w0 = d[1] / q.rows_per_window, w1 = (r1 - 1) / q.rows_per_window + 1;
+                const Acc wr = writes(q);
+                for (int o = 0; o < id; ++o) {                 // (problems are created in the reference's execution order)
+                    const ProbSpec &oq = pl->probs[o];
+                    bool hazard = false;
+                    for (const Acc &rd : reads(q)) hazard = hazard || overlap(rd, writes(oq));        // read after write
+                    for (const Acc &rd : reads(oq)) hazard = hazard || overlap(rd, wr);               // write after read
+                    hazard = hazard || overlap(writes(oq), wr);                                      // write after write
+                    if (hazard && !complete(o, w0, w1)) return -20;
+                }
+                if (d[5] != fw.cnt_base[id] + d[1] / 32 || d[5] + mi > fw.ncnt) return -21;
+                for (int u = 0; u < mi; ++u) {
+                    cnt[d[5] + u] += (unsigned)d[6];
+                    if (cnt[d[5] + u] > (unsigned)gcols[id]) return -22;
+                }
+                ++next[w];
+                ++done;
+                progress = true;
+            }
+        }
+    }
+    if (done != fw.ntiles) return -23;                          // a waiting cycle
+    for (int i = 0; i < np; ++i)
+        for (int u = 0; u < (int)((batch * pl->probs[i].rows_per_window + 31) / 32); ++u)
+            if (cnt[fw.cnt_base[i] + u] != (unsigned)gcols[i]) return -24;
     return 0;
 }
 

@@ -321,6 +321,22 @@ struct Plan {
     ~Plan();
 };
 
+// Where a problem's pointers point: real addresses (a launch's kernarg table) or all-null bases, which leaves byte
+// OFFSETS in the pointer fields plus one BIND_* tag per field - the schedule's relative table that r3d_bind_f32 turns
+// into a call's absolute one on the device (r3d_kernels.hip).
+struct Bases {
+    const char *ws = nullptr, *arena[2] = {nullptr, nullptr}, *iarena[2] = {nullptr, nullptr};
+    const char *x = nullptr, *param = nullptr, *cam = nullptr;
+};
+struct CallShape {
+    bool uv = false;
+    int64_t window_stride = 0, param_stride = 0, cam_stride = 0;
+    long long frames = 0;
+};
+
+int fill_prob(const Plan *pl, const ProbSpec &q, int64_t B, const Model *a, const Bases &bs, const CallShape &cs, GemmProb &g,
+              unsigned char *tags);   // r3d_api.cpp
+
 void set_error(const char *fmt, ...);
 const char *last_error();
 int hip_fail(hipError_t e, const char *what);
@@ -352,6 +368,9 @@ inline size_t frag_index(int o, int k, int nk) {
 }
 const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t B, int nwg, int &spill_row0, std::vector<int4> &tiles,
                                                         std::vector<int> &wgoff, std::vector<StageSchedule> &stages);
+bool schedule_build_fwd(const Plan *pl, int64_t B, int nwg, const std::vector<std::vector<int>> &levels, const std::vector<StageSchedule> &stages,
+                        const std::vector<int4> &tiles, const std::vector<int> &wgoff, Schedule::Fwd &fw, std::vector<int> &out_tiles,
+                        std::vector<int> &out_wgoff);
 Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin = false);   // nullptr + set_error on failure
 int device_cu_count();
 

@@ -25,6 +25,120 @@ namespace r3d {
 Schedule::~Schedule() {
     if (d_tiles) (void)hipFree(d_tiles);
     if (d_wgoff) (void)hipFree(d_wgoff);
+    if (fwd.d_tiles) (void)hipFree(fwd.d_tiles);
+    if (fwd.d_wgoff) (void)hipFree(fwd.d_wgoff);
+    for (int i = 0; i < 2; ++i) {
+        if (fwd.d_rel[i]) (void)hipFree(fwd.d_rel[i]);
+        if (fwd.d_tags[i]) (void)hipFree(fwd.d_tags[i]);
+    }
+}
+
+bool forward_single_launch() {
+    static const bool on = !env_on("R3D_STAGED");
+    return on;
+}
+
+static int64_t units_of(int64_t B, const ProbSpec &q) { return (B * q.rows_per_window + 31) / 32; }
+
+size_t fwd_ctrl_bytes(const Plan *pl, int64_t B) {
+    int64_t ncnt = 0;
+    for (const auto &q : pl->probs) ncnt += units_of(B, q);
+    return ((size_t)(ncnt + 4) * sizeof(unsigned) + 255) / 256 * 256 + pl->probs.size() * sizeof(GemmProb) + 256;
+}
+
+// The single-launch form of a schedule: every workgroup's chunks of all launches concatenated in launch order, each tile
+// carrying the ready counters it raises and the producer units it waits for (r3d_internal.hpp, FWD_TILE_INT4).  Launch
+// order is a topological order of the tiles, and a workgroup's list follows it, so the tile that is first in that order
+// among the unfinished ones can always run: its producers are finished and its workgroup has nothing else in front of
+// it - no waiting cycle exists as long as all workgroups are resident (grid <= CU count).
+// Returns false when the plan cannot run this way (a launch of r3d_gemm_enc_f32, too many producers for a descriptor).
+bool schedule_build_fwd(const Plan *pl, int64_t B, int nwg, const std::vector<std::vector<int>> &levels, const std::vector<StageSchedule> &stages,
+                        const std::vector<int4> &tiles, const std::vector<int> &wgoff, Schedule::Fwd &fw, std::vector<int> &out_tiles,
+                        std::vector<int> &out_wgoff) {
+    const int np = (int)pl->probs.size();
+    if (np > 255) return false;
+    for (const auto &ss : stages)
+        if (ss.kind != STAGE_BIG) return false;
+    for (const Model *m : pl->m)
+        if (m && m->cfg.dense) return false;      // (the dense ablation's overlapping operand rows are not row-local per 32-row unit)
+    fw.nprob = np;
+    fw.cnt_base.assign(np, 0);
+    fw.prob_of_slot.resize(np);
+    std::vector<int> gcols(np), M(np);
+    int ncnt = 0;
+    for (int i = 0; i < np; ++i) {
+        const ProbSpec &q = pl->probs[i];
+        fw.prob_of_slot[i] = i;
+        fw.cnt_base[i] = ncnt;
+        ncnt += (int)units_of(B, q);
+        gcols[i] = (pl->m[q.model]->layers[q.layer].N + 63) / 64;
+        M[i] = (int)(B * q.rows_per_window);
+        if (q.enc_lut >= 0) fw.uses_gather = true;
+    }
+    fw.ncnt = ncnt;
+    std::vector<std::vector<int>> lists(nwg);     // per workgroup: tile descriptors, 24 ints each
+    fw.flops = fw.bytes = 0;
+    for (size_t si = 0; si < stages.size(); ++si) {
+        const StageSchedule &ss = stages[si];
+        const auto &st = levels[si];
+        fw.flops += ss.flops;
+        fw.bytes += ss.bytes;
+        if (ss.nwg > nwg) return false;
+        const int n = ss.nwg, qd = n >> 3, r = n & 7;
+        for (int b = 0; b < n; ++b) {
+            // the chunk workgroup b takes in the staged launch of this level (XCD-aware order, r3d_kernels.hip)
+            const int xcd = b & 7, idx = b >> 3;
+            const int c = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + idx;
+            if (c >= n) continue;                  // (n < 8: workgroups b >= n do not exist in the staged launch either)
+            for (int t = wgoff[ss.wgoff_off + c]; t < wgoff[ss.wgoff_off + c + 1]; ++t) {
+                const int4 &tl = tiles[ss.tiles_off + t];
+                const int slot = tl.x & 0xff, mi = tl.x >> 8, ks = tl.w;
+                const int id = st[slot] & ~STAGE_SPILL_IN;
+                const ProbSpec &q = pl->probs[id];
+                int d[FWD_TILE_INT4 * 4] = {0};
+                d[0] = id | (mi << 8);
+                d[1] = tl.y;
+                d[2] = tl.z;
+                d[3] = ks;
+                d[5] = fw.cnt_base[id] + tl.y / 32;
+                {   // granules of 64 columns this tile completes for each of its units
+                    const int g0 = tl.z / 64, g1 = std::min(gcols[id], (tl.z + 256 / ks) / 64);
+                    d[6] = std::max(g1 - g0, 0);
+                    if (d[6] <= 0) return false;
+                }
+                const int r1 = std::min(tl.y + mi * 32, M[id]);
+                const int w0 = tl.y / q.rows_per_window, w1 = (r1 - 1) / q.rows_per_window + 1;
+                std::vector<int> deps(q.deps);
+                std::sort(deps.begin(), deps.end());
+                deps.erase(std::unique(deps.begin(), deps.end()), deps.end());
+                int nd = 0;
+                for (int dp : deps) {
+                    const ProbSpec &pq = pl->probs[dp];
+                    const int a0 = w0 * pq.rows_per_window, a1 = std::min(w1 * pq.rows_per_window, M[dp]);
+                    if (a1 <= a0) continue;
+                    const int u0 = a0 / 32, u1 = (a1 + 31) / 32;
+                    if (nd == FWD_MAX_DEP || u1 - u0 > 0xffff || gcols[dp] > 0x7fff) return false;
+                    d[8 + 2 * nd] = fw.cnt_base[dp] + u0;
+                    d[9 + 2 * nd] = (u1 - u0) | (gcols[dp] << 16);
+                    ++nd;
+                }
+                d[4] = nd;
+                lists[b].insert(lists[b].end(), d, d + FWD_TILE_INT4 * 4);
+            }
+        }
+    }
+    out_tiles.clear();
+    out_wgoff.assign(1, 0);
+    int grid = 0;
+    for (int b = 0; b < nwg; ++b) {
+        out_tiles.insert(out_tiles.end(), lists[b].begin(), lists[b].end());
+        out_wgoff.push_back((int)(out_tiles.size() / (FWD_TILE_INT4 * 4)));
+        if (!lists[b].empty()) grid = b + 1;
+    }
+    out_wgoff.resize(grid + 1);
+    fw.grid = grid;
+    fw.ntiles = (int)(out_tiles.size() / (FWD_TILE_INT4 * 4));
+    return grid > 0;
 }
 
 Plan::~Plan() {
@@ -480,6 +594,41 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
         hip_fail(e, "schedule upload");
         delete s;
         return nullptr;
+    }
+    // ---- the single-launch form: tile lists with dependencies + the relative problem tables (rays / UV input)
+    if (forward_single_launch()) {
+        std::vector<int> ft, fo;
+        Schedule::Fwd &fw = s->fwd;
+        if (schedule_build_fwd(pl, B, nwg, *s->levels, s->stages, tiles, wgoff, fw, ft, fo)) {
+            const Model *a = pl->m[0];
+            bool ok = (e = hipMalloc((void **)&fw.d_tiles, ft.size() * sizeof(int))) == hipSuccess &&
+                      (e = hipMalloc((void **)&fw.d_wgoff, fo.size() * sizeof(int))) == hipSuccess &&
+                      (e = hipMemcpy(fw.d_tiles, ft.data(), ft.size() * sizeof(int), hipMemcpyHostToDevice)) == hipSuccess &&
+                      (e = hipMemcpy(fw.d_wgoff, fo.data(), fo.size() * sizeof(int), hipMemcpyHostToDevice)) == hipSuccess;
+            for (int uv = 0; ok && uv < 2; ++uv) {
+                if (uv && a->cfg.in_features != 3) break;
+                std::vector<GemmProb> rel(fw.nprob);
+                std::vector<unsigned char> tags((size_t)fw.nprob * BIND_NPTR);
+                Bases none;
+                CallShape cs;
+                cs.uv = uv != 0;
+                bool filled = true;
+                for (int i = 0; i < fw.nprob && filled; ++i)
+                    filled = fill_prob(pl, pl->probs[i], B, a, none, cs, rel[i], tags.data() + (size_t)i * BIND_NPTR) == R3D_OK;
+                if (!filled) { if (uv) break; ok = false; break; }
+                ok = (e = hipMalloc((void **)&fw.d_rel[uv], rel.size() * sizeof(GemmProb))) == hipSuccess &&
+                     (e = hipMalloc((void **)&fw.d_tags[uv], tags.size())) == hipSuccess &&
+                     (e = hipMemcpy(fw.d_rel[uv], rel.data(), rel.size() * sizeof(GemmProb), hipMemcpyHostToDevice)) == hipSuccess &&
+                     (e = hipMemcpy(fw.d_tags[uv], tags.data(), tags.size(), hipMemcpyHostToDevice)) == hipSuccess;
+            }
+            if (!ok) {
+                hip_fail(e, "schedule upload (single-launch form)");
+                delete s;
+                return nullptr;
+            }
+        } else {
+            fw = Schedule::Fwd();      // this plan runs launch by launch
+        }
     }
     s->pinned = pin;
     pl->schedules[B] = s;

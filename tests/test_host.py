@@ -586,6 +586,40 @@ def test_pairs_with_different_channel_counts_get_one_first_level_kind():
         ht.close()
 
 
+def test_single_launch_forward_is_a_sound_dependency_machine():
+    """The whole forward as ONE persistent launch (r3d_forward_f32): tiles of every level in one list per workgroup,
+    ordered by ready counters instead of kernel boundaries.  r3d_debug_forward_check builds those lists and executes
+    them on the host: every tile gets to run (no waiting cycle with all workgroups resident), every counter ends full,
+    and - independently of the dependency ranges the scheduler wrote - whenever a tile runs, every earlier problem that
+    writes what it reads or touches what it writes (same buffer, overlapping columns) is complete for its windows."""
+    lib = _capi.load()
+    fn = lib.r3d_debug_forward_check
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    fn.restype = ctypes.c_int
+    cases = [(default_model_config(ARCHITECTURE="3,3,3,3,3"), (1, 64, 97, 128, 255, 256, 257, 600, 1024, 2048)),
+             (default_model_config(ARCHITECTURE="3,3"), (64, 256, 1024, 4096)),
+             (default_model_config(ARCHITECTURE="3,3", NUM_KPTS=14), (512, 4096)),
+             (default_model_config(ARCHITECTURE="3,3,3", STAGE=1, CAMERA_EMBDDING=False), (100, 300)),
+             (default_model_config(ARCHITECTURE="3,3,3,3", DISABLE_OPTIMIZATIONS=True, CAUSAL=True), (130,)),
+             (default_model_config(ARCHITECTURE="3,3,3", CHANNELS=128, LATENT_FEATURES_DIM=160, STAGE=2), (256,))]
+    for mc, batches in cases:
+        hp, ht = _capi.Handle(config_from_dicts(mc, "pos")), _capi.Handle(config_from_dicts(mc, "trj"))
+        for pair in ((hp, ht), (hp, None), (None, ht)):
+            for B in batches:
+                n, c = ctypes.c_int(), ctypes.c_int()
+                rc = fn(pair[0].ptr if pair[0] else None, pair[1].ptr if pair[1] else None, B, 256, ctypes.byref(n), ctypes.byref(c))
+                assert rc in (0, 1), (mc["ARCHITECTURE"], B, rc)
+                if B > 96:
+                    assert rc == 0 and n.value > 0 and c.value > 0, (mc["ARCHITECTURE"], B, rc)    # the fused plans run as one launch
+        assert fn(hp.ptr, ht.ptr, 256, 64, ctypes.byref(n), ctypes.byref(c)) == 0                   # a smaller chip
+        hp.close()
+        ht.close()
+    # plans with r3d_gemm_enc_f32 launches (the small plan, more than 256 channels) stay launch by launch
+    hp = _capi.Handle(config_from_dicts(default_model_config(ARCHITECTURE="3,3,3", CHANNELS=512), "pos"))
+    assert fn(hp.ptr, None, 256, 256, ctypes.byref(n), ctypes.byref(c)) == 1
+    hp.close()
+
+
 def test_plans_do_not_outlive_a_partner_model():
     """A (pos, trj) plan holds the partner's layer indices and K paddings.  It is keyed by model ids that are never
     reused and dropped when either model is destroyed: a new trajectory model - which malloc may well place at the old
