@@ -291,9 +291,10 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
 #ifdef R3D_TIMING
         static long long *timing_buf1 = nullptr;
         if (getenv("R3D_TIMING_STAGE")) {
-            if (!timing_buf1) (void)hipMalloc((void **)&timing_buf1, (1024 + 4 * 1024) * 8 + 65536);
-            (void)hipMemsetAsync(timing_buf1, 0, (1024 + 4 * 1024) * 8 + 65536, stream);
-            fa.dbg = timing_buf1;
+            const size_t tbytes = (16384 + 4 * 65536) * 8;
+            if (!timing_buf1) (void)hipMalloc((void **)&timing_buf1, tbytes);
+            (void)hipMemsetAsync(timing_buf1, 0, tbytes, stream);
+            if (fw.ntiles <= 65536) fa.dbg = timing_buf1;
         }
 #endif
         if ((e = launch_forward(fa, fw.grid, uv_launch, stream)) != hipSuccess) return hip_fail(e, "launch r3d_forward_f32");
@@ -314,6 +315,26 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             if (getenv("R3D_TIMING_ALL"))
                 for (int w = 0; w < fw.grid && w < 1024; ++w)
                     fprintf(stderr, "[timing-wg] %d start %.2f end %.2f\n", w, (hw[w * 4 + 2] - w0) / 100.0, (hw[w * 4 + 3] - w0) / 100.0);
+            if (const char *dump = getenv("R3D_TIMING_DUMP")) {      // every tile: who ran it, what it is, fetched / ready / finished
+                std::vector<long long> tt((size_t)fw.ntiles * 4);
+                (void)hipMemcpy(tt.data(), timing_buf1 + 16384, tt.size() * 8, hipMemcpyDeviceToHost);
+                if (FILE *f = fopen(dump, "w")) {
+                    for (int i = 0; i < fw.nprob; ++i) {
+                        const ProbSpec &q = pl->probs[i];
+                        fprintf(f, "P %d %s rows_per_window %d M %lld N %d K %d fused %d\n", i, pl->m[q.model]->layers[q.layer].weight_key.c_str(),
+                                q.rows_per_window, (long long)(B * q.rows_per_window), pl->m[q.model]->layers[q.layer].N,
+                                pl->m[q.model]->layers[q.layer].Kpad, q.layer3 >= 0 ? 3 : q.layer2 >= 0 ? 2 : 1);
+                    }
+                    for (int w = 0; w < fw.grid; ++w)
+                        for (int t = fw.h_wgoff[w]; t < fw.h_wgoff[w + 1]; ++t) {
+                            const int *d = &fw.h_tiles[(size_t)t * FWD_TILE_INT4 * 4];
+                            fprintf(f, "T %d %d %d %d %d %d %d %d %.2f %.2f %.2f %lld\n", w, t, d[0] & 0xff, d[0] >> 8, d[1], d[2], d[3], d[4],
+                                    tt[(size_t)t * 4] ? (tt[(size_t)t * 4] - w0) / 100.0 : -1.0, tt[(size_t)t * 4 + 1] ? (tt[(size_t)t * 4 + 1] - w0) / 100.0 : -1.0,
+                                    tt[(size_t)t * 4 + 2] ? (tt[(size_t)t * 4 + 2] - w0) / 100.0 : -1.0, tt[(size_t)t * 4 + 3]);
+                        }
+                    fclose(f);
+                }
+            }
         }
 #endif
         if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");

@@ -286,6 +286,7 @@ struct Schedule {
         int *d_wgoff = nullptr;
         GemmProb *d_rel[2] = {nullptr, nullptr};        // relative problem tables: rays mode / UV mode (built on first use)
         unsigned char *d_tags[2] = {nullptr, nullptr};
+        std::vector<int> h_tiles, h_wgoff;    // host copies of the lists (diagnostics)
         double flops = 0, bytes = 0;
         bool uses_gather = false;             // some problem gathers from the input (UV mode selects the _uv kernel)
     } fwd;

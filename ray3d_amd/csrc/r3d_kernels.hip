@@ -2039,7 +2039,13 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
             const int ndep = __builtin_amdgcn_readfirstlane(te.x);
             sig_base = __builtin_amdgcn_readfirstlane(te.y);
             sig_add = __builtin_amdgcn_readfirstlane(te.z);
+#ifdef R3D_TIMING
+            if (dbg_arg && threadIdx.x == 0) dbg_arg[16384 + (long long)t * 4 + 0] = wall_clock64();      // tile fetched
+#endif
             if (ndep > 0) wait_deps(tiles + t * TS, ndep, cnt, abort_flag);
+#ifdef R3D_TIMING
+            if (dbg_arg && threadIdx.x == 0) dbg_arg[16384 + (long long)t * 4 + 1] = wall_clock64();      // producers ready
+#endif
         }
         ProbRef P = DEP ? *((const GemmProb __attribute__((address_space(4))) *)fargs->probs + pi) : args->p[pi];
 #ifdef R3D_TIMING
@@ -2079,6 +2085,12 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                     if (mi >= 2) first_level_taps<2, true, UV>(P, tl, TS, n, new_prob, smem, cnt, run_dbg);
                     else first_level_taps<1, true, UV>(P, tl, TS, n, new_prob, smem, cnt, run_dbg);
                 }
+#ifdef R3D_TIMING
+                if (DEP && dbg_arg && threadIdx.x == 0) {                    // (a run: the stamps of its first tile stand for all n)
+                    dbg_arg[16384 + (long long)t * 4 + 2] = wall_clock64();
+                    dbg_arg[16384 + (long long)t * 4 + 3] = n;
+                }
+#endif
                 t += n - 1;
                 signalled = true;        // (every tile of the run has raised its own counters)
                 break;
@@ -2136,6 +2148,12 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                 tile_drain();
                 __syncthreads();
                 tile_signal(cnt, sig_base, sig_add, mi);
+#ifdef R3D_TIMING
+                if (dbg_arg && threadIdx.x == 0) {
+                    dbg_arg[16384 + (long long)t * 4 + 2] = wall_clock64();                               // tile finished
+                    dbg_arg[16384 + (long long)t * 4 + 3] = 1;
+                }
+#endif
             }
         }
     }

@@ -38,7 +38,34 @@ bool forward_single_launch() {
     return on;
 }
 
+// development aid (R3D_FWD_DUMP=<file>): the problems with their producers and every workgroup's tiles
+static void dump_fwd(const Plan *pl, int64_t B, int grid, const std::vector<int> &out_tiles, const std::vector<int> &out_wgoff) {
+    const int np = (int)pl->probs.size();
+    std::vector<int> M(np);
+    for (int i = 0; i < np; ++i) M[i] = (int)(B * pl->probs[i].rows_per_window);
+    if (const char *dump = getenv("R3D_FWD_DUMP")) {             // development aid: problems (with producers) and every workgroup's tiles
+        if (FILE *f = fopen(dump, "w")) {
+            for (int i = 0; i < np; ++i) {
+                const ProbSpec &q = pl->probs[i];
+                const Model *mm = pl->m[q.model];
+                fprintf(f, "P %d %s rpw %d M %d N %d K %d K2 %d K3 %d deps", i, mm->layers[q.layer].weight_key.c_str(), q.rows_per_window, M[i],
+                        mm->layers[q.layer].N, mm->layers[q.layer].Kpad, q.layer2 >= 0 ? mm->layers[q.layer2].Kpad : 0,
+                        q.layer3 >= 0 ? mm->layers[q.layer3].Kpad : 0);
+                for (int dpi : q.deps) fprintf(f, " %d", dpi);
+                fprintf(f, "\n");
+            }
+            for (int b = 0; b < grid; ++b)
+                for (int t = out_wgoff[b]; t < out_wgoff[b + 1]; ++t) {
+                    const int *d = &out_tiles[(size_t)t * FWD_TILE_INT4 * 4];
+                    fprintf(f, "T %d %d %d %d %d %d %d\n", b, t, d[0] & 0xff, d[0] >> 8, d[1], d[2], d[3]);
+                }
+            fclose(f);
+        }
+    }
+}
+
 static int64_t units_of(int64_t B, const ProbSpec &q) { return (B * q.rows_per_window + 31) / 32; }
+static SchedProb sched_prob_of(const Plan *pl, const ProbSpec &q, int64_t B);
 
 size_t fwd_ctrl_bytes(const Plan *pl, int64_t B) {
     int64_t ncnt = 0;
@@ -138,6 +165,7 @@ bool schedule_build_fwd(const Plan *pl, int64_t B, int nwg, const std::vector<st
     out_wgoff.resize(grid + 1);
     fw.grid = grid;
     fw.ntiles = (int)(out_tiles.size() / (FWD_TILE_INT4 * 4));
+    dump_fwd(pl, B, grid, out_tiles, out_wgoff);
     return grid > 0;
 }
 
@@ -386,21 +414,11 @@ void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units,
     out.makespan = best->a.worst;
 }
 
-// `spill_row0`: rows [spill_row0, M) of Plan::spill_prob belong to the launch that lists it with STAGE_SPILL_IN, the
-// rows before to its own launch (-1: all rows stay).
-static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, int nwg, int spill_row0, std::vector<int4> &tiles,
-                        std::vector<int> &wgoff, StageSchedule &out) {
-    std::vector<SchedProb> probs;
-    double flops = 0, bytes = 0;
-    for (int i = 0; i < (int)st.size(); ++i) {
-        const int id = st[i] & ~STAGE_SPILL_IN;
-        const ProbSpec &q = pl->probs[id];
+// What the packers need to know about one problem of the plan at B windows: K-loop iterations of a 32-row unit (nk, plus
+// nk2 for the further layers of fused tiles and for measured extras), how far it may be cut along K, the tile height cap.
+static SchedProb sched_prob_of(const Plan *pl, const ProbSpec &q, int64_t B) {
         const Layer &L = pl->m[q.model]->layers[q.layer];
-        const int M_all = (int)(B * q.rows_per_window);
-        int M = M_all, row0 = 0;
-        if (st[i] & STAGE_SPILL_IN) row0 = spill_row0 >= 0 ? spill_row0 : M_all;
-        else if (id == pl->spill_prob && spill_row0 >= 0) M = spill_row0;
-        const double share = M_all > 0 ? (double)(M - row0) / M_all : 0.0;
+        const int M = (int)(B * q.rows_per_window);
         // fused-prologue tiles hold the whole encoded operand in 64 KiB of LDS: rows * (K + 4) floats
         const int enc_cap = q.enc_lut >= 0 ? std::max(1, std::min(3, (64 * 1024) / ((L.Kpad + 4) * 4 * 32))) : 0;
         // split-K sub-tiles of one iteration must come from one buffer of a concatenated operand
@@ -448,6 +466,26 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
                 sp.nk2 = (sp.nk2 * 5 + 8) / 9;
             }
         }
+        return sp;
+}
+
+// `spill_row0`: rows [spill_row0, M) of Plan::spill_prob belong to the launch that lists it with STAGE_SPILL_IN, the
+// rows before to its own launch (-1: all rows stay).
+static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, int nwg, int spill_row0, std::vector<int4> &tiles,
+                        std::vector<int> &wgoff, StageSchedule &out) {
+    std::vector<SchedProb> probs;
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < (int)st.size(); ++i) {
+        const int id = st[i] & ~STAGE_SPILL_IN;
+        const ProbSpec &q = pl->probs[id];
+        const Layer &L = pl->m[q.model]->layers[q.layer];
+        const int M_all = (int)(B * q.rows_per_window);
+        int M = M_all, row0 = 0;
+        if (st[i] & STAGE_SPILL_IN) row0 = spill_row0 >= 0 ? spill_row0 : M_all;
+        else if (id == pl->spill_prob && spill_row0 >= 0) M = spill_row0;
+        const double share = M_all > 0 ? (double)(M - row0) / M_all : 0.0;
+        SchedProb sp = sched_prob_of(pl, q, B);
+        sp.M = M;
         sp.row0 = row0;
         probs.push_back(sp);
         flops += q.flops_per_window * (double)B * share;
@@ -621,6 +659,8 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
                      (e = hipMemcpy(fw.d_rel[uv], rel.data(), rel.size() * sizeof(GemmProb), hipMemcpyHostToDevice)) == hipSuccess &&
                      (e = hipMemcpy(fw.d_tags[uv], tags.data(), tags.size(), hipMemcpyHostToDevice)) == hipSuccess;
             }
+            fw.h_tiles = ft;
+            fw.h_wgoff = fo;
             if (!ok) {
                 hip_fail(e, "schedule upload (single-launch form)");
                 delete s;
