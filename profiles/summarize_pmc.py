@@ -49,8 +49,12 @@ for a, b, c, d in zip(f1, f2, f3, f4):
         b['SQ_LDS_IDX_ACTIVE'] / 1e6, b['GRBM_GUI_ACTIVE'] / 8 / (b['t1'] - b['t0']), c['FETCH_SIZE'] * 2 / 1e3,
         d['WRITE_SIZE'] / 1e3, 100 * d['TCC_HIT_sum'] / max(1, d['TCC_HIT_sum'] + d['TCC_MISS_sum'])))
 
-tot_f = sum(c['FETCH_SIZE'] * 2 / 1e3 for c in f3 if c['name'].startswith('r3d_gemm'))
-tot_w = sum(d['WRITE_SIZE'] / 1e3 for d in f4 if d['name'].startswith('r3d_gemm'))
-n = sum(1 for c in f3 if c['name'].startswith('r3d_gemm'))
-print('# r3d_gemm*: %d launches, fetch %.1f MB + write %.1f MB per forward = %.0f bytes per launch (profiles/traffic.json)'
-      % (n, tot_f, tot_w, (tot_f + tot_w) * 1e6 / max(n, 1)))
+MAIN = ('r3d_gemm', 'r3d_forward')      # the GEMM launches of the staged form / the single launch that holds all of them
+tot_f = sum(c['FETCH_SIZE'] * 2 / 1e3 for c in f3 if c['name'].startswith(MAIN))
+tot_w = sum(d['WRITE_SIZE'] / 1e3 for d in f4 if d['name'].startswith(MAIN))
+n = sum(1 for c in f3 if c['name'].startswith(MAIN))
+busy = sum(a['SQ_VALU_MFMA_BUSY_CYCLES'] for a in f1 if a['name'].startswith(MAIN))
+dur = sum((a['t1'] - a['t0']) / 1e3 for a in f1 if a['name'].startswith(MAIN))
+print('# %s: %d launch(es), fetch %.1f MB + write %.1f MB per forward = %.0f bytes per launch (profiles/traffic.json); '
+      'MFMA-busy %.1f M SIMD-cycles over %.1f us' % ('/'.join(sorted(set(c['name'].split('(')[0][:18] for c in f3 if c['name'].startswith(MAIN)))),
+                                                     n, tot_f, tot_w, (tot_f + tot_w) * 1e6 / max(n, 1), busy / 1e6, dur))
