@@ -206,7 +206,7 @@ int r3d_precision(const r3d_model *m);
 
 /* Builds the static tile schedule of ONE launch for `nprob` GEMM problems (rows M[i], columns N[i], nk[i] K tiles of
  * 32, largest split-K factor max_ks[i], cap on 32-row units per tile max_units[i]) on `nwg` workgroups and verifies
- * that the tiles cover every (32-row unit, 64-column granule) exactly once within the kernel's tile-shape rules.
+ * that the tiles cover every (32-row unit, 32-column granule) exactly once within the kernel's tile-shape rules.
  * Returns 0, or a negative code naming the first violated rule. */
 int r3d_debug_schedule_check(int nprob, const int *M, const int *N, const int *nk, const int *max_ks,
                              const int *max_units, int nwg, int enc, int *out_grid, int *out_tiles,

@@ -586,7 +586,7 @@ int r3d_profile_read(r3d_model *m, r3d_launch_record *records, int capacity) {
 }
 
 // Test hook: build the static schedule of one launch on the host and verify
-// that its tiles cover every (32-row unit, 64-column granule) of every problem exactly once within the
+// that its tiles cover every (32-row unit, 32-column granule) of every problem exactly once within the
 // kernel's tile-shape limits.  Returns 0 or a negative code naming the first violated rule.
 int r3d_debug_schedule_check(int nprob, const int *M, const int *N, const int *nk, const int *max_ks, const int *max_units,
                              int nwg, int enc, int *out_grid, int *out_tiles, double *out_imbalance) {
@@ -604,18 +604,18 @@ int r3d_debug_schedule_check(int nprob, const int *M, const int *N, const int *n
     for (size_t i = 1; i < wgoff.size(); ++i)
         if (wgoff[i] <= wgoff[i - 1] && ss.ntiles > 0) return -3;          // empty or unordered chunk
     std::vector<std::vector<int>> cover(nprob);
-    for (int i = 0; i < nprob; ++i) cover[i].assign((size_t)((M[i] + 31) / 32) * ((N[i] + 63) / 64), 0);
+    for (int i = 0; i < nprob; ++i) cover[i].assign((size_t)((M[i] + 31) / 32) * ((N[i] + COL_GRANULE - 1) / COL_GRANULE), 0);
     for (const int4 &t : tiles) {
         const int pi = t.x & 0xff, mi = t.x >> 8, ks = t.w;
-        if (pi >= nprob || mi < 1 || (ks != 1 && ks != 2 && ks != 4)) return -4;
-        if (ks > max_ks[pi]) return -5;
-        if ((ks == 1 && mi > (max_units[pi] > 0 ? std::min(max_units[pi], GEMM_SCHED_MAX_UNITS) : GEMM_SCHED_MAX_UNITS)) || (ks == 2 && mi > 2) || (ks == 4 && mi != 1)) return -6;
-        if (t.y % 32 || t.y < 0 || t.y >= M[pi] || t.z % (256 / ks) || t.z < 0 || t.z >= N[pi]) return -7;
-        if (ks > 1 && (nk[pi] + ks - 1) / ks < 2) return -8;
-        const int gcols = (N[pi] + 63) / 64;
+        if (pi >= nprob || mi < 1 || (ks != 1 && ks != 2 && ks != 4 && ks != 8)) return -4;
+        if (ks != 8 && ks > max_ks[pi]) return -5;
+        if ((ks == 1 && mi > (max_units[pi] > 0 ? std::min(max_units[pi], GEMM_SCHED_MAX_UNITS) : GEMM_SCHED_MAX_UNITS)) || (ks == 2 && mi > 2) || (ks >= 4 && mi != 1)) return -6;
+        if (t.y % 32 || t.y < 0 || t.y >= M[pi] || t.z % tile_width(ks) || t.z < 0 || t.z >= N[pi]) return -7;
+        if (ks > 1 && ks != 8 && (nk[pi] + ks - 1) / ks < 2) return -8;
+        const int gcols = (N[pi] + COL_GRANULE - 1) / COL_GRANULE;
         for (int u = t.y / 32; u < t.y / 32 + mi; ++u) {
             if (u * 32 >= M[pi]) return -9;
-            for (int g = t.z / 64; g < (t.z + 256 / ks) / 64 && g < gcols; ++g) ++cover[pi][(size_t)u * gcols + g];
+            for (int g = t.z / COL_GRANULE; g < (t.z + tile_width(ks)) / COL_GRANULE && g < gcols; ++g) ++cover[pi][(size_t)u * gcols + g];
         }
     }
     for (int i = 0; i < nprob; ++i)
@@ -625,7 +625,7 @@ int r3d_debug_schedule_check(int nprob, const int *M, const int *N, const int *n
 }
 
 // Test hook: the whole forward's tile lists for `batch` windows on `nwg` CUs, built on the host (no device needed):
-// every 32-row x 64-column cell of every problem must be computed exactly once over all launches, a problem's
+// every 32-row x 32-column cell of every problem must be computed exactly once over all launches, a problem's
 // tiles must sit in launches that list it, and a consumer's launch must come after all of its producers' tiles.
 // Returns 0, or a negative code; *spilled = rows of the first level that run one launch late.
 int r3d_debug_plan_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg, int *launches, int *spilled) {
@@ -646,7 +646,7 @@ int r3d_debug_plan_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg,
     for (int i = 0; i < np; ++i) {
         const ProbSpec &q = pl->probs[i];
         const int M = (int)(batch * q.rows_per_window), N = pl->m[q.model]->layers[q.layer].N;
-        cover[i].assign((size_t)((M + 31) / 32) * ((N + 63) / 64), 0);
+        cover[i].assign((size_t)((M + 31) / 32) * ((N + COL_GRANULE - 1) / COL_GRANULE), 0);
     }
     for (size_t si = 0; si < stages.size(); ++si) {
         const StageSchedule &ss = stages[si];
@@ -671,10 +671,10 @@ int r3d_debug_plan_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg,
                 if (spill_row0 < 0 ? late : (late != (tl.y >= spill_row0))) return -6;
                 if (late && spilled) *spilled += std::min(mi * 32, M - tl.y);
             }
-            const int gcols = (N + 63) / 64;
+            const int gcols = (N + COL_GRANULE - 1) / COL_GRANULE;
             for (int u = tl.y / 32; u < tl.y / 32 + mi; ++u) {
                 if (u * 32 >= M) return -7;
-                for (int g = tl.z / 64; g < (tl.z + 256 / ks) / 64 && g < gcols; ++g) ++cover[id][(size_t)u * gcols + g];
+                for (int g = tl.z / COL_GRANULE; g < (tl.z + tile_width(ks)) / COL_GRANULE && g < gcols; ++g) ++cover[id][(size_t)u * gcols + g];
             }
             last_launch[id] = std::max(last_launch[id], (int)si);
             first_launch[id] = std::min(first_launch[id], (int)si);
@@ -711,7 +711,7 @@ int r3d_debug_forward_check(r3d_model *pos, r3d_model *trj, int64_t batch, int n
     if (out_counters) *out_counters = fw.ncnt;
     const int np = (int)pl->probs.size(), TI = FWD_TILE_INT4 * 4;
     std::vector<int> gcols(np);
-    for (int i = 0; i < np; ++i) gcols[i] = (pl->m[pl->probs[i].model]->layers[pl->probs[i].layer].N + 63) / 64;
+    for (int i = 0; i < np; ++i) gcols[i] = (pl->m[pl->probs[i].model]->layers[pl->probs[i].layer].N + COL_GRANULE - 1) / COL_GRANULE;
     std::vector<unsigned> cnt(fw.ncnt, 0);
     // column range a problem reads / writes in a workspace buffer
     struct Acc { int buf, c0, c1; };

@@ -85,12 +85,12 @@ struct LaunchArgs {
 // ---- the whole forward as ONE persistent launch (r3d_forward_f32): tiles of every DAG level in one list per workgroup,
 // ordered by tile-level dependencies instead of kernel boundaries.  The network is row-local - a tile of rows R of layer L
 // reads rows of layer L-1 that belong to the same windows - so a tile waits for exactly the producer tiles of its
-// windows: one ready counter per (problem, 32-row unit) in the caller's workspace counts finished 64-column granules.
+// windows: one ready counter per (problem, 32-row unit) in the caller's workspace counts finished 32-column granules.
 constexpr int FWD_TILE_INT4 = 6;        // a tile descriptor: 24 ints (below)
 constexpr int FWD_MAX_DEP = 8;
 // ints of a descriptor: [0] problem | units << 8   [1] first row   [2] first column   [3] split-K factor
 //                       [4] number of dependency ranges   [5] index of the first unit's ready counter
-//                       [6] granules (64 columns) this tile adds to each of its units' counters   [7] unused
+//                       [6] granules (32 columns) this tile adds to each of its units' counters   [7] unused
 //                       [8 + 2d] first counter of range d   [9 + 2d] counters in the range | granules required << 16
 struct FwdArgs {
     const int4 *tiles;        // FWD_TILE_INT4 int4 per tile
@@ -359,7 +359,11 @@ struct SchedProb {
     int max_units;   // per-problem cap on 32-row units per tile (0 = the launch default)
     int nk2 = 0;     // K-loop iterations of the fused further layers, in 32-row units (cost only)
     int row0 = 0;    // first row this launch computes (a multiple of 32): rows [row0, M)
+    bool gemv = false;   // M <= GEMV_ROWS rows of a plain layer: 32-column GEMV tiles (tile code ks == 8), r3d_kernels.hip gemv_tile
 };
+constexpr int GEMV_ROWS = 4;          // == GEMV_MAX_M of the kernels (at eight rows the MFMA split-K tiles are the faster ones: 0.207 against 0.222 ms)
+constexpr int COL_GRANULE = 32;       // ready counters and cover checks count columns in granules of this many
+inline int tile_width(int ks) { return ks == 8 ? 32 : 256 / ks; }     // columns of a tile by its split code (8: a GEMV tile)
 void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units, std::vector<int4> &tiles,
                     std::vector<int> &wgoff, StageSchedule &out, bool enc = false);
 // index of weight element (output channel o, GEMM column k) in the fragment-ordered packing

@@ -81,7 +81,7 @@ __device__ __forceinline__ void act_store1(__amdgpu_buffer_rsrc_t r, int byte_of
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, ACT_AUX);
 }
 // A tile is finished when its write-through stores have left the CU: every storing wavefront drains, a barrier, then
-// one relaxed agent-scope add per 32-row unit on the unit's ready counter (granules of 64 columns).  The callers'
+// one relaxed agent-scope add per 32-row unit on the unit's ready counter (granules of 32 columns).  The callers'
 // barrier is the one that ends the tile anyway.
 __device__ __forceinline__ void tile_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void tile_signal(const gu32 cnt, const int sig_base, const int sig_add, const int units) {
@@ -1950,6 +1950,91 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
     }
 }
 
+// ------------------------------------------------------------------------------------ calls of a few windows: GEMV tiles
+//
+// A problem of M <= 4 rows (the MLPs and the top of the conv pyramid in calls of up to four windows) has nothing for a
+// 32-row MFMA tile to chew on: its time is the latency of a K loop - barriers, LDS round trips, a dependent MFMA chain -
+// around a weight stream of a megabyte.  gemv_tile takes one 32-column block of such a problem and makes the stream the
+// only thing that takes time: the eight wavefronts split K tile-wise (wavefront w: K tiles w, w + 8, ...), every
+// wavefront requests ALL its weight fragments up front (the fragment order of the MFMA path: a lane owns one column and
+// sixteen k of a K tile) - one memory round trip - while the workgroup copies the M operand rows into LDS; then plain FMAs
+// (16 per row and K tile), the two k-halves of a wavefront and the eight wavefronts' partial sums added through LDS, bias /
+// LeakyReLU / residual, one 128-byte row segment per row.  32 tiles per 1024-column layer: the five FuseBlocks' layers
+// of a one-window call occupy 160 CUs instead of 80, each for a third of the time.
+constexpr int GEMV_MAX_M = 4;
+__device__ __forceinline__ float act_ld(const float *p) {
+    return __builtin_bit_cast(float, __hip_atomic_load((gu32)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // 4-byte sc1 load
+}
+__device__ __forceinline__ void gemv_tile(ProbRef P, const int col0, float *smem) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int M = P.M, K = P.K, N = P.N, nk32 = K / BK;
+    const int ldA = K + 8;
+    float *As = smem, *red = smem + GEMV_MAX_M * ldA;
+    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.w + (size_t)(col0 >> 5) * nk32 * 1024), 0, nk32 * 4096, 0x00020000);   // (K tiles past the end read as zeros)
+    f32x4 wf[4][4];
+    auto load_round = [&](int j0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                wf[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16 + q * 1024, (wave_u + 8 * (j0 + j)) * 4096, 0));
+    };
+    load_round(0);
+    // the operand rows -> LDS (a virtual concatenation of up to MAX_SEG buffers; every column of such a problem is real)
+    {
+        const int e0 = P.kend[0], e1 = P.kend[1], e2 = P.kend[2];
+        const float *a0 = P.a[0], *a1 = P.a[1], *a2 = P.a[2], *a3 = P.a[3];
+        const int l0 = P.lda[0], l1 = P.lda[1], l2 = P.lda[2], l3 = P.lda[3];
+        for (int r = 0; r < M; ++r)
+            for (int k = tid; k < K; k += GEMM_THREADS) {
+                const float *src = k < e0 ? a0 + (size_t)r * l0 + k : k < e1 ? a1 + (size_t)r * l1 + (k - e0)
+                                 : k < e2 ? a2 + (size_t)r * l2 + (k - e1) : a3 + (size_t)r * l3 + (k - e2);
+                As[r * ldA + k] = act_ld(src);
+            }
+    }
+    __syncthreads();
+    float acc[GEMV_MAX_M];
+#pragma unroll
+    for (int r = 0; r < GEMV_MAX_M; ++r) acc[r] = 0.0f;
+    for (int j0 = 0; wave_u + 8 * j0 < nk32; j0 += 4) {
+        if (j0) load_round(j0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kt = wave_u + 8 * (j0 + j);
+            if (kt >= nk32) break;                                  // (uniform)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < GEMV_MAX_M; ++r) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(As + (r < M ? r : M - 1) * ldA + kt * BK + lh * 16 + q * 4);
+                    acc[r] += a[0] * wf[j][q][0] + a[1] * wf[j][q][1] + a[2] * wf[j][q][2] + a[3] * wf[j][q][3];
+                }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < GEMV_MAX_M; ++r) {
+        acc[r] += __shfl_xor(acc[r], 32, 64);                       // the two k-halves of the wavefront
+        if (lh == 0) red[(wave * GEMV_MAX_M + r) * 32 + li] = acc[r];
+    }
+    __syncthreads();
+    if (tid < M * 32) {
+        const int r = tid >> 5, c = tid & 31, col = col0 + c;
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += red[(w * GEMV_MAX_M + r) * 32 + c];
+        if (col < N) {
+            v = lrelu(v + gload1(P.bias + col), P.slope);
+            if (P.res) v += act_ld(P.res + (size_t)r * P.ldr + col);
+            __hip_atomic_store((gu32)(P.c + (size_t)r * P.ldc + col), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();                                                // the next tile may write LDS
+}
+
 // ------------------------------------------------------------------------------------ tile-level dependencies
 //
 // r3d_forward_f32 runs the tiles of EVERY level of the network in one launch.  What orders them is data: a tile's
@@ -2116,6 +2201,10 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                     case 3: gemm_tile_b3<3>(P, row0, col0, smem, dbg); break;
                     default: gemm_tile_b3<4>(P, row0, col0, smem, dbg); break;
                 }
+                break;
+            }
+            if (ks == 8) {               // a problem of a few rows: one 32-column block, K split over the wavefronts, no MFMA
+                gemv_tile(P, col0, smem);
                 break;
             }
             if (ks > 1) {

@@ -98,7 +98,7 @@ bool schedule_build_fwd(const Plan *pl, int64_t B, int nwg, const std::vector<st
         fw.prob_of_slot[i] = i;
         fw.cnt_base[i] = ncnt;
         ncnt += (int)units_of(B, q);
-        gcols[i] = (pl->m[q.model]->layers[q.layer].N + 63) / 64;
+        gcols[i] = (pl->m[q.model]->layers[q.layer].N + COL_GRANULE - 1) / COL_GRANULE;
         M[i] = (int)(B * q.rows_per_window);
         if (q.enc_lut >= 0) fw.uses_gather = true;
     }
@@ -129,7 +129,7 @@ bool schedule_build_fwd(const Plan *pl, int64_t B, int nwg, const std::vector<st
                 d[3] = ks;
                 d[5] = fw.cnt_base[id] + tl.y / 32;
                 {   // granules of 64 columns this tile completes for each of its units
-                    const int g0 = tl.z / 64, g1 = std::min(gcols[id], (tl.z + 256 / ks) / 64);
+                    const int g0 = tl.z / COL_GRANULE, g1 = std::min(gcols[id], (tl.z + tile_width(ks)) / COL_GRANULE);
                     d[6] = std::max(g1 - g0, 0);
                     if (d[6] <= 0) return false;
                 }
@@ -199,6 +199,10 @@ double unit_cycles(int iters, int ks) {
     return iters * 2200.0 + 2500.0 + (iters < 4 ? (4 - iters) * 1400.0 : 0.0);
 }
 
+// a GEMV tile (r3d_kernels.hip): one memory round trip for the weights of its 32 columns, the operand copy, two barriers,
+// the reduction and the store - ~4 us plus the stream (K tiles / 8 per wavefront)
+double gemv_cycles(int nk) { return 8000.0 + nk / 8.0 * 900.0; }
+
 struct Run {           // `n` consecutive row units of one column block, all in one workgroup's chunk
     int prob, col0, ks, u0, n, cap;
 };
@@ -207,6 +211,7 @@ struct Seg {           // one column block of a problem
     int prob, col0, units, nk, cap, max_ks;
     double c1;
     int ncols;         // columns of the problem inside this block (<= 256)
+    bool gemv = false; // 32-column GEMV tiles instead of row units
 };
 
 struct Assignment {
@@ -234,6 +239,19 @@ bool assign(const std::vector<Seg> &segs, int nbins, double T, int ksplit, Assig
         if (s.c1 == top_c1) top_units += s.units;
     const int top_cap = (int)std::max<long long>(1, (top_units + nbins - 1) / nbins);
     for (const Seg &s : segs) {          // sorted by c1, descending
+        if (s.gemv) {
+            // one tile per 32 columns, each to the workgroup with the most room (they are many and short)
+            const double ck = gemv_cycles(s.nk);
+            for (int j = 0; j * 32 < s.ncols; ++j) {
+                int best = 0;
+                for (int b = 1; b < nbins; ++b)
+                    if (room[b] > room[best]) best = b;
+                if (room[best] + 1e-6 < ck) return false;
+                room[best] -= ck;
+                if (out) out->bins[best].push_back({s.prob, s.col0 + j * 32, 8, 0, 1, 1});
+            }
+            continue;
+        }
         if (s.c1 != cursor_cost) { cursor = 0; cursor_cost = s.c1; }
         const int spread = s.c1 == top_c1 && segs.back().c1 != top_c1 ? top_cap : 1 << 30;
         int u = 0;
@@ -322,12 +340,21 @@ void pack(const std::vector<SchedProb> &probs, int nbins_max, int max_units, Pac
         const int units = (std::max(p.M - p.row0, 0) + 31) / 32;
         const double c1 = unit_cycles(p.nk + p.nk2, 1);
         for (int c0 = 0; c0 < p.N; c0 += 256) {
-            segs.push_back({i, c0, units, p.nk, p.max_units > 0 ? std::min(p.max_units, max_units) : max_units, p.max_ks, c1,
-                            std::min(256, p.N - c0)});
+            Seg sg{i, c0, units, p.nk, p.max_units > 0 ? std::min(p.max_units, max_units) : max_units, p.max_ks, c1,
+                   std::min(256, p.N - c0)};
+            sg.gemv = p.gemv && units == 1 && p.row0 == 0;
+            segs.push_back(sg);
+            if (sg.gemv) {
+                const int pieces = (sg.ncols + 31) / 32;
+                total += pieces * gemv_cycles(p.nk);
+                total_units += pieces;
+                continue;
+            }
             total += units * c1;
             total_units += units;
         }
-        if (p.max_ks < 2) biggest_fixed = std::max(biggest_fixed, c1);
+        if (p.gemv && units == 1 && p.row0 == 0) biggest_fixed = std::max(biggest_fixed, gemv_cycles(p.nk));
+        else if (p.max_ks < 2) biggest_fixed = std::max(biggest_fixed, c1);
     }
     std::stable_sort(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) { return a.c1 > b.c1; });
     const int nbins = (int)std::min<long long>(nbins_max, std::max<long long>(total_units * 4, 1));
@@ -338,7 +365,7 @@ void pack(const std::vector<SchedProb> &probs, int nbins_max, int max_units, Pac
     for (int ksplit = 2; ksplit <= 4; ksplit *= 2) {
         if (ksplit > 2 && widest_split < ksplit) break;      // (nothing in this launch can be cut that finely: same packing)
         double lo = std::max(total / nbins, biggest_fixed), top = std::max(total, lo) + 1.0;
-        for (const Seg &s : segs) top = std::max(top, s.c1 * s.units + 1.0);
+        for (const Seg &s : segs) top = std::max(top, (s.gemv ? gemv_cycles(s.nk) * 8 : s.c1 * s.units) + 1.0);
         // gallop up from the ideal budget (a feasible one is rarely more than a unit above it), then bisect
         double hi = lo;
         if (!assign(segs, nbins, lo, ksplit, nullptr)) {
@@ -429,6 +456,9 @@ static SchedProb sched_prob_of(const Plan *pl, const ProbSpec &q, int64_t B) {
         }
         SchedProb sp{M, L.N, L.Kpad / BK, max_ks, enc_cap};
         if (q.nseg == 1 && q.seg[0].width < L.Kpad) sp.max_ks = 1;   // an operand narrower than its padded K: one bounded descriptor
+        // a plain layer of a few rows (calls of up to eight windows: the MLPs, the top of the pyramid): GEMV tiles
+        sp.gemv = M <= GEMV_ROWS && q.enc_lut < 0 && q.layer2 < 0 && !(q.nseg == 1 && q.seg[0].width < L.Kpad) && L.Kpad >= 64 &&
+                  !env_on("R3D_NO_GEMV");
         const bool b3 = B >= b3_min_batch();               // (r3d_api.cpp passes the bf16x3 operands under the same condition)
         if (b3 && L.bf3 && q.layer2 < 0 && q.enc_lut < 0) {   // bf16-matrix-core tiles: whole tiles of <= 128 rows, ~1.5x the iteration rate
             sp.max_ks = 1;

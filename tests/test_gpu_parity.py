@@ -86,6 +86,31 @@ def test_lifter_matches_oracle_ragged_batches(arch, batch, fused, monkeypatch):
     check_parity(out, ref)
 
 
+@pytest.mark.parametrize("over", [dict(ARCHITECTURE="3,3,3,3,3"), dict(ARCHITECTURE="3,3", NUM_KPTS=14),
+                                  dict(ARCHITECTURE="3,3,3", STAGE=1, CAMERA_EMBDDING=False)])
+def test_calls_of_one_to_four_windows_run_the_gemv_tiles(over, monkeypatch):
+    """Calls of up to four windows: every layer with at most four rows (the MLPs, the top of the pyramid) runs as
+    32-column GEMV tiles (r3d_kernels.hip, gemv_tile: weights streamed once, K split over the wavefronts, no MFMA) -
+    against the oracle, and against the MFMA split-K tiles the same call would use otherwise (R3D_NO_GEMV=1)."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    from oracle import oracle
+    mc = ray3d_amd.default_model_config(**over)
+    for B in (1, 2, 3, 4):
+        outs = []
+        for no_gemv in ("0", "1"):
+            monkeypatch.setenv("R3D_NO_GEMV", no_gemv)
+            pos, trj, (cp, sp), (ct, st) = build_modules(mc)          # (the switch is read when a schedule is built: fresh handles)
+            x, p = synth.synth_rays(B, cp, seed=91), synth.synth_param(B, seed=92)
+            pt = torch.from_numpy(p).cuda() if cp.camera_embedding else None
+            with torch.no_grad():
+                outs.append(ray3d_amd.Ray3DLifter(pos, trj).eval()(torch.from_numpy(x).cuda(), pt).cpu().numpy())
+        ref = oracle.forward(cp, sp, x, p) + oracle.forward(ct, st, x, p)
+        check_parity(outs[0], ref, "%d windows, GEMV tiles" % B)
+        check_parity(outs[1], ref, "%d windows, MFMA split-K tiles" % B)
+        assert not np.array_equal(outs[0], outs[1])                  # (two different evaluations)
+
+
 def test_forward_clip_equals_materialised_windows():
     """In-kernel sliding windows (window_stride = 1) == eval_data_prepare's copies (trainer.py:47-58)."""
     import ray3d_amd
