@@ -516,6 +516,11 @@ def main():
             torch.cuda.synchronize()
             # parity gate BEFORE the timed region (every rank: its own device runs its own copy of the weights)
             parity_err, parity_ref = parity_gate(lifter, dev, args.batch)
+            # the literal command first - W warm-up steps, K timed steps, the GPU's clocks still ramping (a process starts in a
+            # low power state) - reported beside the sustained number, never instead of it
+            torch.cuda.synchronize()
+            time.sleep(0.2)
+            el_cold, _, _ = timed_steps(lambda: lifter(x, p), args.steps, args.warmup, barrier, dev)
             settle_steps = settle_clocks(lambda: lifter(x, p), dev)
             elapsed_own, dev_s, out = timed_steps(lambda: lifter(x, p), args.steps, args.warmup, barrier, dev)
         elapsed = max_over_ranks(elapsed_own)
@@ -532,6 +537,7 @@ def main():
                            "parallelism": "dp%d (independent window batches, no data-path collective)" % world,
                            "schedule_build_ms": round(prepare_ms, 1),
                            "clock_settle_steps": settle_steps,
+                           "ms_per_step_before_clock_settle": round(el_cold / args.steps * 1e3, 4),   # the same K steps right after W warm-up steps from idle clocks
                            "world_size_observed": world if dist is None else dist.get_world_size(),
                            "ms_per_step_per_rank": [round(v, 4) for v in per_rank_ms]},
                 "parity_max_abs_err": parity_err,
