@@ -34,6 +34,9 @@ struct Builder {
         return (int)p.buffers.size() - 1;
     }
     bool first_level_fused = false;
+    bool enc_in_gemm = false;    // gathered first layers as enc_tile problems of r3d_gemm_f32 (not r3d_gemm_enc_f32): calls of few windows,
+                                 // where the second kernel's two-workgroups-per-CU overlap buys nothing and a launch of its own shape
+                                 // would keep the call out of the single-launch form
     bool fuse_pairs = true;
     bool fuse_top = false;       // the top pyramid level (one row per window) as a fused pair too
     struct In { int buf, col, ld, width, dep; };
@@ -49,7 +52,7 @@ struct Builder {
         q.layer3 = -1;
         q.enc_lut = enc_lut;
         q.enc_lut_uv = m.cfg.in_features == 3 ? enc_lut_uv : -1;
-        q.enc_kernel = enc_lut >= 0 && !first_level_fused;
+        q.enc_kernel = enc_lut >= 0 && !first_level_fused && !enc_in_gemm;
         q.enc_rows = rows_pw;
         q.enc_step = 3;
         const Layer &L0 = m.layers[q.layer];
@@ -70,7 +73,7 @@ struct Builder {
         q.c_buf = c_buf; q.c_col = c_col; q.c_ld = c_ld;
         // level 0 is the fused-prologue launch (encoded operands only) - unless the first level runs fused in the
         // GEMM kernel, which takes plain problems alongside
-        q.depth = enc_lut >= 0 || first_level_fused ? 0 : 1;
+        q.depth = enc_lut >= 0 || first_level_fused || enc_in_gemm ? 0 : 1;
         for (int d : q.deps) q.depth = std::max(q.depth, p.probs[d].depth + 1);
         q.flops_per_window = 2.0 * rows_pw * (double)L.K * (double)L.N;
         p.probs.push_back(q);
@@ -227,6 +230,7 @@ static Plan *build_plan(const Model *a, const Model *b, int kind) {
             for (const Model *mm : pl->m)
                 if (mm) all = all && can_fuse(mm);
             B.first_level_fused = all && !small && !env_on("R3D_NO_FIRST_FUSE");
+            B.enc_in_gemm = small && !env_on("R3D_SMALL_ENC_KERNEL");
             B.fuse_pairs = (kind == PLAN_FUSED || kind == PLAN_LARGE) && !env_on("R3D_NO_PAIR_FUSE");
             B.fuse_top = kind == PLAN_LARGE;
         }
