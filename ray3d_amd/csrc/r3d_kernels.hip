@@ -1984,6 +1984,11 @@ __device__ __forceinline__ void gemv_tile(ProbRef P, const int col0, float *smem
                 wf[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16 + q * 1024, (wave_u + 8 * (j0 + j)) * 4096, 0));
     };
     load_round(0);
+    // (the epilogue's bias and residual values: requested now, used after the reduction)
+    const int er = tid >> 5, ecol = col0 + (tid & 31);
+    const bool emit = tid < M * 32 && ecol < N;
+    const float ebias = emit ? gload1(P.bias + ecol) : 0.0f;
+    const float eres = emit && P.res ? act_ld(P.res + (size_t)er * P.ldr + ecol) : 0.0f;
     // the operand rows -> LDS (a virtual concatenation of up to MAX_SEG buffers; every column of such a problem is real)
     {
         const int e0 = P.kend[0], e1 = P.kend[1], e2 = P.kend[2];
@@ -2021,18 +2026,81 @@ __device__ __forceinline__ void gemv_tile(ProbRef P, const int col0, float *smem
         if (lh == 0) red[(wave * GEMV_MAX_M + r) * 32 + li] = acc[r];
     }
     __syncthreads();
-    if (tid < M * 32) {
-        const int r = tid >> 5, c = tid & 31, col = col0 + c;
+    if (emit) {
         float v = 0.0f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) v += red[(w * GEMV_MAX_M + r) * 32 + c];
-        if (col < N) {
-            v = lrelu(v + gload1(P.bias + col), P.slope);
-            if (P.res) v += act_ld(P.res + (size_t)r * P.ldr + col);
-            __hip_atomic_store((gu32)(P.c + (size_t)r * P.ldc + col), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        for (int w = 0; w < 8; ++w) v += red[(w * GEMV_MAX_M + er) * 32 + (tid & 31)];
+        v = lrelu(v + ebias, P.slope) + eres;
+        __hip_atomic_store((gu32)(P.c + (size_t)er * P.ldc + ecol), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();                                                // the next tile may write LDS
+}
+
+// lat_tile: the same shape - one 32-column block of a layer, K split tile-wise over the eight wavefronts, every operand of a
+// wavefront's share requested up front (weights: fragment order; activations: straight from memory into MFMA operand
+// registers, no LDS ring, no per-K-tile barrier), partial sums added through LDS - for layers of 5 .. 32 rows, on the
+// fp32 matrix cores.  A 1024-deep layer is four K tiles per wavefront: one memory round trip and 64 MFMAs where the
+// split-K gemm_tile runs eight barrier-separated iterations (12.5 us per M = B stage of a 16-window call against ~7).
+__device__ __forceinline__ void lat_tile(ProbRef P, const int col0, float *smem) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int M = P.M, K = P.K, N = P.N, nk32 = K / BK;
+    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.w + (size_t)(col0 >> 5) * nk32 * 1024), 0, nk32 * 4096, 0x00020000);
+    const int e0 = P.kend[0], e1 = P.kend[1], e2 = P.kend[2];
+    const int arow = li < M ? li : M - 1;                       // (rows past the problem re-read its last row: never stored)
+    f32x4 wf[4][4], af[4][4];
+    auto load_round = [&](int j0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kt = wave_u + 8 * (j0 + j), k = kt * BK;
+            // the K tile's segment of the (virtual) concatenation: uniform
+            const int sg = k < e0 ? 0 : k < e1 ? 1 : k < e2 ? 2 : 3;
+            const int k0 = sg == 0 ? 0 : sg == 1 ? e0 : sg == 2 ? e1 : e2;
+            const float *base = sg == 0 ? P.a[0] : sg == 1 ? P.a[1] : sg == 2 ? P.a[2] : P.a[3];
+            const int ld = sg == 0 ? P.lda[0] : sg == 1 ? P.lda[1] : sg == 2 ? P.lda[2] : P.lda[3];
+            const __amdgpu_buffer_rsrc_t ars = act_rsrc(base);
+            const bool live = kt < nk32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                wf[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16 + q * 1024, kt * 4096, 0));
+                af[j][q] = live ? act_load4(ars, (arow * ld + (k - k0) + lh * 16 + q * 4) * 4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int j0 = 0; wave_u + 8 * j0 < nk32; j0 += 4) {
+        load_round(j0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][q][kk], wf[j][q][kk], acc, 0, 0, 0);   // (K tiles past the end: zero weights)
+    }
+    float *red = smem;                                             // [wave][register][lane]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int idx = tid + h * GEMM_THREADS, r = idx >> 6, ln = idx & 63;
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += red[(w * 16 + r) * 64 + ln];
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), col = col0 + (ln & 31);
+        if (row < M && col < N) {
+            v = lrelu(v + gload1(P.bias + col), P.slope);
+            if (P.res) v += act_ld(P.res + (size_t)row * P.ldr + col);
+            __hip_atomic_store((gu32)(P.c + (size_t)row * P.ldc + col), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------ tile-level dependencies
@@ -2205,6 +2273,10 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
             }
             if (ks == 8) {               // a problem of a few rows: one 32-column block, K split over the wavefronts, no MFMA
                 gemv_tile(P, col0, smem);
+                break;
+            }
+            if (ks == 16) {              // ... of up to 32 rows: the same shape on the matrix cores
+                lat_tile(P, col0, smem);
                 break;
             }
             if (ks > 1) {

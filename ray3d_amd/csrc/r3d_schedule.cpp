@@ -202,6 +202,8 @@ double unit_cycles(int iters, int ks) {
 // a GEMV tile (r3d_kernels.hip): one memory round trip for the weights of its 32 columns, the operand copy, two barriers,
 // the reduction and the store - ~4 us plus the stream (K tiles / 8 per wavefront)
 double gemv_cycles(int nk) { return 8000.0 + nk / 8.0 * 900.0; }
+// a latency tile: the same plus 16 MFMAs per K tile of a wavefront's share (two wavefronts per SIMD)
+double lat_cycles(int nk) { return 9000.0 + nk / 8.0 * 2600.0; }
 
 struct Run {           // `n` consecutive row units of one column block, all in one workgroup's chunk
     int prob, col0, ks, u0, n, cap;
@@ -212,6 +214,7 @@ struct Seg {           // one column block of a problem
     double c1;
     int ncols;         // columns of the problem inside this block (<= 256)
     bool gemv = false; // 32-column GEMV tiles instead of row units
+    int code = 8;      // ... their tile code: 8 GEMV, 16 latency tile
 };
 
 struct Assignment {
@@ -241,14 +244,14 @@ bool assign(const std::vector<Seg> &segs, int nbins, double T, int ksplit, Assig
     for (const Seg &s : segs) {          // sorted by c1, descending
         if (s.gemv) {
             // one tile per 32 columns, each to the workgroup with the most room (they are many and short)
-            const double ck = gemv_cycles(s.nk);
+            const double ck = s.code == 8 ? gemv_cycles(s.nk) : lat_cycles(s.nk);
             for (int j = 0; j * 32 < s.ncols; ++j) {
                 int best = 0;
                 for (int b = 1; b < nbins; ++b)
                     if (room[b] > room[best]) best = b;
                 if (room[best] + 1e-6 < ck) return false;
                 room[best] -= ck;
-                if (out) out->bins[best].push_back({s.prob, s.col0 + j * 32, 8, 0, 1, 1});
+                if (out) out->bins[best].push_back({s.prob, s.col0 + j * 32, s.code, 0, 1, 1});
             }
             continue;
         }
@@ -342,18 +345,19 @@ void pack(const std::vector<SchedProb> &probs, int nbins_max, int max_units, Pac
         for (int c0 = 0; c0 < p.N; c0 += 256) {
             Seg sg{i, c0, units, p.nk, p.max_units > 0 ? std::min(p.max_units, max_units) : max_units, p.max_ks, c1,
                    std::min(256, p.N - c0)};
-            sg.gemv = p.gemv && units == 1 && p.row0 == 0;
+            sg.gemv = (p.gemv || p.lat) && units == 1 && p.row0 == 0;
+            sg.code = p.gemv ? 8 : 16;
             segs.push_back(sg);
             if (sg.gemv) {
                 const int pieces = (sg.ncols + 31) / 32;
-                total += pieces * gemv_cycles(p.nk);
+                total += pieces * (p.gemv ? gemv_cycles(p.nk) : lat_cycles(p.nk));
                 total_units += pieces;
                 continue;
             }
             total += units * c1;
             total_units += units;
         }
-        if (p.gemv && units == 1 && p.row0 == 0) biggest_fixed = std::max(biggest_fixed, gemv_cycles(p.nk));
+        if ((p.gemv || p.lat) && units == 1 && p.row0 == 0) biggest_fixed = std::max(biggest_fixed, p.gemv ? gemv_cycles(p.nk) : lat_cycles(p.nk));
         else if (p.max_ks < 2) biggest_fixed = std::max(biggest_fixed, c1);
     }
     std::stable_sort(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) { return a.c1 > b.c1; });
@@ -365,7 +369,7 @@ void pack(const std::vector<SchedProb> &probs, int nbins_max, int max_units, Pac
     for (int ksplit = 2; ksplit <= 4; ksplit *= 2) {
         if (ksplit > 2 && widest_split < ksplit) break;      // (nothing in this launch can be cut that finely: same packing)
         double lo = std::max(total / nbins, biggest_fixed), top = std::max(total, lo) + 1.0;
-        for (const Seg &s : segs) top = std::max(top, (s.gemv ? gemv_cycles(s.nk) * 8 : s.c1 * s.units) + 1.0);
+        for (const Seg &s : segs) top = std::max(top, (s.gemv ? lat_cycles(s.nk) * 8 : s.c1 * s.units) + 1.0);
         // gallop up from the ideal budget (a feasible one is rarely more than a unit above it), then bisect
         double hi = lo;
         if (!assign(segs, nbins, lo, ksplit, nullptr)) {
@@ -457,8 +461,10 @@ static SchedProb sched_prob_of(const Plan *pl, const ProbSpec &q, int64_t B) {
         SchedProb sp{M, L.N, L.Kpad / BK, max_ks, enc_cap};
         if (q.nseg == 1 && q.seg[0].width < L.Kpad) sp.max_ks = 1;   // an operand narrower than its padded K: one bounded descriptor
         // a plain layer of a few rows (calls of up to eight windows: the MLPs, the top of the pyramid): GEMV tiles
-        sp.gemv = M <= GEMV_ROWS && q.enc_lut < 0 && q.layer2 < 0 && !(q.nseg == 1 && q.seg[0].width < L.Kpad) && L.Kpad >= 64 &&
-                  !env_on("R3D_NO_GEMV");
+        const bool narrow_ok = q.enc_lut < 0 && q.layer2 < 0 && !(q.nseg == 1 && q.seg[0].width < L.Kpad) && L.Kpad >= 64;
+        sp.gemv = M <= GEMV_ROWS && narrow_ok && !env_on("R3D_NO_GEMV");
+        // ... and of up to 32 rows (one unit): latency tiles on the matrix cores (not beside the bf16x3 tiles: B >= 96 there)
+        sp.lat = !sp.gemv && M <= 32 && narrow_ok && !env_on("R3D_NO_LAT");
         const bool b3 = B >= b3_min_batch();               // (r3d_api.cpp passes the bf16x3 operands under the same condition)
         if (b3 && L.bf3 && q.layer2 < 0 && q.enc_lut < 0) {   // bf16-matrix-core tiles: whole tiles of <= 128 rows, ~1.5x the iteration rate
             sp.max_ks = 1;

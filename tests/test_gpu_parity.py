@@ -111,6 +111,29 @@ def test_calls_of_one_to_four_windows_run_the_gemv_tiles(over, monkeypatch):
         assert not np.array_equal(outs[0], outs[1])                  # (two different evaluations)
 
 
+@pytest.mark.parametrize("over", [dict(ARCHITECTURE="3,3,3,3,3"), dict(ARCHITECTURE="3,3", NUM_KPTS=15, STAGE=2)])
+def test_calls_of_five_to_32_windows_run_the_latency_tiles(over, monkeypatch):
+    """Layers of 5 .. 32 rows (the MLPs and the pyramid's top in calls of up to 32 windows) run as 32-column latency tiles on
+    the matrix cores (lat_tile: K split over the wavefronts, all operands requested up front) - against the oracle and
+    against the split-K gemm tiles the call would use otherwise (R3D_NO_LAT=1)."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    from oracle import oracle
+    mc = ray3d_amd.default_model_config(**over)
+    for B in (5, 11, 32):
+        outs = []
+        for no_lat in ("0", "1"):
+            monkeypatch.setenv("R3D_NO_LAT", no_lat)
+            pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+            x, p = synth.synth_rays(B, cp, seed=93), synth.synth_param(B, seed=94)
+            with torch.no_grad():
+                outs.append(ray3d_amd.Ray3DLifter(pos, trj).eval()(torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()).cpu().numpy())
+        ref = oracle.forward(cp, sp, x, p) + oracle.forward(ct, st, x, p)
+        check_parity(outs[0], ref, "%d windows, latency tiles" % B)
+        check_parity(outs[1], ref, "%d windows, split-K tiles" % B)
+        assert not np.array_equal(outs[0], outs[1])
+
+
 def test_forward_clip_equals_materialised_windows():
     """In-kernel sliding windows (window_stride = 1) == eval_data_prepare's copies (trainer.py:47-58)."""
     import ray3d_amd
