@@ -1962,10 +1962,14 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
 // LeakyReLU / residual, one 128-byte row segment per row.  32 tiles per 1024-column layer: the five FuseBlocks' layers
 // of a one-window call occupy 160 CUs instead of 80, each for a third of the time.
 constexpr int GEMV_MAX_M = 4;
+__device__ __forceinline__ void wait_deps(const int4 *tile, const int ndep, const gu32 cnt, const gu32 abort_flag);
+// (single-launch form: these tiles wait for their producers themselves - BEHIND their weight requests, which depend on no
+//  producer: in a call of a few windows a layer is one memory round trip, and the wait for the previous layer hides it)
+struct TileDeps { const int4 *tile; int ndep; gu32 cnt, abort_flag; };
 __device__ __forceinline__ float act_ld(const float *p) {
     return __builtin_bit_cast(float, __hip_atomic_load((gu32)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // 4-byte sc1 load
 }
-__device__ __forceinline__ void gemv_tile(ProbRef P, const int col0, float *smem) {
+__device__ __forceinline__ void gemv_tile(ProbRef P, const int col0, float *smem, const TileDeps &dep) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -1984,10 +1988,10 @@ __device__ __forceinline__ void gemv_tile(ProbRef P, const int col0, float *smem
                 wf[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16 + q * 1024, (wave_u + 8 * (j0 + j)) * 4096, 0));
     };
     load_round(0);
-    // (the epilogue's bias and residual values: requested now, used after the reduction)
     const int er = tid >> 5, ecol = col0 + (tid & 31);
     const bool emit = tid < M * 32 && ecol < N;
-    const float ebias = emit ? gload1(P.bias + ecol) : 0.0f;
+    const float ebias = emit ? gload1(P.bias + ecol) : 0.0f;       // (the epilogue's bias: requested now, used after the reduction)
+    if (dep.ndep > 0) wait_deps(dep.tile, dep.ndep, dep.cnt, dep.abort_flag);
     const float eres = emit && P.res ? act_ld(P.res + (size_t)er * P.ldr + ecol) : 0.0f;
     // the operand rows -> LDS (a virtual concatenation of up to MAX_SEG buffers; every column of such a problem is real)
     {
@@ -2041,7 +2045,7 @@ __device__ __forceinline__ void gemv_tile(ProbRef P, const int col0, float *smem
 // registers, no LDS ring, no per-K-tile barrier), partial sums added through LDS - for layers of 5 .. 32 rows, on the
 // fp32 matrix cores.  A 1024-deep layer is four K tiles per wavefront: one memory round trip and 64 MFMAs where the
 // split-K gemm_tile runs eight barrier-separated iterations (12.5 us per M = B stage of a 16-window call against ~7).
-__device__ __forceinline__ void lat_tile(ProbRef P, const int col0, float *smem) {
+__device__ __forceinline__ void lat_tile(ProbRef P, const int col0, float *smem, const TileDeps &dep) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -2052,7 +2056,14 @@ __device__ __forceinline__ void lat_tile(ProbRef P, const int col0, float *smem)
     const int e0 = P.kend[0], e1 = P.kend[1], e2 = P.kend[2];
     const int arow = li < M ? li : M - 1;                       // (rows past the problem re-read its last row: never stored)
     f32x4 wf[4][4], af[4][4];
-    auto load_round = [&](int j0) {
+    auto load_w_round = [&](int j0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                wf[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16 + q * 1024, (wave_u + 8 * (j0 + j)) * 4096, 0));
+    };
+    auto load_a_round = [&](int j0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int kt = wave_u + 8 * (j0 + j), k = kt * BK;
@@ -2064,17 +2075,18 @@ __device__ __forceinline__ void lat_tile(ProbRef P, const int col0, float *smem)
             const __amdgpu_buffer_rsrc_t ars = act_rsrc(base);
             const bool live = kt < nk32;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                wf[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16 + q * 1024, kt * 4096, 0));
+            for (int q = 0; q < 4; ++q)
                 af[j][q] = live ? act_load4(ars, (arow * ld + (k - k0) + lh * 16 + q * 4) * 4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            }
         }
     };
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    load_w_round(0);
+    if (dep.ndep > 0) wait_deps(dep.tile, dep.ndep, dep.cnt, dep.abort_flag);
     for (int j0 = 0; wave_u + 8 * j0 < nk32; j0 += 4) {
-        load_round(j0);
+        if (j0) load_w_round(j0);
+        load_a_round(j0);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -2187,6 +2199,7 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
         const int col0 = __builtin_amdgcn_readfirstlane(td.z);
         const int ks = __builtin_amdgcn_readfirstlane(td.w);      // split-K factor of this tile (1, 2 or 4)
         int sig_base = 0, sig_add = 0;
+        TileDeps tdep{nullptr, 0, nullptr, nullptr};
         if constexpr (DEP) {
             const int4 te = tiles[t * TS + 1];
             const int ndep = __builtin_amdgcn_readfirstlane(te.x);
@@ -2195,10 +2208,12 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
 #ifdef R3D_TIMING
             if (dbg_arg && threadIdx.x == 0) dbg_arg[16384 + (long long)t * 4 + 0] = wall_clock64();      // tile fetched
 #endif
-            if (ndep > 0) wait_deps(tiles + t * TS, ndep, cnt, abort_flag);
+            // (GEMV / latency tiles wait themselves, behind their weight requests)
+            if (ndep > 0 && ks < 8) wait_deps(tiles + t * TS, ndep, cnt, abort_flag);
 #ifdef R3D_TIMING
             if (dbg_arg && threadIdx.x == 0) dbg_arg[16384 + (long long)t * 4 + 1] = wall_clock64();      // producers ready
 #endif
+            tdep = TileDeps{tiles + t * TS, ks >= 8 ? ndep : 0, cnt, abort_flag};
         }
         ProbRef P = DEP ? *((const GemmProb __attribute__((address_space(4))) *)fargs->probs + pi) : args->p[pi];
 #ifdef R3D_TIMING
@@ -2272,11 +2287,11 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                 break;
             }
             if (ks == 8) {               // a problem of a few rows: one 32-column block, K split over the wavefronts, no MFMA
-                gemv_tile(P, col0, smem);
+                gemv_tile(P, col0, smem, tdep);
                 break;
             }
             if (ks == 16) {              // ... of up to 32 rows: the same shape on the matrix cores
-                lat_tile(P, col0, smem);
+                lat_tile(P, col0, smem, tdep);
                 break;
             }
             if (ks > 1) {
