@@ -1,6 +1,7 @@
 // extern "C" entry points of libray3d_hip.so (contract: include/ray3d_hip.h).
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 
 #include "r3d_internal.hpp"
 
@@ -183,6 +184,46 @@ int fill_prob(const Plan *pl, const ProbSpec &q, int64_t B, const Model *a, cons
     return R3D_OK;
 }
 
+// Two single-launch forwards must never be on the GPU at the same time: each needs ALL its workgroups resident (a waiting
+// workgroup spins for tiles of workgroups that may not have been dispatched yet), and two such kernels from two streams
+// could each hold part of the chip and wait for the rest forever (until the bounded spins give up).  Within a process the
+// library therefore orders them: per device it remembers the stream and an event of the last single-launch forward, and a
+// forward on ANOTHER stream first records an event behind the work of the previous forward's stream and waits for it (a
+// device-side dependency, no host synchronisation).  The common case - one stream - costs a mutex and a compare.  Streams being captured are left alone (a capture
+// must not wait on events from outside it): capture one forward stream per graph, replay graphs one at a time.
+struct FwdOrder {
+    std::mutex mu;
+    hipEvent_t ev[64] = {nullptr};
+    hipStream_t last[64] = {nullptr};
+    bool have[64] = {false};
+};
+static FwdOrder g_fwd_order;
+
+static hipError_t order_single_launch(hipStream_t stream, bool before) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipSuccess;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }
+    if (cs != hipStreamCaptureStatusNone) return hipSuccess;
+    std::lock_guard<std::mutex> lock(g_fwd_order.mu);
+    if (!before) {                                   // (after the launch: just remember whose it was - no event on the one-stream path)
+        g_fwd_order.last[dev] = stream;
+        g_fwd_order.have[dev] = true;
+        return hipSuccess;
+    }
+    if (!g_fwd_order.have[dev] || g_fwd_order.last[dev] == stream) return hipSuccess;
+    // another stream ran the previous one: an event behind everything that stream has been given so far, and wait for it
+    if (!g_fwd_order.ev[dev]) {
+        hipError_t e = hipEventCreateWithFlags(&g_fwd_order.ev[dev], hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    hipStreamCaptureStatus ocs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(g_fwd_order.last[dev], &ocs) != hipSuccess || ocs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return hipSuccess; }
+    hipError_t e = hipEventRecord(g_fwd_order.ev[dev], g_fwd_order.last[dev]);
+    if (e != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }      // (the other stream is gone: nothing of it can still run)
+    return hipStreamWaitEvent(stream, g_fwd_order.ev[dev], 0);
+}
+
 static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *out, float *out_trj, void *ws,
                size_t ws_bytes, void *stream_v) {
     Model *a = pos ? pos : trj, *b = pos ? trj : nullptr;
@@ -275,6 +316,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         ba.enc_bytes = (unsigned)((size_t)frames * JF * sizeof(float));
         ba.param_stride = (int)in->param_stride;
         if ((e = rec.begin("r3d_bind_f32", stage_no, 1, 0.0, 0.0)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        if ((e = order_single_launch(stream, true)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
         if ((e = launch_bind(ba, stream)) != hipSuccess) return hip_fail(e, "launch r3d_bind_f32");
         if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
         ++stage_no;
@@ -298,6 +340,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         }
 #endif
         if ((e = launch_forward(fa, fw.grid, uv_launch, stream)) != hipSuccess) return hip_fail(e, "launch r3d_forward_f32");
+        if ((e = order_single_launch(stream, false)) != hipSuccess) return hip_fail(e, "hipEventRecord");
 #ifdef R3D_TIMING
         if (fa.dbg) {
             (void)hipStreamSynchronize(stream);

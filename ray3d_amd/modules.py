@@ -285,8 +285,9 @@ class Ray3DLifter(nn.Module):
         """forward() with the batch cut into `parts` row ranges that run concurrently on separate HIP
         streams (windows are independent).  One forward is 14 dependent launches, several of them too
         small for 256 CUs; a second, independent launch sequence fills the gaps - worth +7 % at B = 256 before the
-        small launches were re-scheduled, 3 % slower than forward() since: kept for callers whose batches
-        are too small to fill the chip.  The result is ordered after the caller's stream on entry and visible to it on exit.
+        small launches were re-scheduled, 3 % slower than forward() since.  With the single-launch forward
+        (round 3) the library orders the parts' persistent kernels one after the other (two of them must never share the
+        chip), so the parts only overlap their bind / decode kernels: kept for API compatibility and for R3D_STAGED=1.  The result is ordered after the caller's stream on entry and visible to it on exit.
         Each range is scheduled for its own batch size, so sums may differ from forward() in the last
         bits (split-K tiles), never by more than the schedule-invariance tests allow."""
         self.pos._check_inputs(x, param)
