@@ -201,6 +201,8 @@ static FwdOrder g_fwd_order;
 
 static hipError_t order_single_launch(hipStream_t stream, bool before) {
     int dev = 0;
+    static const bool off = env_on("R3D_NO_STREAM_ORDER");       // (development: what happens without it - DESIGN.md 4.0)
+    if (off) return hipSuccess;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipSuccess;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }
