@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 
 #include "r3d_internal.hpp"
 
@@ -244,11 +245,13 @@ bool assign(const std::vector<Seg> &segs, int nbins, double T, int ksplit, Assig
     for (const Seg &s : segs) {          // sorted by c1, descending
         if (s.gemv) {
             // one tile per 32 columns, each to the workgroup with the most room (they are many and short)
+            // (equal pieces: to the workgroups in the order of their room, round after round)
             const double ck = s.code == 8 ? gemv_cycles(s.nk) : lat_cycles(s.nk);
+            std::vector<int> by_room(nbins);
+            for (int b = 0; b < nbins; ++b) by_room[b] = b;
+            std::stable_sort(by_room.begin(), by_room.end(), [&](int x, int y) { return room[x] > room[y]; });
             for (int j = 0; j * 32 < s.ncols; ++j) {
-                int best = 0;
-                for (int b = 1; b < nbins; ++b)
-                    if (room[b] > room[best]) best = b;
+                const int best = by_room[j % nbins];
                 if (room[best] + 1e-6 < ck) return false;
                 room[best] -= ck;
                 if (out) out->bins[best].push_back({s.prob, s.col0 + j * 32, s.code, 0, 1, 1});
@@ -265,15 +268,20 @@ bool assign(const std::vector<Seg> &segs, int nbins, double T, int ksplit, Assig
             // least certain, and first-fit stacked a dozen of them on ONE full workgroup that then ended 20 us after the
             // rest of the launch while others idled (fp32 first-level launch: 249 against 228 us; bf16x3 second launch:
             // 57 against 48 us)
+            // (a heap of the workgroups by room: the roomiest first, lower index first at equal room - as a linear scan would pick)
+            auto less_room = [&](int x, int y) { return room[x] != room[y] ? room[x] < room[y] : x > y; };
+            std::vector<int> heap(nbins);
+            for (int b = 0; b < nbins; ++b) heap[b] = b;
+            std::make_heap(heap.begin(), heap.end(), less_room);
             while (u < s.units) {
-                int best = 0;
-                for (int b = 1; b < nbins; ++b)
-                    if (room[b] > room[best]) best = b;
+                std::pop_heap(heap.begin(), heap.end(), less_room);
+                const int best = heap.back();
                 if (room[best] + 1e-6 < s.c1) break;
                 const int take = std::min(std::min(2, (int)std::floor((room[best] + 1e-6) / s.c1)), s.units - u);
                 room[best] -= take * s.c1;
                 if (out) out->bins[best].push_back({s.prob, s.col0, 1, u, take, s.cap});
                 u += take;
+                std::push_heap(heap.begin(), heap.end(), less_room);
             }
         } else if (s.c1 <= T) {
             while (u < s.units) {
@@ -507,6 +515,13 @@ static SchedProb sched_prob_of(const Plan *pl, const ProbSpec &q, int64_t B) {
 
 // `spill_row0`: rows [spill_row0, M) of Plan::spill_prob belong to the launch that lists it with STAGE_SPILL_IN, the
 // rows before to its own launch (-1: all rows stay).
+struct StageMemo {
+    std::vector<int4> tiles;
+    std::vector<int> wgoff;
+    StageSchedule ss;
+};
+static thread_local std::map<std::vector<int>, StageMemo> g_stage_memo;     // per schedule_build_host call
+
 static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, int nwg, int spill_row0, std::vector<int4> &tiles,
                         std::vector<int> &wgoff, StageSchedule &out) {
     std::vector<SchedProb> probs;
@@ -532,8 +547,24 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
     }
     bool enc = false;
     for (int e : st) enc = enc || pl->probs[e & ~STAGE_SPILL_IN].enc_kernel;
-    // the fused-prologue kernel runs two workgroups per CU (one encodes while the other multiplies)
-    schedule_stage(probs, enc ? 2 * nwg : nwg, GEMM_SCHED_MAX_UNITS, tiles, wgoff, out, enc);
+    // The level assignments and spill candidates schedule_build_host compares differ in two or three launches only: a
+    // launch's packing is a function of its problems' shapes, so it is computed once per distinct launch of a build.
+    std::vector<int> key{enc ? 1 : 0, nwg};
+    for (const SchedProb &sp : probs)
+        key.insert(key.end(), {sp.M, sp.N, sp.nk, sp.max_ks, sp.max_units, sp.nk2, sp.row0, sp.gemv ? 1 : sp.lat ? 2 : 0});
+    auto hit = g_stage_memo.find(key);
+    if (hit == g_stage_memo.end()) {
+        StageMemo m;
+        // the fused-prologue kernel runs two workgroups per CU (one encodes while the other multiplies)
+        schedule_stage(probs, enc ? 2 * nwg : nwg, GEMM_SCHED_MAX_UNITS, m.tiles, m.wgoff, m.ss, enc);
+        hit = g_stage_memo.emplace(key, std::move(m)).first;
+    }
+    const StageMemo &m = hit->second;
+    out = m.ss;
+    out.tiles_off = tiles.size();
+    out.wgoff_off = wgoff.size();
+    tiles.insert(tiles.end(), m.tiles.begin(), m.tiles.end());
+    wgoff.insert(wgoff.end(), m.wgoff.begin(), m.wgoff.end());
     out.flops = flops;
     out.bytes = bytes;
 }
@@ -543,6 +574,7 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
 const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t B, int nwg, int &spill_row0, std::vector<int4> &tiles,
                                                         std::vector<int> &wgoff, std::vector<StageSchedule> &stages) {
     spill_row0 = -1;
+    g_stage_memo.clear();
     const std::vector<std::vector<int>> *levels = &pl->stages;
     const bool dump = getenv("R3D_PLAN_DUMP") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
