@@ -218,18 +218,25 @@ def roofline(lifter, x, p, step_ms, reps=5, fn=None, batch=None):
                 (None if custom else tj.get("batches", {}).get(str(batch), {}).get(name))
         except Exception:
             traffic = None
-    return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
-            "peak_of": "fp32 MFMA (v_mfma_f32_32x32x2_f32)" if prec == "f32" else "bf16 MFMA / 6 products (bf16x3)",
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-            "launches_per_step": d["launches"] // reps,
-            "avg_launch_us": round(ms / d["launches"] * 1e3, 2),
-            "avg_launch_us_bracketed": round(d["ms"] / d["launches"] * 1e3, 2),
-            "event_pair_us": round(pair * 1e3, 2), "scale_to_step": round(scale, 4),
-            "step_us": round(step_ms * 1e3, 1),
-            "kernels_us_per_step": {k: round(v["ms"] * scale / reps * 1e3, 1) for k, v in agg.items()},
-            "flops_per_launch": d["flops"] / d["launches"],
-            "hbm_view": {"algorithmic_GBps": round(d["bytes"] / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
-                         "frac": round(d["bytes"] / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}}
+    out = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
+           "peak_of": "fp32 MFMA (v_mfma_f32_32x32x2_f32)" if prec == "f32" else "bf16 MFMA / 6 products (bf16x3)",
+           "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+           "launches_per_step": d["launches"] // reps,
+           "avg_launch_us": round(ms / d["launches"] * 1e3, 2),
+           "avg_launch_us_bracketed": round(d["ms"] / d["launches"] * 1e3, 2),
+           "event_pair_us": round(pair * 1e3, 2), "scale_to_step": round(scale, 4),
+           "step_us": round(step_ms * 1e3, 1),
+           "kernels_us_per_step": {k: round(v["ms"] * scale / reps * 1e3, 1) for k, v in agg.items()},
+           "flops_per_launch": d["flops"] / d["launches"],
+           "hbm_view": {"algorithmic_GBps": round(d["bytes"] / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+                        "frac": round(d["bytes"] / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}}
+    # which roof binds: the matrix time of the algorithmic FLOPs at peak against one stream of the algorithmic bytes at
+    # 8 TB/s - a call of a few windows streams 200 MB of weights for a handful of FLOPs and is HBM-bound
+    if d["bytes"] / (PEAK_HBM_GBS * 1e9) > d["flops"] / (peak * 1e12):
+        hv = out["hbm_view"]
+        out.update({"bound": "hbm", "achieved": hv["algorithmic_GBps"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hv["frac"],
+                    "peak_of": "HBM3E", "mfma_view": {"achieved_TFLOPs": round(achieved, 2), "frac": round(achieved / peak, 4)}})
+    return out
 
 
 def bf16x3_line(dev, states, x, p, out_f32, args, barrier, cfg):
