@@ -315,7 +315,7 @@ static Plan *build_plan(const Model *a, const Model *b, int kind) {
     std::vector<int> asap;
     for (const auto &q : pl->probs) asap.push_back(q.depth);
     // `pin_first`: the problem that reads the spilled one stays right behind it instead of moving as late as it can
-    auto levelise = [&](bool spill, bool pin_first, std::vector<std::vector<int>> &stages) -> bool {
+    auto levelise = [&](bool spill, bool pin_first, std::vector<std::vector<int>> &stages, bool early = false) -> bool {
         const int n = (int)pl->probs.size();
         for (int i = 0; i < n; ++i) pl->probs[i].depth = asap[i];
         int deepest = 0, pt = -1;
@@ -348,6 +348,9 @@ static Plan *build_plan(const Model *a, const Model *b, int kind) {
         for (int i = 0; i < n; ++i)
             for (int d : pl->probs[i].deps) users[d].push_back(i);
         auto movable = [&](const ProbSpec &q) {
+            // (a call of a few windows is a latency chain, not a packing problem: everything as early as its inputs allow,
+            //  so that GlobalInfo's five layers are long done when the decoders ask for them)
+            if (early) return false;
             const std::string &key = pl->m[q.model]->layers[q.layer].weight_key;
             if (pin_first && pt >= 0 && std::find(q.deps.begin(), q.deps.end(), pt) != q.deps.end()) return false;
             if (spill && pl->m[q.model]->cfg.kind == R3D_KIND_TRJ && key.rfind("LocalLayer.", 0) == 0 && q.layer3 < 0) return true;
@@ -404,6 +407,11 @@ static Plan *build_plan(const Model *a, const Model *b, int kind) {
     if (!(can_spill && levelise(true, false, pl->stages_spill))) pl->stages_spill.clear();
     if (!(can_spill && levelise(true, true, pl->stages_spill_alt)) || pl->stages_spill_alt == pl->stages_spill) pl->stages_spill_alt.clear();
     levelise(false, false, pl->stages);
+    // (the un-fused plan also as early as possible: what calls of up to four windows run - schedule_build_host)
+    if (kind == PLAN_SMALL) {
+        levelise(false, false, pl->stages_asap, true);
+        if (pl->stages_asap == pl->stages) pl->stages_asap.clear();
+    }
     // workspace offsets
     int64_t off = 0;
     for (auto &bf : pl->buffers) {

@@ -589,6 +589,10 @@ const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t
         }
         return sum;
     };
+    if (!pl->stages_asap.empty() && B <= GEMV_ROWS) {
+        build_all(pl->stages_asap, -1, tiles, wgoff, stages);
+        return &pl->stages_asap;
+    }
     const double c_plain = build_all(pl->stages, -1, tiles, wgoff, stages);
     double c_best = c_plain;
     std::vector<int> searched0, searched1;      // the two launches the last row search ran on, and what it found

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-launch times of one forward (library's own HIP events), median of a few runs.  usage: stage_times.py [B] [reps]"""
+"""Per-launch times of one forward (library's own HIP events), median of a few runs.
+usage: [ARCH=3,3 J=14] stage_times.py [B] [reps]"""
 import sys, os
 import numpy as np
 import torch
@@ -12,7 +13,7 @@ from ray3d_amd.spec import config_from_dicts
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 15
-mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3,3,3")
+mc = ray3d_amd.default_model_config(ARCHITECTURE=os.environ.get("ARCH", "3,3,3,3,3"), NUM_KPTS=int(os.environ.get("J", "17")))
 fac = ray3d_amd.Model(mc, {}, is_train=False)
 pos, trj = fac.get_pos_model(), fac.get_trj_model()
 for m, kind, seed in ((pos, "pos", 1), (trj, "trj", 2)):
