@@ -477,7 +477,7 @@ static SchedProb sched_prob_of(const Plan *pl, const ProbSpec &q, int64_t B) {
         if (b3 && L.bf3 && q.layer2 < 0 && q.enc_lut < 0) {   // bf16-matrix-core tiles: whole tiles of <= 128 rows, ~1.5x the iteration rate
             sp.max_ks = 1;
             sp.max_units = 4;
-            sp.nk = (sp.nk * 2 + 2) / 3;
+            sp.nk = (sp.nk * 3 + 2) / 4;            // (31 against 39 us for a single-unit M = B tile by the per-tile stamps)
         }
         if (q.enc_lut >= 0 && q.layer3 < 0) {
             // a gathered operand without the fused level (GlobalInfo's current frames in the first-level launch): table load,
@@ -495,19 +495,20 @@ static SchedProb sched_prob_of(const Plan *pl, const ProbSpec &q, int64_t B) {
             // 45.5 us for a body-part tile, 67.5 us for the trajectory model's at 2.1 GHz)
             sp.nk2 = 2 * sp.nk + mm->layers[q.layer2].Kpad / BK + mm->layers[q.layer3].Kpad / BK + (L.Kpad <= 64 ? 5 : 12);
             if (b3 && L.bf3_conv) {
-                // on the bf16 matrix cores: 0.7x for every first-level unit.  (Separate factors from the phase stamps - a
-                // body-part unit 27.5 us against 41.5 in fp32, the trajectory model's 57 against 66 - schedule WORSE:
-                // 0.560 against 0.533 ms at 256 windows, 1.70 against 1.60 at 1024; the model's errors compensate.)
-                sp.nk2 = (sp.nk2 + sp.nk) * 7 / 10 - sp.nk;
+                // on the bf16 matrix cores, by the per-tile stamps of the single-launch forward (tools/fwd_gantt.py): a
+                // body-part tile 57.7 us against 89.3 in fp32 (0.65x), the trajectory model's 60 against 73 (0.82x).  (Round 2,
+                // launch by launch, did better with one 0.7x for both; with tile-level dependencies the measured factors win:
+                // 0.465 against 0.471 ms at 256 windows, 1.387 against 1.406 at 1024.)
+                sp.nk2 = (sp.nk2 + sp.nk) * (L.Kpad <= 64 ? 65 : 82) / 100 - sp.nk;
             }
         } else if (q.layer2 >= 0) {                // fused pair: whole tiles of <= 128 rows, no split
             sp.max_ks = 1;
             sp.max_units = 4;
             sp.nk2 = pl->m[q.model]->layers[q.layer2].Kpad / BK;
             if (b3 && L.bf3_conv && pl->m[q.model]->layers[q.layer2].bf3_conv && q.nseg == 1) {   // on the bf16 matrix cores: tiles of <= 96 rows,
-                sp.max_units = 3;                                                            // ~0.55x the time per unit (measured)
-                sp.nk = (sp.nk * 5 + 8) / 9;
-                sp.nk2 = (sp.nk2 * 5 + 8) / 9;
+                sp.max_units = 3;                                                            // 0.65x (two units) .. 0.8x (one) the time per unit
+                sp.nk = (sp.nk * 7 + 5) / 10;
+                sp.nk2 = (sp.nk2 * 7 + 5) / 10;
             }
         }
         return sp;
