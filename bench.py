@@ -448,7 +448,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):
+        # (under a launcher the collectives run even with one rank: the same code path as N > 1, over RCCL)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)

@@ -983,6 +983,36 @@ def test_bench_eval_mode_single_gpu():
     assert np.isfinite(line["mpjpe_mm"]["action_average"]) and line["config"]["clips"] == 10
 
 
+@pytest.mark.parametrize("mode", ["windows", "eval"])
+def test_bench_under_the_drivers_launcher_with_one_rank(mode):
+    """The driver starts N > 1 as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.  One GPU is what a
+    test box has: the same launch form with N = 1 initialises RCCL and runs every collective of the N > 1 path (barrier, MAX
+    all_reduce, the per-rank all_gathers, in eval mode the all_gather of the per-clip rows) with one rank."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    extra = ["--no-cpu-baseline", "--no-bf16x3", "--no-shipped-cfgs", "--no-b1024"] if mode == "windows" else ["--mode", "eval", "--clips", "6"]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"] + extra,
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["world_size_observed"] == 1
+    if mode == "windows":
+        assert line["parity_max_abs_err"] <= 1e-4 and len(line["config"]["ms_per_step_per_rank"]) == 1
+    else:
+        assert line["config"]["shard_imbalance"] == 1.0 and len(line["config"]["pass_ms_per_rank"]) == 1
+
+
 def test_clip_sharded_eval_over_rccl_two_gpus():
     """Two ranks over RCCL (started by bench.py itself through torch.distributed.run): whole clips sharded longest
     first, ONE all_gather of the per-clip rows; the gathered errors must equal the single-rank run's.  Skipped on a
