@@ -280,7 +280,6 @@ struct Schedule {
     // single-launch form (empty / null when the plan has launches it cannot hold: r3d_gemm_enc_f32 stages)
     struct Fwd {
         int grid = 0, ntiles = 0, ncnt = 0, nprob = 0;
-        std::vector<int> prob_of_slot;        // table index -> Plan::probs index
         std::vector<int> cnt_base;            // per table index: first ready counter
         int4 *d_tiles = nullptr;              // FWD_TILE_INT4 int4 per tile
         int *d_wgoff = nullptr;

@@ -91,12 +91,10 @@ bool schedule_build_fwd(const Plan *pl, int64_t B, int nwg, const std::vector<st
         if (m && m->cfg.dense) return false;      // (the dense ablation's overlapping operand rows are not row-local per 32-row unit)
     fw.nprob = np;
     fw.cnt_base.assign(np, 0);
-    fw.prob_of_slot.resize(np);
     std::vector<int> gcols(np), M(np);
     int ncnt = 0;
     for (int i = 0; i < np; ++i) {
         const ProbSpec &q = pl->probs[i];
-        fw.prob_of_slot[i] = i;
         fw.cnt_base[i] = ncnt;
         ncnt += (int)units_of(B, q);
         gcols[i] = (pl->m[q.model]->layers[q.layer].N + COL_GRANULE - 1) / COL_GRANULE;
