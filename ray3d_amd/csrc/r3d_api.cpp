@@ -329,6 +329,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         fa.probs = table;
         fa.cnt = cnt;
         fa.ncnt = fw.ncnt;
+        if (const char *ft = getenv("R3D_FAULT_TILE")) fa.fault_tile1 = atoi(ft) + 1;   // test hook: see FwdArgs
         const bool uv_launch = uv && fw.uses_gather;
         if ((e = rec.begin(uv_launch ? "r3d_forward_uv_f32" : "r3d_forward_f32", stage_no, fw.grid, fw.flops, fw.bytes)) != hipSuccess)
             return hip_fail(e, "hipEventRecord");

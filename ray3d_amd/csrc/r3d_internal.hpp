@@ -98,7 +98,7 @@ struct FwdArgs {
     const GemmProb *probs;    // the call's problem table (absolute pointers; written by r3d_bind_f32 ahead of the launch)
     unsigned *cnt;            // ready counters, zeroed by r3d_bind_f32; cnt[ncnt] is the abort flag (a spin gave up)
     int ncnt;
-    int pad_;
+    int fault_tile1;          // test hook (R3D_FAULT_TILE=<n>): workgroup 0's n-th tile behind the first level never raises its counters (0: none; n + 1 stored)
     long long *dbg;
 };
 constexpr int BIND_NPTR = 18;  // pointer fields of a GemmProb, in the order r3d_bind_f32 walks them

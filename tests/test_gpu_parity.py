@@ -1094,6 +1094,36 @@ def test_forward_captured_in_a_hip_graph_after_prepare():
         ray3d_amd._capi.release(hp, ht, B)
 
 
+def test_a_tile_that_never_reports_ends_in_nan_not_in_a_hang(monkeypatch):
+    """The single-launch forward orders its tiles by ready counters; a counter that never fills must not hang the GPU.
+    R3D_FAULT_TILE makes one tile of workgroup 0 skip its counter update: its consumers spin, give up after ~1 s, raise the
+    launch's abort flag, every later wait returns at once and the decoder turns the outputs into NaN.  The next forward
+    (bind kernel: fresh counters) is correct again."""
+    import time
+    import ray3d_amd
+    from ray3d_amd import synth
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
+    pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    B = 200
+    x = torch.from_numpy(synth.synth_rays(B, cp, seed=97)).cuda()
+    p = torch.from_numpy(synth.synth_param(B, seed=98)).cuda()
+    with torch.no_grad():
+        good = lifter(x, p)
+        torch.cuda.synchronize()
+        monkeypatch.setenv("R3D_FAULT_TILE", "0")
+        t0 = time.perf_counter()
+        bad = lifter(x, p)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        monkeypatch.delenv("R3D_FAULT_TILE")
+        again = lifter(x, p)
+        torch.cuda.synchronize()
+    assert torch.isnan(bad).all(), "a forward with a missing counter update must be poisoned"
+    assert 0.5 < dt < 20.0, dt                      # it waited for the bounded spins, and no longer
+    assert torch.equal(good, again)
+
+
 def test_pos_and_trj_with_different_channel_counts():
     """CHANNELS may differ between the two networks (separate model_configs in the reference): one of them fusable
     (<= 256 channels), the other not - the pair then runs the un-fused first level for both (r3d_plan.cpp) instead of
