@@ -193,9 +193,25 @@ namespace {
 // prologue and run at 1.0 us per iteration.
 // Units of one to three iterations (the camera-embedding layers, K = 2 / 32) are all prologue and epilogue: 4 us per
 // unit by the workgroups' busy times (-DR3D_TIMING, R3D_TIMING_ALL), whatever the tile height.
+// (R3D_COST="iter,fixed,ks_iter,ks_fixed,first_extra,first_extra_wide,pair_scale": the constants, for tools/tune_cost.py)
+struct CostModel {
+    // (first_extra_wide 12 -> 7 and the fused pairs' second layer priced 8 % up: tools/tune_cost.py on the GPU - 1.946 against
+    //  1.976 ms at 1024 windows, 0.591 against 0.589 at 256; the other constants sit on a plateau)
+    double iter = 2200.0, fixed = 2500.0, ks_iter = 2600.0, ks_fixed = 6800.0, first_extra = 5.0, first_extra_wide = 7.0, pair_scale = 1.08;
+};
+const CostModel &cost_model() {
+    static const CostModel c = [] {
+        CostModel m;
+        if (const char *e = getenv("R3D_COST"))
+            sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf,%lf", &m.iter, &m.fixed, &m.ks_iter, &m.ks_fixed, &m.first_extra, &m.first_extra_wide, &m.pair_scale);
+        return m;
+    }();
+    return c;
+}
 double unit_cycles(int iters, int ks) {
-    if (ks > 1) return iters * 2600.0 + 6800.0;
-    return iters * 2200.0 + 2500.0 + (iters < 4 ? (4 - iters) * 1400.0 : 0.0);
+    const CostModel &c = cost_model();
+    if (ks > 1) return iters * c.ks_iter + c.ks_fixed;
+    return iters * c.iter + c.fixed + (iters < 4 ? (4 - iters) * 1400.0 : 0.0);
 }
 
 // a GEMV tile (r3d_kernels.hip): one memory round trip for the weights of its 32 columns, the operand copy, two barriers,
@@ -491,7 +507,7 @@ static SchedProb sched_prob_of(const Plan *pl, const ProbSpec &q, int64_t B) {
             // (+ the gather passes over the tile's 96 first-layer rows and the phase changes: one pass when the operand
             // tile is narrow enough to hold all rows, three otherwise; 5 / 12 iterations' time by the phase stamps:
             // 45.5 us for a body-part tile, 67.5 us for the trajectory model's at 2.1 GHz)
-            sp.nk2 = 2 * sp.nk + mm->layers[q.layer2].Kpad / BK + mm->layers[q.layer3].Kpad / BK + (L.Kpad <= 64 ? 5 : 12);
+            sp.nk2 = 2 * sp.nk + mm->layers[q.layer2].Kpad / BK + mm->layers[q.layer3].Kpad / BK + (int)(L.Kpad <= 64 ? cost_model().first_extra : cost_model().first_extra_wide);
             if (b3 && L.bf3_conv) {
                 // on the bf16 matrix cores, by the per-tile stamps of the single-launch forward (tools/fwd_gantt.py): a
                 // body-part tile 57.7 us against 89.3 in fp32 (0.65x), the trajectory model's 60 against 73 (0.82x).  (Round 2,
@@ -502,7 +518,7 @@ static SchedProb sched_prob_of(const Plan *pl, const ProbSpec &q, int64_t B) {
         } else if (q.layer2 >= 0) {                // fused pair: whole tiles of <= 128 rows, no split
             sp.max_ks = 1;
             sp.max_units = 4;
-            sp.nk2 = pl->m[q.model]->layers[q.layer2].Kpad / BK;
+            sp.nk2 = (int)(pl->m[q.model]->layers[q.layer2].Kpad / BK * cost_model().pair_scale + 0.5);
             if (b3 && L.bf3_conv && pl->m[q.model]->layers[q.layer2].bf3_conv && q.nseg == 1) {   // on the bf16 matrix cores: tiles of <= 96 rows,
                 sp.max_units = 3;                                                            // 0.65x (two units) .. 0.8x (one) the time per unit
                 sp.nk = (sp.nk * 7 + 5) / 10;
