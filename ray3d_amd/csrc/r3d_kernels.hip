@@ -692,15 +692,13 @@ __device__ __forceinline__ void gemm_tile_b3(ProbRef P, const int row0, const in
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
                     av[mi][p] = *reinterpret_cast<const bf16x8 *>(s + p * PLANE + mi * 32 * B3_LD + h * 8);
+            // (product-major: consecutive MFMAs go to different accumulators - no back-to-back dependent pair when MI > 1)
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PW[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][2], wp[0], acc[mi], 0, 0, 0);
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][1], wp[1], acc[mi], 0, 0, 0);
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][0], wp[2], acc[mi], 0, 0, 0);
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][1], wp[0], acc[mi], 0, 0, 0);
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][0], wp[1], acc[mi], 0, 0, 0);
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][0], wp[0], acc[mi], 0, 0, 0);
-            }
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi][PA[t]], wp[PW[t]], acc[mi], 0, 0, 0);
         }
         __syncthreads();
         st_cur = st_next;
@@ -929,15 +927,13 @@ __device__ __forceinline__ void b3t_mma_ktile(const char *xb, const int pitch, c
 #pragma unroll
             for (int p = 0; p < 3; ++p)
                 av[mi][p] = *reinterpret_cast<const bf16x8 *>(xb + p * plane_bytes + ((mi * 32 + li) * pitch + h * 16 + lh * 8) * 2);
+        // (product-major, smallest product first: consecutive MFMAs go to different accumulators)
+        constexpr int PW[6] = {0, 1, 2, 0, 1, 0}, PX[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[0], av[mi][2], acc[mi], 0, 0, 0);
-            acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[1], av[mi][1], acc[mi], 0, 0, 0);
-            acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[2], av[mi][0], acc[mi], 0, 0, 0);
-            acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[0], av[mi][1], acc[mi], 0, 0, 0);
-            acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[1], av[mi][0], acc[mi], 0, 0, 0);
-            acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[0], av[mi][0], acc[mi], 0, 0, 0);
-        }
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[PW[t]], av[mi][PX[t]], acc[mi], 0, 0, 0);
     }
 }
 
