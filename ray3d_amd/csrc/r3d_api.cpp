@@ -292,18 +292,23 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
     const bool single = forward_single_launch() && sched->fwd.grid > 0 && !(uv && !sched->fwd.d_rel[1]);
     if (single) {
         // ---- the whole forward as ONE persistent launch: bind (zero the ready counters, resolve the problem table), run
-        const Schedule::Fwd &fw = sched->fwd;
-        char *ctrl = reinterpret_cast<char *>(ws) + workspace_act_bytes(pl, B);
-        unsigned *cnt = reinterpret_cast<unsigned *>(ctrl);
-        GemmProb *table = reinterpret_cast<GemmProb *>(ctrl + ((size_t)(fw.ncnt + 4) * sizeof(unsigned) + 255) / 256 * 256);
+        Schedule::Fwd &fw = sched->fwd;
+        // Control region: the caller's workspace while the stream is being captured (the graph binds for itself), the
+        // schedule's own otherwise - there a call on the buffers of the previous one finds the table bound and a zeroed
+        // bank of counters, and skips r3d_bind_f32 (4-5 us per call; R3D_BIND_ALWAYS=1: never)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
+        static const bool bind_always = env_on("R3D_BIND_ALWAYS");
+        const bool own = cap == hipStreamCaptureStatusNone && fw.d_ctrl != nullptr && !bind_always;
+        char *ctrl = own ? fw.d_ctrl : reinterpret_cast<char *>(ws) + workspace_act_bytes(pl, B);
+        const size_t bank_bytes = ((size_t)(fw.ncnt + 4) * sizeof(unsigned) + 255) / 256 * 256;
+        GemmProb *table = reinterpret_cast<GemmProb *>(ctrl + (own ? 2 : 1) * bank_bytes);
         BindArgs ba;
         memset(&ba, 0, sizeof ba);
         ba.rel = fw.d_rel[uv ? 1 : 0];
         ba.tags = fw.d_tags[uv ? 1 : 0];
         ba.out = table;
-        ba.cnt = cnt;
         ba.nprob = fw.nprob;
-        ba.ncnt = fw.ncnt;
         ba.base[BIND_WS] = ws;
         ba.base[BIND_ARENA0] = bases.arena[0];
         ba.base[BIND_ARENA1] = bases.arena[1];
@@ -317,17 +322,29 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         ba.cam_stride = in->cam_stride;
         ba.enc_bytes = (unsigned)((size_t)frames * JF * sizeof(float));
         ba.param_stride = (int)in->param_stride;
-        if ((e = rec.begin("r3d_bind_f32", stage_no, 1, 0.0, 0.0)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        Schedule::Fwd::Bound &bd = fw.bound;
+        bool bound = own && bd.valid && bd.uv == (uv ? 1 : 0) && bd.enc_ws == ba.enc_ws && bd.cam_stride == ba.cam_stride &&
+                     bd.enc_bytes == ba.enc_bytes && bd.param_stride == ba.param_stride;
+        for (int k = 0; bound && k < BIND_NBASE; ++k) bound = bd.base[k] == ba.base[k];
+        const int bank = bound ? bd.bank ^ 1 : 0;
+        unsigned *cnt = reinterpret_cast<unsigned *>(ctrl + (own ? bank : 0) * bank_bytes);
         if ((e = order_single_launch(stream, true)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
-        if ((e = launch_bind(ba, stream)) != hipSuccess) return hip_fail(e, "launch r3d_bind_f32");
-        if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
-        ++stage_no;
+        if (!bound) {
+            ba.cnt = reinterpret_cast<unsigned *>(ctrl);
+            ba.ncnt = own ? (int)(2 * bank_bytes / sizeof(unsigned)) - 4 : fw.ncnt;      // (the kernel zeroes ncnt + 4 words: both banks)
+            if ((e = rec.begin("r3d_bind_f32", stage_no, 1, 0.0, 0.0)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+            if ((e = launch_bind(ba, stream)) != hipSuccess) return hip_fail(e, "launch r3d_bind_f32");
+            if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
+            ++stage_no;
+        }
+        bd.valid = false;          // (until this call's launch is on the stream: it is what zeroes the bank the next call runs on)
         FwdArgs fa;
         memset(&fa, 0, sizeof fa);
         fa.tiles = fw.d_tiles;
         fa.wg_off = fw.d_wgoff;
         fa.probs = table;
         fa.cnt = cnt;
+        fa.cnt_next = own ? reinterpret_cast<unsigned *>(ctrl + (bank ^ 1) * bank_bytes) : nullptr;
         fa.ncnt = fw.ncnt;
         if (const char *ft = getenv("R3D_FAULT_TILE")) fa.fault_tile1 = atoi(ft) + 1;   // test hook: see FwdArgs
         const bool uv_launch = uv && fw.uses_gather;
@@ -344,6 +361,16 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
 #endif
         if ((e = launch_forward(fa, fw.grid, uv_launch, stream)) != hipSuccess) return hip_fail(e, "launch r3d_forward_f32");
         if ((e = order_single_launch(stream, false)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        if (own) {                     // the next call on these buffers needs no bind
+            bd.valid = true;
+            bd.bank = bank;
+            bd.uv = uv ? 1 : 0;
+            bd.enc_ws = ba.enc_ws;
+            bd.cam_stride = ba.cam_stride;
+            bd.enc_bytes = ba.enc_bytes;
+            bd.param_stride = ba.param_stride;
+            for (int k = 0; k < BIND_NBASE; ++k) bd.base[k] = ba.base[k];
+        }
 #ifdef R3D_TIMING
         if (fa.dbg) {
             (void)hipStreamSynchronize(stream);

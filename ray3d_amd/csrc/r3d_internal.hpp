@@ -97,6 +97,8 @@ struct FwdArgs {
     const int *wg_off;        // [grid + 1]: workgroup b executes tiles [wg_off[b], wg_off[b+1])
     const GemmProb *probs;    // the call's problem table (absolute pointers; written by r3d_bind_f32 ahead of the launch)
     unsigned *cnt;            // ready counters, zeroed by r3d_bind_f32; cnt[ncnt] is the abort flag (a spin gave up)
+    unsigned *cnt_next;       // the other bank of counters (library-owned control region), zeroed by THIS launch for the
+                              // next call, which then needs no r3d_bind_f32 of its own; nullptr: one bank, bound per call
     int ncnt;
     int fault_tile1;          // test hook (R3D_FAULT_TILE=<n>): workgroup 0's n-th tile behind the first level never raises its counters (0: none; n + 1 stored)
     long long *dbg;
@@ -288,6 +290,21 @@ struct Schedule {
         std::vector<int> h_tiles, h_wgoff;    // host copies of the lists (diagnostics)
         double flops = 0, bytes = 0;
         bool uses_gather = false;             // some problem gathers from the input (UV mode selects the _uv kernel)
+        // Library-owned control region of the calls that are not being captured into a graph: two banks of ready
+        // counters (+ abort flag) and the bound problem table.  A call whose buffers are the ones the table was bound
+        // to skips r3d_bind_f32: it runs on the bank the previous launch zeroed and zeroes the other one itself.
+        // (Captured calls keep their control region in the caller's workspace and bind inside the graph: a replay
+        // must not depend on, or disturb, what eager calls left here.)
+        char *d_ctrl = nullptr;
+        size_t bank_bytes = 0;
+        struct Bound {
+            bool valid = false;
+            int bank = 0;
+            const void *base[BIND_NBASE] = {nullptr};
+            long long enc_ws = 0, cam_stride = 0;
+            unsigned enc_bytes = 0;
+            int param_stride = 0, uv = 0;
+        } bound;
     } fwd;
     ~Schedule();
 };

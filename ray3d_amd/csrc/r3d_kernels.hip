@@ -304,16 +304,18 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
 
     // ---- W fragments: [(n/32)][k tile][q][lane][4] in HBM, this wavefront's 32 columns
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // make the descriptor provably wave-uniform
+    // (the wavefront's K-slice of an iteration is part of the base, not of the scalar offset: the compiler
+    // kept wave_u / WN in a VGPR and wrapped every W load in a waterfall loop)
     __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(P.w + ((size_t)((col0 >> 5) + wave_u % WN) * nk32) * 1024), 0, nk32 * 4096,
-        0x00020000);   // (K tiles past the end read as zeros through the descriptor's bound)
+        const_cast<float *>(P.w + ((size_t)((col0 >> 5) + wave_u % WN) * nk32 + wave_u / WN) * 1024), 0,
+        (nk32 - wave_u / WN) * 4096, 0x00020000);   // (K tiles past the end read as zeros through the descriptor's bound)
     const int w_voff = lane * 16;
     f32x4 rb[4], rbn[4], rbn2[4];           // W fragments of the current and the next K tile(s)
     auto load_w = [&](int kt, f32x4 (&dst)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             dst[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                wrsrc, w_voff + q * 1024, (kt * KS + wave_u / WN) * 4096, 0));
+                wrsrc, w_voff + q * 1024, kt * KS * 4096, 0));
     };
 
     f32x16 acc[MI];
@@ -1521,7 +1523,7 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
             if (ts == R3D_TS) R3D_TSTAMP(5);
             // ---- activations (in place: the residual tap's stay in acc0 for the epilogue) -> H
             load_frag(w1rsrc, tap * tiles_per_tap, rb);
-            load_frag(w1rsrc, tap * tiles_per_tap + (tiles_per_tap > 1 ? 1 : 0), rbn);
+            load_frag(w1rsrc, __builtin_amdgcn_readfirstlane(tap * tiles_per_tap + (tiles_per_tap > 1 ? 1 : 0)), rbn);   // (else: four waterfall loops)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 float *wr = H + (mi * 32 + 4 * lh) * PAIR_LD + wave * 32 + li;
@@ -1838,7 +1840,7 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
             if (ts == R3D_TS) R3D_TSTAMP(5);
             // ---- activations -> H planes (the residual tap's stay in acc0, fp32, for the epilogue)
             load_w(w1rsrc, tap * tiles_per_tap, wa);
-            load_w(w1rsrc, tap * tiles_per_tap + (tiles_per_tap > 1 ? 1 : 0), wb);
+            load_w(w1rsrc, __builtin_amdgcn_readfirstlane(tap * tiles_per_tap + (tiles_per_tap > 1 ? 1 : 0)), wb);
             b3t_activate_to_planes<MI>(acc0, slope0, Hb, FLB_H_PLANE, li, ch0);
             __syncthreads();
             if (ts == R3D_TS) R3D_TSTAMP(6);
@@ -2175,6 +2177,13 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
     const gu32 abort_flag = DEP ? (gu32)(fargs->cnt + fargs->ncnt) : (gu32) nullptr;
     const int t0 = __builtin_amdgcn_readfirstlane(wg_off[wg]);
     const int t1 = __builtin_amdgcn_readfirstlane(wg_off[wg + 1]);
+    if constexpr (DEP) {
+        // the other bank of ready counters (and its abort flag): zero for the next call, which then runs without r3d_bind_f32
+        // (nothing reads that bank before this launch has ended)
+        unsigned *nx = fargs->cnt_next;
+        if (nx != nullptr)
+            for (int j = blockIdx.x * GEMM_THREADS + threadIdx.x; j < fargs->ncnt + 4; j += gridDim.x * GEMM_THREADS) nx[j] = 0u;
+    }
     long long *dbg = nullptr;
 #ifdef R3D_TIMING
     long long *dbg_arg = DEP ? fargs->dbg : args->dbg;
@@ -2463,6 +2472,23 @@ hipError_t launch_bind(const BindArgs &args, hipStream_t stream) {
 // 3-output trajectory head itself - cheaper than a dependency between wavefronts.  These layers are
 // 0.05 % of the FLOPs; as GEMMs their N = 3..15 would waste a 256-column tile.
 // Three output rows (one joint) of a decoder against one hidden row: all loads first, then the reductions.
+// Sum over the 64 lanes with DPP adds (six dependent VALU instructions; __shfl_xor goes through the LDS crossbar, ~8x the
+// latency per step, and the decoder kernel is a chain of such reductions): pairs, quads, half rows, rows of 16, then
+// row 0 -> 1 and 2 -> 3 (row_bcast:15), rows 0-1 -> 2-3 (row_bcast:31); lane 63 holds the total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float x) {              // (rows outside the mask add 0)
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = dpp_add<0xb1, 0xf>(v);       // quad_perm [1,0,3,2]
+    v = dpp_add<0x4e, 0xf>(v);       // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);      // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);      // row_mirror
+    v = dpp_add<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 struct DecodeJoint {
     f32x4 w[3][4];
     __device__ __forceinline__ void load(const float *wrows, int lane) {
@@ -2478,25 +2504,28 @@ struct DecodeJoint {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc += hv[j][0] * w[n][j][0] + hv[j][1] * w[n][j][1] + hv[j][2] * w[n][j][2] + hv[j][3] * w[n][j][3];
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
-            o[n] = acc;
+            o[n] = wave_sum(acc);
         }
     }
 };
 
-// One wavefront per (window, joint): a single memory round trip (the joint's three decoder rows, its hidden
-// row, and - recomputed by every wavefront, cheaper than a dependency - the trajectory head), 64-lane dot
-// products, and the (x, y, z) written straight into the joint slot of the reference's reassembly.
-extern "C" __global__ __launch_bounds__(256) void r3d_decode_f32(const DecodeArgs a) {
+// One wavefront per (joint, W consecutive windows): the joint's three decoder rows and the trajectory head's three are
+// read once for its windows, each window's two hidden rows stream through two register sets (the next window loads
+// while this one is reduced), 64-lane dot products, and the (x, y, z) written straight into the joint slot of the
+// reference's reassembly.  Every wavefront recomputes the trajectory head of its windows - cheaper than a dependency
+// between wavefronts.  W = 4 from 128 windows (22.7 against 27.9 us at 1024 windows: fewer, longer wavefronts), W = 1 below
+// (3.5 us at one window; every further window of a wavefront adds 0.6 us to a launch that is one round of wavefronts anyway).
+template <int DECODE_WINDOWS>
+__device__ __forceinline__ void decode_body(const DecodeArgs &a) {
     const int lane = threadIdx.x & 63;
     const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // global wavefront index
     const int per_win = a.has_pos ? a.J : 1;
-    const long long b = gw / per_win;
-    if (b >= a.B) return;
+    const long long b0 = gw / per_win * DECODE_WINDOWS;
+    if (b0 >= a.B) return;
     // (single-launch forward: a dependency spin that gave up leaves garbage behind - make it loud)
     const bool poisoned = a.abort_flag != nullptr && __hip_atomic_load((gu32)a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    const int jf = (int)(gw - b * per_win);          // joint in flat decoder order
+    const float poison = poisoned ? __builtin_nanf("") : 0.0f;
+    const int jf = (int)(gw % per_win);              // joint in flat decoder order
     const int ts = a.nsrc - 1;
     int s = 0, o = 0;
     if (a.has_pos) {
@@ -2504,44 +2533,70 @@ extern "C" __global__ __launch_bounds__(256) void r3d_decode_f32(const DecodeArg
         for (int q = 0; q < npos; ++q)
             if (3 * jf >= a.first[q]) { s = q; o = 3 * jf - a.first[q]; }
     }
-    f32x4 hv[4], ht[4];
+    f32x4 hv[2][4], ht[2][4];                        // two windows in flight: the next one loads while this one is reduced
     DecodeJoint rt, rj;
+    if (a.has_trj) rt.load(a.w[ts], lane);
+    if (a.has_pos) rj.load(a.w[s] + (size_t)o * MLP_HIDDEN, lane);
+    auto load_window = [&](int i) {                  // (windows past the batch re-read the last one; nothing is stored for them)
+        const long long b = b0 + i < a.B ? b0 + i : a.B - 1;
+        if (a.has_trj) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ht[i & 1][j] = gload4(a.h[ts] + b * MLP_HIDDEN + j * 256 + lane * 4);
+        }
+        if (a.has_pos) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hv[i & 1][j] = gload4(a.h[s] + b * MLP_HIDDEN + j * 256 + lane * 4);
+        }
+    };
+    load_window(0);
+    // (the epilogue's constants requested before the reductions, not behind them)
+    float bt[3] = {0.0f, 0.0f, 0.0f}, bj[3] = {0.0f, 0.0f, 0.0f};
+    int e = 0;
     if (a.has_trj) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ht[j] = gload4(a.h[ts] + b * MLP_HIDDEN + j * 256 + lane * 4);
-        rt.load(a.w[ts], lane);
+        for (int n = 0; n < 3; ++n) bt[n] = a.bias[ts][n];
     }
     if (a.has_pos) {
+        e = a.slot[a.first[s] + o];                  // (x, y, z) of a joint are consecutive in the output
 #pragma unroll
-        for (int j = 0; j < 4; ++j) hv[j] = gload4(a.h[s] + b * MLP_HIDDEN + j * 256 + lane * 4);
-        rj.load(a.w[s] + (size_t)o * MLP_HIDDEN, lane);
+        for (int n = 0; n < 3; ++n) bj[n] = a.bias[s][o + n];
     }
-    float trj[3] = {0.0f, 0.0f, 0.0f};
-    if (a.has_trj) {
-        rt.dot(ht, trj);
 #pragma unroll
-        for (int n = 0; n < 3; ++n) trj[n] += a.bias[ts][n] + (poisoned ? __builtin_nanf("") : 0.0f);
-        if (lane == 0 && jf == 0) {
+    for (int i = 0; i < DECODE_WINDOWS; ++i) {
+        if (i + 1 < DECODE_WINDOWS) load_window(i + 1);
+        const long long b = b0 + i;
+        const bool live = b < a.B;
+        float trj[3] = {0.0f, 0.0f, 0.0f};
+        if (a.has_trj) {
+            rt.dot(ht[i & 1], trj);
 #pragma unroll
-            for (int n = 0; n < 3; ++n) {
-                if (a.out_trj) a.out_trj[b * 3 + n] = trj[n];
-                if (!a.has_pos) a.out[b * 3 + n] = trj[n];
+            for (int n = 0; n < 3; ++n) trj[n] += bt[n] + poison;
+            if (live && lane == 0 && jf == 0) {
+#pragma unroll
+                for (int n = 0; n < 3; ++n) {
+                    if (a.out_trj) a.out_trj[b * 3 + n] = trj[n];
+                    if (!a.has_pos) a.out[b * 3 + n] = trj[n];
+                }
             }
         }
-    }
-    if (!a.has_pos) return;
-    float v[3];
-    rj.dot(hv, v);
-    if (lane == 0) {
-        const int e = a.slot[a.first[s] + o];     // (x, y, z) of a joint are consecutive in the output
+        if (!a.has_pos) continue;
+        float v[3];
+        rj.dot(hv[i & 1], v);
+        if (live && lane == 0) {
 #pragma unroll
-        for (int n = 0; n < 3; ++n) a.out[b * (a.J * 3) + e + n] = v[n] + a.bias[s][o + n] + trj[n] + (poisoned ? __builtin_nanf("") : 0.0f);
+            for (int n = 0; n < 3; ++n) a.out[b * (a.J * 3) + e + n] = v[n] + bj[n] + trj[n] + poison;
+        }
     }
 }
 
+extern "C" __global__ __launch_bounds__(256) void r3d_decode_f32(const DecodeArgs a) { decode_body<1>(a); }
+extern "C" __global__ __launch_bounds__(256) void r3d_decode_w4_f32(const DecodeArgs a) { decode_body<4>(a); }
+
 hipError_t launch_decode(const DecodeArgs &args, hipStream_t stream) {
-    const long long waves = args.B * (args.has_pos ? args.J : 1);
-    r3d_decode_f32<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream>>>(args);
+    const int w = args.B >= 128 ? 4 : 1;
+    const long long waves = (args.B + w - 1) / w * (args.has_pos ? args.J : 1);
+    if (w == 4) r3d_decode_w4_f32<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream>>>(args);
+    else r3d_decode_f32<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream>>>(args);
     return hipGetLastError();
 }
 

@@ -28,6 +28,7 @@ Schedule::~Schedule() {
     if (d_wgoff) (void)hipFree(d_wgoff);
     if (fwd.d_tiles) (void)hipFree(fwd.d_tiles);
     if (fwd.d_wgoff) (void)hipFree(fwd.d_wgoff);
+    if (fwd.d_ctrl) (void)hipFree(fwd.d_ctrl);
     for (int i = 0; i < 2; ++i) {
         if (fwd.d_rel[i]) (void)hipFree(fwd.d_rel[i]);
         if (fwd.d_tags[i]) (void)hipFree(fwd.d_tags[i]);
@@ -748,6 +749,10 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
             }
             fw.h_tiles = ft;
             fw.h_wgoff = fo;
+            if (ok) {                  // the library-owned control region (Schedule::Fwd::d_ctrl): two counter banks + the bound table
+                fw.bank_bytes = ((size_t)(fw.ncnt + 4) * sizeof(unsigned) + 255) / 256 * 256;
+                ok = (e = hipMalloc((void **)&fw.d_ctrl, 2 * fw.bank_bytes + (size_t)fw.nprob * sizeof(GemmProb))) == hipSuccess;
+            }
             if (!ok) {
                 hip_fail(e, "schedule upload (single-launch form)");
                 delete s;

@@ -1094,6 +1094,57 @@ def test_forward_captured_in_a_hip_graph_after_prepare():
         ray3d_amd._capi.release(hp, ht, B)
 
 
+def test_a_call_on_the_buffers_of_the_previous_one_skips_the_bind_kernel():
+    """Eager calls keep their ready counters and bound problem table in a control region the schedule owns: a call whose
+    input / parameter / workspace pointers are the previous call's runs WITHOUT r3d_bind_f32, on the counter bank the
+    previous launch zeroed (r3d_api.cpp).  Outputs must not depend on which path a call took: repeated calls, calls that
+    alternate between two inputs (bind every time), new contents behind the same pointer, and eager calls around the
+    replay of a captured graph - which binds inside the graph, in the caller's workspace - all give the same bits."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
+    pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    B = 150
+    x1 = torch.from_numpy(synth.synth_rays(B, cp, seed=201)).cuda()
+    x2 = torch.from_numpy(synth.synth_rays(B, cp, seed=202)).cuda()
+    p = torch.from_numpy(synth.synth_param(B, seed=203)).cuda()
+    names = lambda recs: [r["kernel"] for r in recs]
+    with torch.no_grad():
+        first = lifter(x1, p)
+        recs = lifter.profile_call(lambda: lifter(x1, p), x1.device)
+        assert "r3d_forward_f32" in names(recs) and "r3d_bind_f32" not in names(recs), names(recs)
+        for _ in range(4):                                   # both counter banks, twice
+            assert torch.equal(lifter(x1, p), first)
+        other = lifter(x2, p)                                # another input pointer: bound again
+        recs = lifter.profile_call(lambda: lifter(x1, p), x1.device)
+        assert "r3d_bind_f32" in names(recs), names(recs)
+        for _ in range(3):
+            assert torch.equal(lifter(x2, p), other)
+            assert torch.equal(lifter(x1, p), first)
+        check_parity(first, _oracle_lift(((cp, sp), (ct, st)), x1.cpu().numpy(), p.cpu().numpy()), "bind skipped, %d windows" % B)
+        # new contents behind the pointer the table is bound to
+        keep = x1.clone()
+        x1.copy_(x2)
+        assert torch.equal(lifter(x1, p), other)
+        x1.copy_(keep)
+        assert torch.equal(lifter(x1, p), first)
+        # a captured forward of the other input between eager calls
+        out = torch.empty((B, 1, 17, 3), device="cuda")
+        g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                lifter._run(ray3d_amd._capi.R3D_INPUT_RAYS, x2, 27, B, p, 2, out=out)
+        assert torch.equal(lifter(x1, p), first)
+        assert torch.equal(lifter(x1, p), first)
+        for _ in range(2):
+            out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, other)
+            assert torch.equal(lifter(x1, p), first)        # (table still bound to x1: the replay used the workspace's region)
+
+
 def test_a_tile_that_never_reports_ends_in_nan_not_in_a_hang(monkeypatch):
     """The single-launch forward orders its tiles by ready counters; a counter that never fills must not hang the GPU.
     R3D_FAULT_TILE makes one tile of workgroup 0 skip its counter update: its consumers spin, give up after ~1 s, raise the
