@@ -258,8 +258,8 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         return R3D_ERR_WORKSPACE;
     }
     hipStream_t stream = (hipStream_t)stream_v;
-    float *wsf = (float *)ws;
-    auto buf_ptr = [&](int id) -> float * { return wsf + (size_t)pl->buffers[id].offset_per_window * (size_t)B; };
+    float *act_base = (float *)ws;         // (poll mode: the schedule's own activation bank of this call)
+    auto buf_ptr = [&](int id) -> float * { return act_base + (size_t)pl->buffers[id].offset_per_window * (size_t)B; };
     Recorder rec{a, stream};
     hipError_t e;
     int stage_no = 0;
@@ -302,12 +302,14 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         const bool own = cap == hipStreamCaptureStatusNone && fw.d_ctrl != nullptr && !bind_always;
         char *ctrl = own ? fw.d_ctrl : reinterpret_cast<char *>(ws) + workspace_act_bytes(pl, B);
         const size_t bank_bytes = ((size_t)(fw.ncnt + 4) * sizeof(unsigned) + 255) / 256 * 256;
-        GemmProb *table = reinterpret_cast<GemmProb *>(ctrl + (own ? 2 : 1) * bank_bytes);
+        GemmProb *tables = reinterpret_cast<GemmProb *>(ctrl + (own ? 2 : 1) * bank_bytes);   // (own: one table per activation bank)
+        // calls of a few windows, not captured: activations in the schedule's own two banks, data as its own ready flag
+        const bool poll = own && fw.d_act != nullptr;
         BindArgs ba;
         memset(&ba, 0, sizeof ba);
         ba.rel = fw.d_rel[uv ? 1 : 0];
         ba.tags = fw.d_tags[uv ? 1 : 0];
-        ba.out = table;
+        ba.out = tables;
         ba.nprob = fw.nprob;
         ba.base[BIND_WS] = ws;
         ba.base[BIND_ARENA0] = bases.arena[0];
@@ -332,11 +334,27 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         if (!bound) {
             ba.cnt = reinterpret_cast<unsigned *>(ctrl);
             ba.ncnt = own ? (int)(2 * bank_bytes / sizeof(unsigned)) - 4 : fw.ncnt;      // (the kernel zeroes ncnt + 4 words: both banks)
+            if (poll) {                 // both activation banks armed, bank 0's table
+                ba.base[BIND_WS] = fw.d_act;
+                ba.arm = fw.d_act;
+                ba.arm_vec4 = (long long)(2 * fw.act_bytes / 16);
+            }
             if ((e = rec.begin("r3d_bind_f32", stage_no, 1, 0.0, 0.0)) != hipSuccess) return hip_fail(e, "hipEventRecord");
             if ((e = launch_bind(ba, stream)) != hipSuccess) return hip_fail(e, "launch r3d_bind_f32");
+            if (poll) {                 // ... and bank 1's
+                BindArgs b1 = ba;
+                b1.base[BIND_WS] = fw.d_act + fw.act_bytes;
+                b1.out = tables + fw.nprob;
+                b1.ncnt = -4;
+                b1.arm = nullptr;
+                if ((e = launch_bind(b1, stream)) != hipSuccess) return hip_fail(e, "launch r3d_bind_f32");
+            }
             if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
             ++stage_no;
+            ba.base[BIND_WS] = ws;      // (the key of the bound state: what the caller passed)
         }
+        const GemmProb *table = tables + (poll ? bank * fw.nprob : 0);
+        if (poll) act_base = reinterpret_cast<float *>(fw.d_act + (size_t)bank * fw.act_bytes);
         bd.valid = false;          // (until this call's launch is on the stream: it is what zeroes the bank the next call runs on)
         FwdArgs fa;
         memset(&fa, 0, sizeof fa);
@@ -346,6 +364,11 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         fa.cnt = cnt;
         fa.cnt_next = own ? reinterpret_cast<unsigned *>(ctrl + (bank ^ 1) * bank_bytes) : nullptr;
         fa.ncnt = fw.ncnt;
+        if (poll) {
+            fa.poll = 1;
+            fa.arm = fw.d_act + (size_t)(bank ^ 1) * fw.act_bytes;
+            fa.arm_vec4 = (long long)(fw.act_bytes / 16);
+        }
         if (const char *ft = getenv("R3D_FAULT_TILE")) fa.fault_tile1 = atoi(ft) + 1;   // test hook: see FwdArgs
         const bool uv_launch = uv && fw.uses_gather;
         if ((e = rec.begin(uv_launch ? "r3d_forward_uv_f32" : "r3d_forward_f32", stage_no, fw.grid, fw.flops, fw.bytes)) != hipSuccess)

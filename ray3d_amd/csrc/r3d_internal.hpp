@@ -100,6 +100,9 @@ struct FwdArgs {
     unsigned *cnt_next;       // the other bank of counters (library-owned control region), zeroed by THIS launch for the
                               // next call, which then needs no r3d_bind_f32 of its own; nullptr: one bank, bound per call
     int ncnt;
+    int poll;                 // GEMV / latency tiles read their operands until no ACT_SENTINEL is left instead of waiting for counters
+    void *arm;                // the other bank of activations: filled with sentinels by this launch, for the next call (or nullptr)
+    long long arm_vec4;       // ... its size in 16-byte units
     int fault_tile1;          // test hook (R3D_FAULT_TILE=<n>): workgroup 0's n-th tile behind the first level never raises its counters (0: none; n + 1 stored)
     long long *dbg;
 };
@@ -115,6 +118,8 @@ struct BindArgs {
     long long enc_ws, cam_stride;  // per call: window stride in elements, doubles between camera rows
     unsigned enc_bytes;
     int param_stride;
+    void *arm;                     // activation bank(s) to fill with sentinels (poll mode; nullptr otherwise)
+    long long arm_vec4;
 };
 
 constexpr int MAX_DEC = 6;     // 5 body-part decoders + the trajectory decoder
@@ -297,6 +302,12 @@ struct Schedule {
         // must not depend on, or disturb, what eager calls left here.)
         char *d_ctrl = nullptr;
         size_t bank_bytes = 0;
+        // Calls of a few windows (tiles of the GEMV / latency kinds in the lists): two library-owned banks of ACTIVATIONS as
+        // well, each filled with sentinels by the launch that runs on the other one - the tiles then take data as its
+        // own ready flag (r3d_kernels.hip, ACT_SENTINEL).  Not while capturing: a captured call uses the caller's
+        // workspace and the ready counters.
+        char *d_act = nullptr;
+        size_t act_bytes = 0;
         struct Bound {
             bool valid = false;
             int bank = 0;

@@ -1963,9 +1963,34 @@ constexpr int GEMV_MAX_M = 4;
 __device__ __forceinline__ void wait_deps(const int4 *tile, const int ndep, const gu32 cnt, const gu32 abort_flag);
 // (single-launch form: these tiles wait for their producers themselves - BEHIND their weight requests, which depend on no
 //  producer: in a call of a few windows a layer is one memory round trip, and the wait for the previous layer hides it)
-struct TileDeps { const int4 *tile; int ndep; gu32 cnt, abort_flag; };
+struct TileDeps { const int4 *tile; int ndep; gu32 cnt, abort_flag; bool poll; };
 __device__ __forceinline__ float act_ld(const float *p) {
     return __builtin_bit_cast(float, __hip_atomic_load((gu32)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // 4-byte sc1 load
+}
+// Data as its own ready flag (calls of a few windows, FwdArgs::poll): the activation bank of the call was filled with
+// ACT_SENTINEL - a quiet NaN no arithmetic produces - before the launch, GEMV / latency tiles read their operands until
+// no sentinel is left in them instead of waiting for ready counters first, and their producers' write-through stores need
+// no drain, counter update and counter poll in between: a dependency hop is one store -> load latency.  Every float is
+// its own flag, so no ordering between stores is assumed.  (A producer that computes exactly this NaN - only from an
+// input that carries it - stores the canonical quiet NaN instead.)
+constexpr unsigned ACT_SENTINEL = 0x7fc5a1e7u;
+__device__ __forceinline__ bool act_missing(float v) { return __builtin_bit_cast(unsigned, v) == ACT_SENTINEL; }
+__device__ __forceinline__ void act_st(float *p, float v) {
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    u = u == ACT_SENTINEL ? 0x7fc00000u : u;
+    __hip_atomic_store((gu32)p, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one round of a bounded poll loop: true = give up (the launch's abort flag is up, or this wavefront has polled for ~1 s
+// and raises it) - the caller goes on with what it has, the decoder turns the outputs into NaN
+__device__ __forceinline__ bool poll_gave_up(unsigned &spins, long long &t_first, const gu32 abort_flag) {
+    __builtin_amdgcn_s_sleep(2);
+    if ((++spins & 31) != 0) return false;
+    if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+    const long long now = wall_clock64();                       // 100 MHz
+    if (t_first == 0) { t_first = now; return false; }
+    if (now - t_first <= 100000000LL) return false;
+    __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
 }
 __device__ __forceinline__ void gemv_tile(ProbRef P, const int col0, float *smem, const TileDeps &dep) {
     int tid = threadIdx.x;
@@ -1989,19 +2014,35 @@ __device__ __forceinline__ void gemv_tile(ProbRef P, const int col0, float *smem
     const int er = tid >> 5, ecol = col0 + (tid & 31);
     const bool emit = tid < M * 32 && ecol < N;
     const float ebias = emit ? gload1(P.bias + ecol) : 0.0f;       // (the epilogue's bias: requested now, used after the reduction)
-    if (dep.ndep > 0) wait_deps(dep.tile, dep.ndep, dep.cnt, dep.abort_flag);
-    const float eres = emit && P.res ? act_ld(P.res + (size_t)er * P.ldr + ecol) : 0.0f;
+    if (dep.ndep > 0 && !dep.poll) wait_deps(dep.tile, dep.ndep, dep.cnt, dep.abort_flag);
     // the operand rows -> LDS (a virtual concatenation of up to MAX_SEG buffers; every column of such a problem is real)
+    // (poll mode: read until no sentinel is left - each wavefront for its own elements, the barrier collects them)
     {
         const int e0 = P.kend[0], e1 = P.kend[1], e2 = P.kend[2];
         const float *a0 = P.a[0], *a1 = P.a[1], *a2 = P.a[2], *a3 = P.a[3];
         const int l0 = P.lda[0], l1 = P.lda[1], l2 = P.lda[2], l3 = P.lda[3];
-        for (int r = 0; r < M; ++r)
-            for (int k = tid; k < K; k += GEMM_THREADS) {
-                const float *src = k < e0 ? a0 + (size_t)r * l0 + k : k < e1 ? a1 + (size_t)r * l1 + (k - e0)
-                                 : k < e2 ? a2 + (size_t)r * l2 + (k - e1) : a3 + (size_t)r * l3 + (k - e2);
-                As[r * ldA + k] = act_ld(src);
-            }
+        unsigned spins = 0;
+        long long t_first = 0;
+        for (;;) {
+            bool missing = false;
+            for (int r = 0; r < M; ++r)
+                for (int k = tid; k < K; k += GEMM_THREADS) {
+                    const float *src = k < e0 ? a0 + (size_t)r * l0 + k : k < e1 ? a1 + (size_t)r * l1 + (k - e0)
+                                     : k < e2 ? a2 + (size_t)r * l2 + (k - e1) : a3 + (size_t)r * l3 + (k - e2);
+                    const float v = act_ld(src);
+                    missing |= act_missing(v);
+                    As[r * ldA + k] = v;
+                }
+            if (!dep.poll || !__any(missing) || poll_gave_up(spins, t_first, dep.abort_flag)) break;
+        }
+    }
+    // (the residual is an input of the operand's producer chain: whoever sees the operand sees it - polled all the same)
+    float eres = 0.0f;
+    if (emit && P.res) {
+        unsigned spins = 0;
+        long long t_first = 0;
+        do eres = act_ld(P.res + (size_t)er * P.ldr + ecol);
+        while (dep.poll && act_missing(eres) && !poll_gave_up(spins, t_first, dep.abort_flag));
     }
     __syncthreads();
     float acc[GEMV_MAX_M];
@@ -2033,7 +2074,7 @@ __device__ __forceinline__ void gemv_tile(ProbRef P, const int col0, float *smem
 #pragma unroll
         for (int w = 0; w < 8; ++w) v += red[(w * GEMV_MAX_M + er) * 32 + (tid & 31)];
         v = lrelu(v + ebias, P.slope) + eres;
-        __hip_atomic_store((gu32)(P.c + (size_t)er * P.ldc + ecol), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        act_st(P.c + (size_t)er * P.ldc + ecol, v);
     }
     __syncthreads();                                                // the next tile may write LDS
 }
@@ -2081,10 +2122,23 @@ __device__ __forceinline__ void lat_tile(ProbRef P, const int col0, float *smem,
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     load_w_round(0);
-    if (dep.ndep > 0) wait_deps(dep.tile, dep.ndep, dep.cnt, dep.abort_flag);
+    if (dep.ndep > 0 && !dep.poll) wait_deps(dep.tile, dep.ndep, dep.cnt, dep.abort_flag);
+    unsigned spins = 0;
+    long long t_first = 0;
     for (int j0 = 0; wave_u + 8 * j0 < nk32; j0 += 4) {
         if (j0) load_w_round(j0);
-        load_a_round(j0);
+        for (;;) {                                                     // (poll mode: until the round holds no sentinel)
+            load_a_round(j0);
+            if (!dep.poll) break;
+            bool missing = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) missing |= act_missing(af[j][q][kk]);
+            if (!__any(missing) || poll_gave_up(spins, t_first, dep.abort_flag)) break;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -2106,8 +2160,15 @@ __device__ __forceinline__ void lat_tile(ProbRef P, const int col0, float *smem,
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), col = col0 + (ln & 31);
         if (row < M && col < N) {
             v = lrelu(v + gload1(P.bias + col), P.slope);
-            if (P.res) v += act_ld(P.res + (size_t)row * P.ldr + col);
-            __hip_atomic_store((gu32)(P.c + (size_t)row * P.ldc + col), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (P.res) {
+                float rv;
+                unsigned rspins = 0;
+                long long rt = 0;
+                do rv = act_ld(P.res + (size_t)row * P.ldr + col);
+                while (dep.poll && act_missing(rv) && !poll_gave_up(rspins, rt, dep.abort_flag));
+                v += rv;
+            }
+            act_st(P.c + (size_t)row * P.ldc + col, v);
         }
     }
     __syncthreads();
@@ -2158,6 +2219,141 @@ __device__ __forceinline__ void wait_deps(const int4 *tile, const int ndep, cons
     __syncthreads();
 }
 
+// A workgroup's consecutive GEMV tiles as one run (single-launch form; calls of up to four windows are little else): the
+// tile loop of gemv_tile with the NEXT tile's first round of weights requested while this tile computes.  Every layer's
+// weights are read once per call, i.e. from HBM, and a CU that has a tile in every layer of the chain would otherwise
+// start that 2-3 us round trip only when its previous tile is done - longer than the tile itself.  The request goes out
+// behind this tile's operand loads (memory returns in order: in front of them it would delay them) and ahead of its
+// arithmetic.  Tiles whose consumers all take data as its own flag (FWD_TILE_NOSIGNAL, poll mode) skip the drain and the
+// counter update.
+constexpr int FWD_TILE_NOSIGNAL = 1;      // descriptor int 7, bit 0 (r3d_schedule.cpp)
+__device__ __forceinline__ void gemv_run(FwdArgsPtr fargs, const int4 *tl, const int TS, const int n, float *smem, const gu32 cnt,
+                                         const gu32 abort_flag, int &plain_seen, long long *dbg_arg, const int t_first_tile) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool poll = fargs->poll != 0;
+    typedef const GemmProb __attribute__((address_space(4))) *ProbPtr;
+    auto prob_of = [&](int i) -> ProbPtr {
+        return (ProbPtr)fargs->probs + (__builtin_amdgcn_readfirstlane(tl[i * TS].x) & 0xff);
+    };
+    auto request = [&](ProbPtr P, int col0, int j0, f32x4 (&wf)[4][4]) {
+        const int nk32 = P->K / BK;
+        __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(P->w + (size_t)(col0 >> 5) * nk32 * 1024), 0, nk32 * 4096, 0x00020000);   // (K tiles past the end read as zeros)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                wf[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16 + q * 1024, (wave_u + 8 * (j0 + j)) * 4096, 0));
+    };
+    f32x4 wa[4][4], wb[4][4];
+    request(prob_of(0), __builtin_amdgcn_readfirstlane(tl[0].z), 0, wa);
+    auto body = [&](const int i, f32x4 (&wf)[4][4], f32x4 (&wnext)[4][4]) {
+        const int4 *tile = tl + i * TS;
+        ProbPtr Pp = prob_of(i);
+        ProbRef P = *Pp;
+        const int col0 = __builtin_amdgcn_readfirstlane(tile[0].z);
+        const int4 te = tile[1];
+        const int ndep = __builtin_amdgcn_readfirstlane(te.x), sig_base = __builtin_amdgcn_readfirstlane(te.y);
+        const int sig_add = __builtin_amdgcn_readfirstlane(te.z), flags = __builtin_amdgcn_readfirstlane(te.w);
+#ifdef R3D_TIMING
+        if (dbg_arg && threadIdx.x == 0) dbg_arg[16384 + (long long)(t_first_tile + i) * 4 + 0] = wall_clock64();
+#endif
+        const int M = P.M, K = P.K, N = P.N, nk32 = K / BK;
+        const int ldA = K + 8;
+        float *As = smem, *red = smem + GEMV_MAX_M * ldA;
+        const int er = tid >> 5, ecol = col0 + (tid & 31);
+        const bool emit = tid < M * 32 && ecol < N;
+        const float ebias = emit ? gload1(P.bias + ecol) : 0.0f;
+        if (ndep > 0 && !poll) wait_deps(tile, ndep, cnt, abort_flag);
+        {
+            const int e0 = P.kend[0], e1 = P.kend[1], e2 = P.kend[2];
+            const float *a0 = P.a[0], *a1 = P.a[1], *a2 = P.a[2], *a3 = P.a[3];
+            const int l0 = P.lda[0], l1 = P.lda[1], l2 = P.lda[2], l3 = P.lda[3];
+            unsigned spins = 0;
+            long long t_first = 0;
+            for (;;) {
+                bool missing = false;
+                for (int r = 0; r < M; ++r)
+                    for (int k = tid; k < K; k += GEMM_THREADS) {
+                        const float *src = k < e0 ? a0 + (size_t)r * l0 + k : k < e1 ? a1 + (size_t)r * l1 + (k - e0)
+                                         : k < e2 ? a2 + (size_t)r * l2 + (k - e1) : a3 + (size_t)r * l3 + (k - e2);
+                        const float v = act_ld(src);
+                        missing |= act_missing(v);
+                        As[r * ldA + k] = v;
+                    }
+                if (!poll || !__any(missing) || poll_gave_up(spins, t_first, abort_flag)) break;
+            }
+        }
+        float eres = 0.0f;
+        if (emit && P.res) {
+            unsigned spins = 0;
+            long long t_first = 0;
+            do eres = act_ld(P.res + (size_t)er * P.ldr + ecol);
+            while (poll && act_missing(eres) && !poll_gave_up(spins, t_first, abort_flag));
+        }
+        if (i + 1 < n) request(prob_of(i + 1), __builtin_amdgcn_readfirstlane(tl[(i + 1) * TS].z), 0, wnext);
+        __syncthreads();
+#ifdef R3D_TIMING
+        if (dbg_arg && threadIdx.x == 0) dbg_arg[16384 + (long long)(t_first_tile + i) * 4 + 1] = wall_clock64();
+#endif
+        float acc[GEMV_MAX_M];
+#pragma unroll
+        for (int r = 0; r < GEMV_MAX_M; ++r) acc[r] = 0.0f;
+        for (int j0 = 0; wave_u + 8 * j0 < nk32; j0 += 4) {
+            if (j0) request(Pp, col0, j0, wf);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kt = wave_u + 8 * (j0 + j);
+                if (kt >= nk32) break;                                  // (uniform)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < GEMV_MAX_M; ++r) {
+                        const f32x4 a = *reinterpret_cast<const f32x4 *>(As + (r < M ? r : M - 1) * ldA + kt * BK + lh * 16 + q * 4);
+                        acc[r] += a[0] * wf[j][q][0] + a[1] * wf[j][q][1] + a[2] * wf[j][q][2] + a[3] * wf[j][q][3];
+                    }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < GEMV_MAX_M; ++r) {
+            acc[r] += __shfl_xor(acc[r], 32, 64);                       // the two k-halves of the wavefront
+            if (lh == 0) red[(wave * GEMV_MAX_M + r) * 32 + li] = acc[r];
+        }
+        __syncthreads();
+        // (test hook: workgroup 0's n-th tile neither stores nor reports - what the bounded spins are for)
+        const bool faulty = blockIdx.x == 0 && plain_seen++ == fargs->fault_tile1 - 1;
+        if (emit && !faulty) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += red[(w * GEMV_MAX_M + er) * 32 + (tid & 31)];
+            v = lrelu(v + ebias, P.slope) + eres;
+            act_st(P.c + (size_t)er * P.ldc + ecol, v);
+        }
+        if (!(poll && (flags & FWD_TILE_NOSIGNAL))) {
+            tile_drain();
+            __syncthreads();
+            if (!faulty) tile_signal(cnt, sig_base, sig_add, 1);
+        } else {
+            __syncthreads();                                            // the next tile may write LDS
+        }
+#ifdef R3D_TIMING
+        if (dbg_arg && threadIdx.x == 0) {
+            dbg_arg[16384 + (long long)(t_first_tile + i) * 4 + 2] = wall_clock64();
+            dbg_arg[16384 + (long long)(t_first_tile + i) * 4 + 3] = 1;
+        }
+#endif
+    };
+    int i = 0;
+    for (; i + 1 < n; i += 2) {
+        body(i, wa, wb);
+        body(i + 1, wb, wa);
+    }
+    if (i < n) body(i, wa, wb);
+}
+
 template <bool ENC, bool UV, bool DEP = false>
 __device__ __forceinline__ void gemm_persistent(float *smem) {
     LaunchArgsPtr args = (LaunchArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -2183,6 +2379,13 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
         unsigned *nx = fargs->cnt_next;
         if (nx != nullptr)
             for (int j = blockIdx.x * GEMM_THREADS + threadIdx.x; j < fargs->ncnt + 4; j += gridDim.x * GEMM_THREADS) nx[j] = 0u;
+        // ... and the other bank of activations (poll mode): sentinels
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 *arm = reinterpret_cast<u32x4 *>(fargs->arm);
+        if (arm != nullptr) {
+            const u32x4 sv = {ACT_SENTINEL, ACT_SENTINEL, ACT_SENTINEL, ACT_SENTINEL};
+            for (long long j = blockIdx.x * GEMM_THREADS + threadIdx.x; j < fargs->arm_vec4; j += gridDim.x * GEMM_THREADS) arm[j] = sv;
+        }
     }
     long long *dbg = nullptr;
 #ifdef R3D_TIMING
@@ -2204,13 +2407,14 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
         const int row0 = __builtin_amdgcn_readfirstlane(td.y);
         const int col0 = __builtin_amdgcn_readfirstlane(td.z);
         const int ks = __builtin_amdgcn_readfirstlane(td.w);      // split-K factor of this tile (1, 2 or 4)
-        int sig_base = 0, sig_add = 0;
-        TileDeps tdep{nullptr, 0, nullptr, nullptr};
+        int sig_base = 0, sig_add = 0, tflags = 0;
+        TileDeps tdep{nullptr, 0, nullptr, nullptr, false};
         if constexpr (DEP) {
             const int4 te = tiles[t * TS + 1];
             const int ndep = __builtin_amdgcn_readfirstlane(te.x);
             sig_base = __builtin_amdgcn_readfirstlane(te.y);
             sig_add = __builtin_amdgcn_readfirstlane(te.z);
+            tflags = __builtin_amdgcn_readfirstlane(te.w);
 #ifdef R3D_TIMING
             if (dbg_arg && threadIdx.x == 0) dbg_arg[16384 + (long long)t * 4 + 0] = wall_clock64();      // tile fetched
 #endif
@@ -2219,7 +2423,7 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
 #ifdef R3D_TIMING
             if (dbg_arg && threadIdx.x == 0) dbg_arg[16384 + (long long)t * 4 + 1] = wall_clock64();      // producers ready
 #endif
-            tdep = TileDeps{tiles + t * TS, ks >= 8 ? ndep : 0, cnt, abort_flag};
+            tdep = TileDeps{tiles + t * TS, ks >= 8 ? ndep : 0, cnt, abort_flag, fargs->poll != 0};
         }
         ProbRef P = DEP ? *((const GemmProb __attribute__((address_space(4))) *)fargs->probs + pi) : args->p[pi];
 #ifdef R3D_TIMING
@@ -2293,6 +2497,19 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                 break;
             }
             if (ks == 8) {               // a problem of a few rows: one 32-column block, K split over the wavefronts, no MFMA
+                if constexpr (DEP) {     // ... this workgroup's consecutive tiles of the kind as one run (weights requested a tile ahead)
+                    int n = 1;
+                    while (t + n < t1 && __builtin_amdgcn_readfirstlane(tiles[(t + n) * TS].w) == 8) ++n;
+#ifdef R3D_TIMING
+                    long long *run_dbg_arg = dbg_arg;
+#else
+                    long long *run_dbg_arg = nullptr;
+#endif
+                    gemv_run(fargs, tiles + t * TS, TS, n, smem, cnt, abort_flag, plain_seen, run_dbg_arg, t);
+                    t += n - 1;
+                    signalled = true;
+                    break;
+                }
                 gemv_tile(P, col0, smem, tdep);
                 break;
             }
@@ -2326,6 +2543,7 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
         }
         } while (false);
         if constexpr (DEP) {
+            if (!signalled && fargs->poll != 0 && (tflags & FWD_TILE_NOSIGNAL)) signalled = true;   // (a latency tile nobody counts on)
             if (!signalled) {            // (the tile functions end on a barrier: drain, one more barrier, raise the counters)
                 tile_drain();
                 __syncthreads();
@@ -2381,6 +2599,11 @@ extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_forward_uv_f32(co
 extern "C" __global__ __launch_bounds__(256) void r3d_bind_f32(const BindArgs b) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, total = gridDim.x * blockDim.x;
     for (int j = i; j < b.ncnt + 4; j += total) b.cnt[j] = 0u;
+    if (b.arm != nullptr) {          // poll mode: every activation of the call's bank(s) starts as "not there yet"
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 sv = {ACT_SENTINEL, ACT_SENTINEL, ACT_SENTINEL, ACT_SENTINEL};
+        for (long long j = i; j < b.arm_vec4; j += total) reinterpret_cast<u32x4 *>(b.arm)[j] = sv;
+    }
     if (i >= b.nprob) return;
     GemmProb g = b.rel[i];
     const unsigned char *tg = b.tags + (size_t)i * BIND_NPTR;
@@ -2458,7 +2681,7 @@ hipError_t launch_forward(const FwdArgs &args, int nwg, bool uv, hipStream_t str
 }
 
 hipError_t launch_bind(const BindArgs &args, hipStream_t stream) {
-    const int threads = std::max(args.nprob, std::min(args.ncnt + 4, 64 * 256));
+    const int threads = std::max(args.nprob, std::min((int)std::max<long long>(args.ncnt + 4, args.arm ? args.arm_vec4 : 0), 256 * 256));
     r3d_bind_f32<<<dim3((threads + 255) / 256), dim3(256), 0, stream>>>(args);
     return hipGetLastError();
 }

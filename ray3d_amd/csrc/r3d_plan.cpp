@@ -37,6 +37,9 @@ struct Builder {
     bool enc_in_gemm = false;    // gathered first layers as enc_tile problems of r3d_gemm_f32 (not r3d_gemm_enc_f32): calls of few windows,
                                  // where the second kernel's two-workgroups-per-CU overlap buys nothing and a launch of its own shape
                                  // would keep the call out of the single-launch form
+    bool single_assign = false;  // no buffer element is written twice in a call (the plan of calls of few windows: their GEMV /
+                                 // latency tiles may take data as its own ready flag - r3d_kernels.hip, ACT_SENTINEL - which a
+                                 // stale value from earlier in the call would defeat)
     bool fuse_pairs = true;
     bool fuse_top = false;       // the top pyramid level (one row per window) as a fused pair too
     struct In { int buf, col, ld, width, dep; };
@@ -85,13 +88,17 @@ struct Builder {
     int fc_block(const std::string &prefix, const std::vector<In> &ins, int nblocks, int c_buf, int c_col, int c_ld,
                  int enc_lut = -1, int enc_lut_uv = -1) {
         const int H = MLP_HIDDEN;
-        const int h = buffer(prefix + ".h", H), y = buffer(prefix + ".y", H);
+        int h = buffer(prefix + ".h", H), y = buffer(prefix + ".y", H);
         int last = problem(prefix + ".fc_1", 1, ins, -1, 0, 0, h, 0, H, {}, enc_lut, enc_lut_uv);
         for (int n = 0; n < nblocks; ++n) {
             const std::string q = prefix + ".layers." + std::to_string(n);
+            if (single_assign && n > 0) y = buffer(prefix + ".y" + std::to_string(n), H);
             const int p1 = problem(q + ".w1", 1, {{h, 0, H, H, last}}, -1, 0, 0, y, 0, H);
-            // out = x + lrelu(bn(w2 y))  (rie.py:122-135): residual = h, written in place
-            last = problem(q + ".w2", 1, {{y, 0, H, H, p1}}, h, 0, H, h, 0, H, {last});
+            // out = x + lrelu(bn(w2 y))  (rie.py:122-135): residual = h, written in place - or, where every element of a
+            // call's activations must be written exactly once (single_assign), into a buffer of its own
+            const int hn = single_assign ? buffer(prefix + ".h" + std::to_string(n + 1), H) : h;
+            last = problem(q + ".w2", 1, {{y, 0, H, H, p1}}, h, 0, H, hn, 0, H, {last});
+            h = hn;
         }
         if (c_buf < 0) {
             p.decs.push_back({mi, m.layer_index.at(prefix + ".fc_2"), h});
@@ -231,6 +238,7 @@ static Plan *build_plan(const Model *a, const Model *b, int kind) {
                 if (mm) all = all && can_fuse(mm);
             B.first_level_fused = all && !small && !env_on("R3D_NO_FIRST_FUSE");
             B.enc_in_gemm = small && !env_on("R3D_SMALL_ENC_KERNEL");
+            B.single_assign = small;
             B.fuse_pairs = (kind == PLAN_FUSED || kind == PLAN_LARGE) && !env_on("R3D_NO_PAIR_FUSE");
             B.fuse_top = kind == PLAN_LARGE;
         }

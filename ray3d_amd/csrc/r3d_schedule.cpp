@@ -29,6 +29,7 @@ Schedule::~Schedule() {
     if (fwd.d_tiles) (void)hipFree(fwd.d_tiles);
     if (fwd.d_wgoff) (void)hipFree(fwd.d_wgoff);
     if (fwd.d_ctrl) (void)hipFree(fwd.d_ctrl);
+    if (fwd.d_act) (void)hipFree(fwd.d_act);
     for (int i = 0; i < 2; ++i) {
         if (fwd.d_rel[i]) (void)hipFree(fwd.d_rel[i]);
         if (fwd.d_tags[i]) (void)hipFree(fwd.d_tags[i]);
@@ -103,6 +104,17 @@ bool schedule_build_fwd(const Plan *pl, int64_t B, int nwg, const std::vector<st
         if (q.enc_lut >= 0) fw.uses_gather = true;
     }
     fw.ncnt = ncnt;
+    // problems that run as GEMV / latency tiles, and the problems all of whose consumers do (or that only the decoder kernel
+    // reads): in poll mode nobody waits for their ready counters, and their tiles carry FWD_TILE_NOSIGNAL (descriptor int 7)
+    std::vector<char> narrow(np, 0), quiet(np, 1);
+    for (size_t si = 0; si < stages.size(); ++si)
+        for (int t = 0; t < stages[si].ntiles; ++t) {
+            const int4 &tl = tiles[stages[si].tiles_off + t];
+            if (tl.w >= 8) narrow[levels[si][tl.x & 0xff] & ~STAGE_SPILL_IN] = 1;
+        }
+    for (int i = 0; i < np; ++i)
+        for (int dp : pl->probs[i].deps)
+            if (!narrow[i]) quiet[dp] = 0;
     std::vector<std::vector<int>> lists(nwg);     // per workgroup: tile descriptors, 24 ints each
     fw.flops = fw.bytes = 0;
     for (size_t si = 0; si < stages.size(); ++si) {
@@ -150,6 +162,7 @@ bool schedule_build_fwd(const Plan *pl, int64_t B, int nwg, const std::vector<st
                     ++nd;
                 }
                 d[4] = nd;
+                d[7] = ks >= 8 && quiet[id] ? 1 : 0;
                 lists[b].insert(lists[b].end(), d, d + FWD_TILE_INT4 * 4);
             }
         }
@@ -751,7 +764,14 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
             fw.h_wgoff = fo;
             if (ok) {                  // the library-owned control region (Schedule::Fwd::d_ctrl): two counter banks + the bound table
                 fw.bank_bytes = ((size_t)(fw.ncnt + 4) * sizeof(unsigned) + 255) / 256 * 256;
-                ok = (e = hipMalloc((void **)&fw.d_ctrl, 2 * fw.bank_bytes + (size_t)fw.nprob * sizeof(GemmProb))) == hipSuccess;
+                ok = (e = hipMalloc((void **)&fw.d_ctrl, 2 * fw.bank_bytes + 2 * (size_t)fw.nprob * sizeof(GemmProb))) == hipSuccess;
+            }
+            bool narrow = false;       // GEMV / latency tiles in the lists: activation banks of the library's own (poll mode)
+            for (size_t t = 0; t * FWD_TILE_INT4 * 4 < ft.size(); ++t) narrow |= ft[t * FWD_TILE_INT4 * 4 + 3] >= 8;
+            // (up to 16 windows: at 32 the sentinel fill of a 10 MB bank costs more than the hops save - 0.219 against 0.213 ms)
+            if (ok && narrow && pl->kind == PLAN_SMALL && B <= 16 && !env_on("R3D_NO_POLL")) {     // (that plan writes no activation twice: r3d_plan.cpp, single_assign)
+                fw.act_bytes = (((size_t)pl->floats_per_window * (size_t)B + (size_t)pl->tail_floats + 64) * sizeof(float) + 255) / 256 * 256;
+                ok = (e = hipMalloc((void **)&fw.d_act, 2 * fw.act_bytes)) == hipSuccess;
             }
             if (!ok) {
                 hip_fail(e, "schedule upload (single-launch form)");
