@@ -128,7 +128,12 @@ typedef struct {
 
 /* Bytes of scratch HBM that suffice for every forward of AT MOST B windows (either model may be NULL): the maximum over
  * the launch plans calls of 1..B windows can select (small calls run less fused plans with larger intermediates), so a
- * caller may size its workspace once for its largest batch. */
+ * caller may size its workspace once for its largest batch.
+ * The workspace is scratch: nothing in it has to survive between calls, and the caller may use it for something else
+ * between them.  (What a forward needs ACROSS calls - the ready counters and the bound problem table of the single-launch
+ * forward, and for calls of <= 16 windows two banks of activations - lives in device memory the library owns, per
+ * cached batch size; a forward that is being captured into a hipGraph keeps all of it inside the workspace instead, so
+ * a graph's workspace must stay allocated, and untouched by other work while the graph runs, as any captured buffer.) */
 size_t r3d_workspace_bytes(const r3d_model *pos, const r3d_model *trj, int64_t B);
 
 /* Everything a forward of B windows needs besides its arguments - the launch plan of the pair and the tile schedule

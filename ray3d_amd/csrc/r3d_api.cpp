@@ -790,7 +790,8 @@ int r3d_debug_plan_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg,
 // run (no waiting cycle), every counter must end full, and - independently of the dependency ranges the scheduler wrote -
 // at the moment a tile runs, every earlier problem that writes what the tile reads, or reads / writes what the tile
 // writes (same buffer, overlapping columns), must be complete for the tile's windows.
-// Returns 0 (or 1: this plan runs launch by launch, nothing to check), or a negative code.
+// Returns 0 (or 1: this plan runs launch by launch, nothing to check), or a negative code.  For the plan of calls of a few
+// windows also: every workspace element is written exactly once per call (what poll mode relies on).
 int r3d_debug_forward_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg, int *out_tiles, int *out_counters) {
     Model *a = reinterpret_cast<Model *>(pos ? pos : trj), *b = reinterpret_cast<Model *>(pos && trj ? trj : nullptr);
     if (!a) return -1;
@@ -831,6 +832,32 @@ int r3d_debug_forward_check(r3d_model *pos, r3d_model *trj, int64_t batch, int n
             if (cnt[fw.cnt_base[prob] + u] != (unsigned)gcols[prob]) return false;
         return true;
     };
+    if (pl->kind == PLAN_SMALL) {
+        // Calls of a few windows may take data as its own ready flag (poll mode): no element of a workspace buffer may then
+        // be written twice in a call (a stale value would pass for data), and everything a problem reads from the workspace
+        // must be written by some problem (a sentinel nobody replaces would be waited for until the spins give up).
+        for (int i = 0; i < np; ++i)
+            for (int o = 0; o < i; ++o)
+                if (overlap(writes(pl->probs[i]), writes(pl->probs[o]))) return -25;
+        // (column-exact where reader and writer see the buffer with the same row geometry - the MLPs' concatenations; a
+        // pyramid level reads three of its producer's rows as one, there only "somebody writes this buffer" is checked)
+        for (int i = 0; i < np; ++i)
+            for (const Acc &rd : reads(pl->probs[i])) {
+                std::vector<char> covered(rd.c1 - rd.c0, 0);
+                bool any = false, same_rows = true;
+                for (int o = 0; o < np; ++o) {
+                    const Acc w = writes(pl->probs[o]);
+                    if (w.buf != rd.buf) continue;
+                    any = true;
+                    same_rows = same_rows && pl->probs[o].rows_per_window == pl->probs[i].rows_per_window;
+                    for (int c = std::max(w.c0, rd.c0); c < std::min(w.c1, rd.c1); ++c) covered[c - rd.c0] = 1;
+                }
+                if (!any) return -26;
+                if (same_rows)
+                    for (char c : covered)
+                        if (!c) return -26;
+            }
+    }
     std::vector<int> next(fw.grid);
     for (int w = 0; w < fw.grid; ++w) next[w] = fo[w];
     int done = 0;

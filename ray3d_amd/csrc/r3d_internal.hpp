@@ -103,7 +103,8 @@ struct FwdArgs {
     int poll;                 // GEMV / latency tiles read their operands until no ACT_SENTINEL is left instead of waiting for counters
     void *arm;                // the other bank of activations: filled with sentinels by this launch, for the next call (or nullptr)
     long long arm_vec4;       // ... its size in 16-byte units
-    int fault_tile1;          // test hook (R3D_FAULT_TILE=<n>): workgroup 0's n-th tile behind the first level never raises its counters (0: none; n + 1 stored)
+    int fault_tile1;          // test hook (R3D_FAULT_TILE=<n>): workgroup 0's n-th tile behind the first level never raises its counters, and
+                              // its n-th GEMV tile neither stores nor reports (0: none; n + 1 stored)
     long long *dbg;
 };
 constexpr int BIND_NPTR = 18;  // pointer fields of a GemmProb, in the order r3d_bind_f32 walks them

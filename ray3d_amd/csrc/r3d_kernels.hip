@@ -2228,7 +2228,7 @@ __device__ __forceinline__ void wait_deps(const int4 *tile, const int ndep, cons
 // counter update.
 constexpr int FWD_TILE_NOSIGNAL = 1;      // descriptor int 7, bit 0 (r3d_schedule.cpp)
 __device__ __forceinline__ void gemv_run(FwdArgsPtr fargs, const int4 *tl, const int TS, const int n, float *smem, const gu32 cnt,
-                                         const gu32 abort_flag, int &plain_seen, long long *dbg_arg, const int t_first_tile) {
+                                         const gu32 abort_flag, int &gemv_seen, long long *dbg_arg, const int t_first_tile) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -2324,7 +2324,7 @@ __device__ __forceinline__ void gemv_run(FwdArgsPtr fargs, const int4 *tl, const
         }
         __syncthreads();
         // (test hook: workgroup 0's n-th tile neither stores nor reports - what the bounded spins are for)
-        const bool faulty = blockIdx.x == 0 && plain_seen++ == fargs->fault_tile1 - 1;
+        const bool faulty = blockIdx.x == 0 && gemv_seen++ == fargs->fault_tile1 - 1;
         if (emit && !faulty) {
             float v = 0.0f;
 #pragma unroll
@@ -2397,7 +2397,7 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
     }
 #endif
     int prev_pi = -1;
-    int plain_seen = 0;
+    int plain_seen = 0, gemv_seen = 0;       // (test hook: this workgroup's tiles so far, per kind)
     for (int t = t0; t < t1; ++t) {
         const int4 td = tiles[t * TS];
         const int pi = __builtin_amdgcn_readfirstlane(td.x & 0xff);
@@ -2505,7 +2505,7 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
 #else
                     long long *run_dbg_arg = nullptr;
 #endif
-                    gemv_run(fargs, tiles + t * TS, TS, n, smem, cnt, abort_flag, plain_seen, run_dbg_arg, t);
+                    gemv_run(fargs, tiles + t * TS, TS, n, smem, cnt, abort_flag, gemv_seen, run_dbg_arg, t);
                     t += n - 1;
                     signalled = true;
                     break;

@@ -591,12 +591,14 @@ def test_single_launch_forward_is_a_sound_dependency_machine():
     ordered by ready counters instead of kernel boundaries.  r3d_debug_forward_check builds those lists and executes
     them on the host: every tile gets to run (no waiting cycle with all workgroups resident), every counter ends full,
     and - independently of the dependency ranges the scheduler wrote - whenever a tile runs, every earlier problem that
-    writes what it reads or touches what it writes (same buffer, overlapping columns) is complete for its windows."""
+    writes what it reads or touches what it writes (same buffer, overlapping columns) is complete for its windows.  For the
+    plan of calls of <= 48 windows it also checks that no workspace element is written twice in a call and that every
+    element read is written - what the GEMV / latency tiles' "data as its own ready flag" mode relies on."""
     lib = _capi.load()
     fn = lib.r3d_debug_forward_check
     fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     fn.restype = ctypes.c_int
-    cases = [(default_model_config(ARCHITECTURE="3,3,3,3,3"), (1, 64, 97, 128, 255, 256, 257, 600, 1024, 2048)),
+    cases = [(default_model_config(ARCHITECTURE="3,3,3,3,3"), (1, 2, 4, 5, 16, 33, 48, 64, 97, 128, 255, 256, 257, 600, 1024, 2048)),
              (default_model_config(ARCHITECTURE="3,3"), (64, 256, 1024, 4096)),
              (default_model_config(ARCHITECTURE="3,3", NUM_KPTS=14), (512, 4096)),
              (default_model_config(ARCHITECTURE="3,3,3", STAGE=1, CAMERA_EMBDDING=False), (100, 300)),
