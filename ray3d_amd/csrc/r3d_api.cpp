@@ -554,7 +554,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         dec_flops += 2.0 * (double)B * L.K * L.N;
     }
     if (da.has_pos) output_slots(da.J, firsts, da.slot);
-    if ((e = rec.begin("r3d_decode_f32", stage_no, 0, dec_flops, (double)B * da.nsrc * MLP_HIDDEN * 4.0)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+    if ((e = rec.begin(B >= 128 ? "r3d_decode_w4_f32" : "r3d_decode_f32", stage_no, 0, dec_flops, (double)B * da.nsrc * MLP_HIDDEN * 4.0)) != hipSuccess) return hip_fail(e, "hipEventRecord");
     if ((e = launch_decode(da, stream)) != hipSuccess) return hip_fail(e, "launch r3d_decode_f32");
     if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
     if (rec.on()) a->nrec = (int)rec.n;

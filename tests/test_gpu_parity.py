@@ -1155,6 +1155,8 @@ def test_a_tile_that_never_reports_ends_in_nan_not_in_a_hang(monkeypatch):
     import time
     import ray3d_amd
     from ray3d_amd import synth
+    if os.environ.get("R3D_STAGED") == "1":
+        pytest.skip("one launch per level: stream order, no ready counters to miss")
     mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
     pos, trj, (cp, sp), (ct, st) = build_modules(mc)
     lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
