@@ -1232,6 +1232,39 @@ def test_calls_of_a_few_windows_take_data_as_its_own_ready_flag(B, monkeypatch):
     assert torch.equal(again, first)
 
 
+@pytest.mark.parametrize("B", [3, 200])
+def test_two_streams_share_a_lifter(B):
+    """Eager calls of one batch size share the schedule's control region (and, for a few windows, its activation banks)
+    whatever stream they are on; the library orders single-launch forwards of different streams with an event, a call
+    that finds the table bound to other buffers binds again behind that event.  Two streams taking turns on one lifter
+    with different inputs, nothing synchronised in between, get what each gets alone."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
+    pos, trj, (cp, _), _ = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    xa = torch.from_numpy(synth.synth_rays(B, cp, seed=401)).cuda()
+    xb = torch.from_numpy(synth.synth_rays(B, cp, seed=402)).cuda()
+    p = torch.from_numpy(synth.synth_param(B, seed=403)).cuda()
+    with torch.no_grad():
+        ra, rb = lifter(xa, p), lifter(xb, p)
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for it in range(8):
+            with torch.cuda.stream(s1):
+                oa = lifter(xa, p)
+            with torch.cuda.stream(s2):
+                ob = lifter(xb, p)
+                if it % 3 == 2:
+                    ob2 = lifter(xb, p)                      # (the same stream and buffers twice in a row: no bind)
+                    outs.append((ob2, rb))
+            outs += [(oa, ra), (ob, rb)]
+        torch.cuda.synchronize()
+    for got, want in outs:
+        assert torch.equal(got, want)
+
+
 def test_pos_and_trj_with_different_channel_counts():
     """CHANNELS may differ between the two networks (separate model_configs in the reference): one of them fusable
     (<= 256 channels), the other not - the pair then runs the un-fused first level for both (r3d_plan.cpp) instead of
