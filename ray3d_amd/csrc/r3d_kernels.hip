@@ -2304,17 +2304,21 @@ __device__ __forceinline__ void gemv_run(FwdArgsPtr fargs, const int4 *tl, const
         for (int r = 0; r < GEMV_MAX_M; ++r) acc[r] = 0.0f;
         for (int j0 = 0; wave_u + 8 * j0 < nk32; j0 += 4) {
             if (j0) request(Pp, col0, j0, wf);
+            // (row by row, and only the rows there are: one window reads and multiplies a quarter of what four do - 0.098 against
+            //  0.108 ms at one window, 0.116 against 0.124 at two, 0.147 against 0.143 at four; two accumulator chains per row: the same)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int kt = wave_u + 8 * (j0 + j);
-                if (kt >= nk32) break;                                  // (uniform)
+            for (int r = 0; r < GEMV_MAX_M; ++r) {
+                if (r >= M) break;                                      // (uniform)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int j = 0; j < 4; ++j) {
+                    const int kt = wave_u + 8 * (j0 + j);
+                    if (kt >= nk32) break;                              // (uniform)
 #pragma unroll
-                    for (int r = 0; r < GEMV_MAX_M; ++r) {
-                        const f32x4 a = *reinterpret_cast<const f32x4 *>(As + (r < M ? r : M - 1) * ldA + kt * BK + lh * 16 + q * 4);
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 a = *reinterpret_cast<const f32x4 *>(As + r * ldA + kt * BK + lh * 16 + q * 4);
                         acc[r] += a[0] * wf[j][q][0] + a[1] * wf[j][q][1] + a[2] * wf[j][q][2] + a[3] * wf[j][q][3];
                     }
+                }
             }
         }
 #pragma unroll
@@ -2543,7 +2547,15 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
         }
         } while (false);
         if constexpr (DEP) {
-            if (!signalled && fargs->poll != 0 && (tflags & FWD_TILE_NOSIGNAL)) signalled = true;   // (a latency tile nobody counts on)
+            if (!signalled && fargs->poll != 0 && (tflags & FWD_TILE_NOSIGNAL)) {   // (a latency tile nobody counts on)
+                signalled = true;
+#ifdef R3D_TIMING
+                if (dbg_arg && threadIdx.x == 0) {
+                    dbg_arg[16384 + (long long)t * 4 + 2] = wall_clock64();
+                    dbg_arg[16384 + (long long)t * 4 + 3] = 1;
+                }
+#endif
+            }
             if (!signalled) {            // (the tile functions end on a barrier: drain, one more barrier, raise the counters)
                 tile_drain();
                 __syncthreads();
