@@ -2122,6 +2122,16 @@ __device__ __forceinline__ void lat_tile(ProbRef P, const int col0, float *smem,
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     load_w_round(0);
+    // the epilogue's bias: requested now, used after the reduction (this thread's two outputs: r3d of the two passes below)
+    float ebias[2], eres[2] = {0.0f, 0.0f};
+    int erow[2], ecol[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int idx = tid + h * GEMM_THREADS, r = idx >> 6, ln = idx & 63;
+        erow[h] = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        ecol[h] = col0 + (ln & 31);
+        ebias[h] = erow[h] < M && ecol[h] < N ? gload1(P.bias + ecol[h]) : 0.0f;
+    }
     if (dep.ndep > 0 && !dep.poll) wait_deps(dep.tile, dep.ndep, dep.cnt, dep.abort_flag);
     unsigned spins = 0;
     long long t_first = 0;
@@ -2139,13 +2149,21 @@ __device__ __forceinline__ void lat_tile(ProbRef P, const int col0, float *smem,
                     for (int kk = 0; kk < 4; ++kk) missing |= act_missing(af[j][q][kk]);
             if (!__any(missing) || poll_gave_up(spins, t_first, dep.abort_flag)) break;
         }
+        if (j0 == 0 && P.res) {                                     // the residual: on its way while the matrix cores work (checked below)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int h = 0; h < 2; ++h)
+                if (erow[h] < M && ecol[h] < N) eres[h] = act_ld(P.res + (size_t)erow[h] * P.ldr + ecol[h]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (wave_u + 8 * (j0 + j) >= nk32) break;               // (uniform; a 256-deep layer is ONE K tile per wavefront, not four - three
+                                                                    //  quarters of that tile's matrix time went into zeros)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][q][kk], wf[j][q][kk], acc, 0, 0, 0);   // (K tiles past the end: zero weights)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][q][kk], wf[j][q][kk], acc, 0, 0, 0);
+        }
     }
     float *red = smem;                                             // [wave][register][lane]
 #pragma unroll
@@ -2157,15 +2175,14 @@ __device__ __forceinline__ void lat_tile(ProbRef P, const int col0, float *smem,
         float v = 0.0f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) v += red[(w * 16 + r) * 64 + ln];
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), col = col0 + (ln & 31);
+        const int row = erow[h], col = ecol[h];
         if (row < M && col < N) {
-            v = lrelu(v + gload1(P.bias + col), P.slope);
+            v = lrelu(v + ebias[h], P.slope);
             if (P.res) {
-                float rv;
+                float rv = eres[h];
                 unsigned rspins = 0;
                 long long rt = 0;
-                do rv = act_ld(P.res + (size_t)row * P.ldr + col);
-                while (dep.poll && act_missing(rv) && !poll_gave_up(rspins, rt, dep.abort_flag));
+                while (dep.poll && act_missing(rv) && !poll_gave_up(rspins, rt, dep.abort_flag)) rv = act_ld(P.res + (size_t)row * P.ldr + col);
                 v += rv;
             }
             act_st(P.c + (size_t)row * P.ldc + col, v);
