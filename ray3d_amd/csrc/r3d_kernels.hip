@@ -1963,7 +1963,7 @@ constexpr int GEMV_MAX_M = 4;
 __device__ __forceinline__ void wait_deps(const int4 *tile, const int ndep, const gu32 cnt, const gu32 abort_flag);
 // (single-launch form: these tiles wait for their producers themselves - BEHIND their weight requests, which depend on no
 //  producer: in a call of a few windows a layer is one memory round trip, and the wait for the previous layer hides it)
-struct TileDeps { const int4 *tile; int ndep; gu32 cnt, abort_flag; bool poll; };
+struct TileDeps { const int4 *tile; int ndep; gu32 cnt, abort_flag; bool poll; long long *tstamp; };   // (tstamp: -DR3D_TIMING builds, this tile's four stamps)
 __device__ __forceinline__ float act_ld(const float *p) {
     return __builtin_bit_cast(float, __hip_atomic_load((gu32)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // 4-byte sc1 load
 }
@@ -2149,6 +2149,9 @@ __device__ __forceinline__ void lat_tile(ProbRef P, const int col0, float *smem,
                     for (int kk = 0; kk < 4; ++kk) missing |= act_missing(af[j][q][kk]);
             if (!__any(missing) || poll_gave_up(spins, t_first, dep.abort_flag)) break;
         }
+#ifdef R3D_TIMING
+        if (j0 == 0 && dep.tstamp && threadIdx.x == 0) dep.tstamp[1] = wall_clock64();      // (this wavefront's first operand round has arrived)
+#endif
         if (j0 == 0 && P.res) {                                     // the residual: on its way while the matrix cores work (checked below)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -2429,7 +2432,7 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
         const int col0 = __builtin_amdgcn_readfirstlane(td.z);
         const int ks = __builtin_amdgcn_readfirstlane(td.w);      // split-K factor of this tile (1, 2 or 4)
         int sig_base = 0, sig_add = 0, tflags = 0;
-        TileDeps tdep{nullptr, 0, nullptr, nullptr, false};
+        TileDeps tdep{nullptr, 0, nullptr, nullptr, false, nullptr};
         if constexpr (DEP) {
             const int4 te = tiles[t * TS + 1];
             const int ndep = __builtin_amdgcn_readfirstlane(te.x);
@@ -2444,7 +2447,10 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
 #ifdef R3D_TIMING
             if (dbg_arg && threadIdx.x == 0) dbg_arg[16384 + (long long)t * 4 + 1] = wall_clock64();      // producers ready
 #endif
-            tdep = TileDeps{tiles + t * TS, ks >= 8 ? ndep : 0, cnt, abort_flag, fargs->poll != 0};
+            tdep = TileDeps{tiles + t * TS, ks >= 8 ? ndep : 0, cnt, abort_flag, fargs->poll != 0, nullptr};
+#ifdef R3D_TIMING
+            if (dbg_arg) tdep.tstamp = dbg_arg + 16384 + (long long)t * 4;
+#endif
         }
         ProbRef P = DEP ? *((const GemmProb __attribute__((address_space(4))) *)fargs->probs + pi) : args->p[pi];
 #ifdef R3D_TIMING

@@ -162,7 +162,7 @@ bool schedule_build_fwd(const Plan *pl, int64_t B, int nwg, const std::vector<st
                     ++nd;
                 }
                 d[4] = nd;
-                d[7] = ks >= 8 && quiet[id] ? 1 : 0;
+                d[7] = quiet[id] ? 1 : 0;              // (any kind of tile: a first-layer tile whose consumers all poll needs no drain either)
                 lists[b].insert(lists[b].end(), d, d + FWD_TILE_INT4 * 4);
             }
         }
