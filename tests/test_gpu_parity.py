@@ -1240,6 +1240,8 @@ def test_two_streams_share_a_lifter(B):
     with different inputs, nothing synchronised in between, get what each gets alone."""
     import ray3d_amd
     from ray3d_amd import synth
+    if os.environ.get("R3D_STAGED") == "1":
+        pytest.skip("launch by launch nothing orders two streams: they need a lifter (a workspace) each")
     mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
     pos, trj, (cp, _), _ = build_modules(mc)
     lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
