@@ -35,13 +35,14 @@ extern "C" {
 #define R3D_ERR_STATE (-4)      /* call order violated (e.g. forward before finalize)    */
 #define R3D_ERR_HIP (-5)        /* a HIP runtime call failed                             */
 #define R3D_ERR_WORKSPACE (-6)  /* workspace too small                                   */
+#define R3D_ERR_ABORTED (-7)    /* r3d_status: a forward gave up waiting for its own tiles: its outputs are NaN */
 
 #define R3D_KIND_POS 0 /* lib/model/rie.py:172  RIEModel            -> (B,1,J,3) */
 #define R3D_KIND_TRJ 1 /* lib/model/rie.py:437  RIETrajectoryModel  -> (B,1,1,3) */
 
 /* Mirrors the constructor arguments the reference factory passes
  * (lib/model/__init__.py:23-46 -> lib/model/rie.py:178-181 / :443-446). */
-#define R3D_ABI_VERSION 3 /* bumped whenever a struct below changes size or layout: r3d_abi_version() returns the
+#define R3D_ABI_VERSION 4 /* bumped whenever a struct below changes size or layout: r3d_abi_version() returns the
                            * library's; a binding compares it with the header it was written against       */
 
 typedef struct {
@@ -158,6 +159,22 @@ int r3d_forward(r3d_model *m, const r3d_input *in, int64_t B, float *out_dev,
 int r3d_forward_pair(r3d_model *pos, r3d_model *trj, const r3d_input *in, int64_t B,
                      float *out_dev, float *out_trj_dev, void *workspace_dev,
                      size_t workspace_bytes, void *hip_stream);
+
+/* ---- errors of a forward that surface on the device; per-handle options ---- */
+
+/* The reference's seam reports errors as Python exceptions.  A forward is asynchronous, so what can only
+ * be found out on the device is reported here: r3d_status synchronises `hip_stream` and returns R3D_ERR_ABORTED when a
+ * forward of this handle (for a pair: ask the pos handle) since the last call gave up waiting for its own tiles - the
+ * single-launch forward needs all its workgroups resident, which another process's persistent kernel on the same GPU or
+ * a CU mask can prevent; such a forward ends after the spin timeout with NaN outputs, never hangs.  The flag is cleared
+ * by the call.  Remedy: R3D_OPT_STAGED (the Python mirror's checked entry points do exactly that, once, before raising). */
+int r3d_status(r3d_model *m, void *hip_stream);
+
+#define R3D_OPT_STAGED 1          /* value != 0: this handle's forwards run as one launch per level of the network (no
+                                   * co-residency assumption; a few percent slower) instead of one persistent launch    */
+#define R3D_OPT_SPIN_TIMEOUT_MS 2 /* how long a tile of the single-launch forward waits for its producers before the
+                                   * forward gives up (default 1000)                                                    */
+int r3d_set_option(r3d_model *m, int32_t option, int64_t value);
 
 /* ---- instrumentation (bench.py / tests) ---- */
 

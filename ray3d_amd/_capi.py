@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libray3d_hip.so")
 
 R3D_KIND_POS, R3D_KIND_TRJ = 0, 1
 R3D_INPUT_RAYS, R3D_INPUT_UV = 0, 1
+R3D_ERR_ABORTED = -7
+R3D_OPT_STAGED, R3D_OPT_SPIN_TIMEOUT_MS = 1, 2
 
 # every symbol include/ray3d_hip.h declares (tests check the library exports exactly these)
 EXPORTS = (
@@ -21,9 +23,9 @@ EXPORTS = (
     "r3d_set_weight", "r3d_finalize", "r3d_workspace_bytes", "r3d_forward", "r3d_forward_pair",
     "r3d_profile_enable", "r3d_profile_read", "r3d_clip_metrics", "r3d_last_error", "r3d_version",
     "r3d_prepare", "r3d_release", "r3d_abi_version", "r3d_precision", "r3d_debug_schedule_check", "r3d_debug_plan_check",
-    "r3d_debug_forward_check",
+    "r3d_debug_forward_check", "r3d_status", "r3d_set_option",
 )
-ABI_VERSION = 3                                                          # R3D_ABI_VERSION of the header this binding follows
+ABI_VERSION = 4                                                          # R3D_ABI_VERSION of the header this binding follows
 METRIC_NAMES = ("mpjpe", "p_mpjpe", "n_mpjpe", "velocity", "root")     # R3D_METRIC_* order
 METRIC_OUT_DOUBLES = 5 * (1 + 128)                                      # R3D_METRIC_OUT_DOUBLES
 
@@ -78,6 +80,8 @@ def load():
     lib.r3d_prepare.argtypes = [vp, vp, C.c_int64]
     lib.r3d_release.argtypes = [vp, vp, C.c_int64]
     lib.r3d_precision.argtypes = [vp]
+    lib.r3d_status.argtypes = [vp, vp]
+    lib.r3d_set_option.argtypes = [vp, C.c_int32, C.c_int64]
     lib.r3d_profile_enable.argtypes = [vp, C.c_int]
     lib.r3d_profile_read.argtypes = [vp, C.POINTER(LaunchRecord), C.c_int]
     lib.r3d_clip_metrics.argtypes = [vp, vp, C.c_int64, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp, vp]
@@ -135,6 +139,18 @@ class Handle:
     def precision(self) -> str:
         """'f32' or 'bf16x3': what the handle's large GEMMs run in (r3d_config.bf16x3 or the R3D_BF16X3 override)."""
         return "bf16x3" if check(load().r3d_precision(self.ptr), "r3d_precision") == 1 else "f32"
+
+    def set_option(self, option: int, value: int):
+        check(load().r3d_set_option(self.ptr, option, value), "r3d_set_option")
+
+    def status(self, stream: int) -> bool:
+        """r3d_status: synchronises `stream`; True when every forward of this handle since the last call finished, False
+        when one gave up waiting for its own tiles (outputs NaN; the flag is cleared)."""
+        rc = load().r3d_status(self.ptr, stream)
+        if rc == R3D_ERR_ABORTED:
+            return False
+        check(rc, "r3d_status")
+        return True
 
     def profile_enable(self, on: bool):
         check(load().r3d_profile_enable(self.ptr, 1 if on else 0), "r3d_profile_enable")

@@ -289,7 +289,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
     Schedule *sched = schedule_get(pl, B, device_cu_count());
     if (!sched) return R3D_ERR_HIP;
     const unsigned *abort_flag = nullptr;
-    const bool single = forward_single_launch() && sched->fwd.grid > 0 && !(uv && !sched->fwd.d_rel[1]);
+    const bool single = forward_single_launch() && !a->opt_staged && !(b && b->opt_staged) && sched->fwd.grid > 0 && !(uv && !sched->fwd.d_rel[1]);
     if (single) {
         // ---- the whole forward as ONE persistent launch: bind (zero the ready counters, resolve the problem table), run
         Schedule::Fwd &fw = sched->fwd;
@@ -369,9 +369,10 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             fa.arm = fw.d_act + (size_t)(bank ^ 1) * fw.act_bytes;
             fa.arm_vec4 = (long long)(fw.act_bytes / 16);
         }
+        fa.spin_ticks = (long long)std::max(a->spin_timeout_ms, 1) * 100000LL;          // 100 MHz wall clock
         if (const char *ft = getenv("R3D_FAULT_TILE")) fa.fault_tile1 = atoi(ft) + 1;   // test hook: see FwdArgs
         const bool uv_launch = uv && fw.uses_gather;
-        if ((e = rec.begin(uv_launch ? "r3d_forward_uv_f32" : "r3d_forward_f32", stage_no, fw.grid, fw.flops, fw.bytes)) != hipSuccess)
+        if ((e = rec.begin(forward_kernel_name(fw.kernel, uv_launch), stage_no, fw.grid, fw.flops, fw.bytes)) != hipSuccess)
             return hip_fail(e, "hipEventRecord");
 #ifdef R3D_TIMING
         static long long *timing_buf1 = nullptr;
@@ -382,7 +383,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             if (fw.ntiles <= 65536) fa.dbg = timing_buf1;
         }
 #endif
-        if ((e = launch_forward(fa, fw.grid, uv_launch, stream)) != hipSuccess) return hip_fail(e, "launch r3d_forward_f32");
+        if ((e = launch_forward(fa, fw.grid, fw.kernel, uv_launch, stream)) != hipSuccess) return hip_fail(e, "launch r3d_forward_f32");
         if ((e = order_single_launch(stream, false)) != hipSuccess) return hip_fail(e, "hipEventRecord");
         if (own) {                     // the next call on these buffers needs no bind
             bd.valid = true;
@@ -533,6 +534,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
     da.out = out;
     da.out_trj = da.has_pos ? out_trj : nullptr;
     da.abort_flag = abort_flag;
+    da.status = a->status_host;
     double dec_flops = 0;
     int first = 0;
     // plan.decs lists the pos parts (Torso, LArm, RArm, LLeg, RLeg) then the trajectory decoder
@@ -917,8 +919,36 @@ int r3d_clip_metrics(const float *pred_dev, const float *gt_dev, int64_t n_frame
     return 0;
 }
 
+int r3d_set_option(r3d_model *m, int32_t option, int64_t value) {
+    Model *mm = reinterpret_cast<Model *>(m);
+    if (!mm) { r3d::set_error("r3d_set_option: null model"); return R3D_ERR_ARG; }
+    switch (option) {
+        case R3D_OPT_STAGED: mm->opt_staged = value != 0; return R3D_OK;
+        case R3D_OPT_SPIN_TIMEOUT_MS:
+            if (value < 1 || value > 600000) { r3d::set_error("r3d_set_option: spin timeout must be 1 .. 600000 ms (got %lld)", (long long)value); return R3D_ERR_ARG; }
+            mm->spin_timeout_ms = (int)value;
+            return R3D_OK;
+        default: r3d::set_error("r3d_set_option: unknown option %d", option); return R3D_ERR_ARG;
+    }
+}
+
+int r3d_status(r3d_model *m, void *stream) {
+    Model *mm = reinterpret_cast<Model *>(m);
+    if (!mm) { r3d::set_error("r3d_status: null model"); return R3D_ERR_ARG; }
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return r3d::hip_fail(e, "hipStreamSynchronize");
+    if (mm->status_host && *reinterpret_cast<volatile unsigned *>(mm->status_host) != 0u) {
+        *reinterpret_cast<volatile unsigned *>(mm->status_host) = 0u;
+        r3d::set_error("a dependency wait of the single-launch forward gave up after %d ms (workgroups not co-resident: the GPU is shared "
+                       "with another persistent kernel, or CUs are masked): the outputs of that forward are NaN.  Run the handle "
+                       "level by level: r3d_set_option(m, R3D_OPT_STAGED, 1)", mm->spin_timeout_ms);
+        return R3D_ERR_ABORTED;
+    }
+    return R3D_OK;
+}
+
 const char *r3d_last_error(void) { return r3d::last_error(); }
-const char *r3d_version(void) { return "ray3d_hip 0.3 (gfx950, ABI 3)"; }
+const char *r3d_version(void) { return "ray3d_hip 0.4 (gfx950, ABI 4)"; }
 int r3d_abi_version(void) { return R3D_ABI_VERSION; }
 int r3d_precision(const r3d_model *m) {
     if (!m) { r3d::set_error("r3d_precision: null model"); return R3D_ERR_ARG; }

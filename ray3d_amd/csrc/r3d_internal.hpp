@@ -103,10 +103,12 @@ struct FwdArgs {
     int poll;                 // GEMV / latency tiles read their operands until no ACT_SENTINEL is left instead of waiting for counters
     void *arm;                // the other bank of activations: filled with sentinels by this launch, for the next call (or nullptr)
     long long arm_vec4;       // ... its size in 16-byte units
+    long long spin_ticks;     // bound of a dependency wait in ticks of the 100 MHz wall clock (r3d_set_option, R3D_OPT_SPIN_TIMEOUT_MS)
     int fault_tile1;          // test hook (R3D_FAULT_TILE=<n>): workgroup 0's n-th tile behind the first level never raises its counters, and
                               // its n-th GEMV tile neither stores nor reports (0: none; n + 1 stored)
     long long *dbg;
 };
+enum { FWD_KERNEL_F32 = 0, FWD_KERNEL_B3 = 1, FWD_KERNEL_LAT = 2, FWD_KERNEL_COUNT = 3 };   // specialisations of the single-launch forward
 constexpr int BIND_NPTR = 18;  // pointer fields of a GemmProb, in the order r3d_bind_f32 walks them
 enum { BIND_NULL = 0, BIND_WS, BIND_ARENA0, BIND_ARENA1, BIND_IARENA0, BIND_IARENA1, BIND_X, BIND_PARAM, BIND_CAM, BIND_NBASE };
 struct BindArgs {
@@ -139,6 +141,7 @@ struct DecodeArgs {
     float *out;                // pos: (B, J, 3);  trj-only: (B, 3)
     float *out_trj;            // optional (B, 3)
     const unsigned *abort_flag;   // single-launch forward: nonzero when a dependency spin gave up - the outputs become NaN
+    unsigned *status;             // ... and this word (pinned host memory of the handle: Model::status_host) becomes 1 - r3d_status
     int slot[5 * 16];          // flat pos output index -> element of (J,3) it lands in
 };
 
@@ -222,6 +225,10 @@ struct Model {
     int device = -1;
     bool finalized = false;
     bool dirty = true;
+    // r3d_set_option
+    bool opt_staged = false;          // this handle's forwards run one launch per level (no co-residency assumption)
+    int spin_timeout_ms = 1000;       // bound of a dependency wait of the single-launch forward
+    unsigned *status_host = nullptr;  // pinned host word the decoder kernel raises when a wait gave up (r3d_status reads and clears it)
     // profiling
     bool profiling = false;
     struct Rec {
@@ -296,6 +303,7 @@ struct Schedule {
         std::vector<int> h_tiles, h_wgoff;    // host copies of the lists (diagnostics)
         double flops = 0, bytes = 0;
         bool uses_gather = false;             // some problem gathers from the input (UV mode selects the _uv kernel)
+        int kernel = FWD_KERNEL_F32;          // which specialisation runs these lists: FWD_KERNEL_* (by the tile kinds they hold)
         // Library-owned control region of the calls that are not being captured into a graph: two banks of ready
         // counters (+ abort flag) and the bound problem table.  A call whose buffers are the ones the table was bound
         // to skips r3d_bind_f32: it runs on the bank the previous launch zeroed and zeroes the other one itself.
@@ -415,7 +423,9 @@ int device_cu_count();
 enum { STAGE_BIG = 0, STAGE_ENC = 1 };   // r3d_gemm_f32 / r3d_gemm_enc_f32
 hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, int kind, bool uv, hipStream_t stream);   // uv: the launch gathers pixel keypoints
 hipError_t launch_decode(const DecodeArgs &args, hipStream_t stream);
-hipError_t launch_forward(const FwdArgs &args, int nwg, bool uv, hipStream_t stream);
+hipError_t launch_forward(const FwdArgs &args, int nwg, int kind, bool uv, hipStream_t stream);
+const char *forward_kernel_name(int kind, bool uv);
+int forward_resident_capacity(int kind, bool uv);      // workgroups of that kernel the current device holds at once (0: unknown)
 hipError_t launch_bind(const BindArgs &args, hipStream_t stream);
 bool forward_single_launch();   // the single-launch form is in use (R3D_STAGED=1 turns it off)
 size_t fwd_ctrl_bytes(const Plan *pl, int64_t B);   // workspace bytes behind the activations: counters + problem table

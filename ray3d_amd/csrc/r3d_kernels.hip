@@ -1960,10 +1960,10 @@ __device__ __forceinline__ void first_level_taps_b3(ProbRef P, const int4 *tile_
 // LeakyReLU / residual, one 128-byte row segment per row.  32 tiles per 1024-column layer: the five FuseBlocks' layers
 // of a one-window call occupy 160 CUs instead of 80, each for a third of the time.
 constexpr int GEMV_MAX_M = 4;
-__device__ __forceinline__ void wait_deps(const int4 *tile, const int ndep, const gu32 cnt, const gu32 abort_flag);
+__device__ __forceinline__ void wait_deps(const int4 *tile, const int ndep, const gu32 cnt, const gu32 abort_flag, const long long spin_ticks);
 // (single-launch form: these tiles wait for their producers themselves - BEHIND their weight requests, which depend on no
 //  producer: in a call of a few windows a layer is one memory round trip, and the wait for the previous layer hides it)
-struct TileDeps { const int4 *tile; int ndep; gu32 cnt, abort_flag; bool poll; long long *tstamp; };   // (tstamp: -DR3D_TIMING builds, this tile's four stamps)
+struct TileDeps { const int4 *tile; int ndep; gu32 cnt, abort_flag; bool poll; long long *tstamp; long long spin_ticks; };   // (tstamp: -DR3D_TIMING builds, this tile's four stamps)
 __device__ __forceinline__ float act_ld(const float *p) {
     return __builtin_bit_cast(float, __hip_atomic_load((gu32)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // 4-byte sc1 load
 }
@@ -1980,15 +1980,16 @@ __device__ __forceinline__ void act_st(float *p, float v) {
     u = u == ACT_SENTINEL ? 0x7fc00000u : u;
     __hip_atomic_store((gu32)p, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// one round of a bounded poll loop: true = give up (the launch's abort flag is up, or this wavefront has polled for ~1 s
-// and raises it) - the caller goes on with what it has, the decoder turns the outputs into NaN
-__device__ __forceinline__ bool poll_gave_up(unsigned &spins, long long &t_first, const gu32 abort_flag) {
+// one round of a bounded poll loop: true = give up (the launch's abort flag is up, or this wavefront has polled for
+// `spin_ticks` of the 100 MHz wall clock - r3d_set_option(R3D_OPT_SPIN_TIMEOUT_MS), 1 s by default - and raises it): the
+// caller goes on with what it has, the decoder turns the outputs into NaN and raises the handle's status (r3d_status)
+__device__ __forceinline__ bool poll_gave_up(unsigned &spins, long long &t_first, const gu32 abort_flag, const long long spin_ticks) {
     __builtin_amdgcn_s_sleep(2);
     if ((++spins & 31) != 0) return false;
     if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
     const long long now = wall_clock64();                       // 100 MHz
     if (t_first == 0) { t_first = now; return false; }
-    if (now - t_first <= 100000000LL) return false;
+    if (now - t_first <= spin_ticks) return false;
     __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
 }
@@ -2014,7 +2015,7 @@ __device__ __forceinline__ void gemv_tile(ProbRef P, const int col0, float *smem
     const int er = tid >> 5, ecol = col0 + (tid & 31);
     const bool emit = tid < M * 32 && ecol < N;
     const float ebias = emit ? gload1(P.bias + ecol) : 0.0f;       // (the epilogue's bias: requested now, used after the reduction)
-    if (dep.ndep > 0 && !dep.poll) wait_deps(dep.tile, dep.ndep, dep.cnt, dep.abort_flag);
+    if (dep.ndep > 0 && !dep.poll) wait_deps(dep.tile, dep.ndep, dep.cnt, dep.abort_flag, dep.spin_ticks);
     // the operand rows -> LDS (a virtual concatenation of up to MAX_SEG buffers; every column of such a problem is real)
     // (poll mode: read until no sentinel is left - each wavefront for its own elements, the barrier collects them)
     {
@@ -2033,7 +2034,7 @@ __device__ __forceinline__ void gemv_tile(ProbRef P, const int col0, float *smem
                     missing |= act_missing(v);
                     As[r * ldA + k] = v;
                 }
-            if (!dep.poll || !__any(missing) || poll_gave_up(spins, t_first, dep.abort_flag)) break;
+            if (!dep.poll || !__any(missing) || poll_gave_up(spins, t_first, dep.abort_flag, dep.spin_ticks)) break;
         }
     }
     // (the residual is an input of the operand's producer chain: whoever sees the operand sees it - polled all the same)
@@ -2042,7 +2043,7 @@ __device__ __forceinline__ void gemv_tile(ProbRef P, const int col0, float *smem
         unsigned spins = 0;
         long long t_first = 0;
         do eres = act_ld(P.res + (size_t)er * P.ldr + ecol);
-        while (dep.poll && act_missing(eres) && !poll_gave_up(spins, t_first, dep.abort_flag));
+        while (dep.poll && act_missing(eres) && !poll_gave_up(spins, t_first, dep.abort_flag, dep.spin_ticks));
     }
     __syncthreads();
     float acc[GEMV_MAX_M];
@@ -2132,7 +2133,14 @@ __device__ __forceinline__ void lat_tile(ProbRef P, const int col0, float *smem,
         ecol[h] = col0 + (ln & 31);
         ebias[h] = erow[h] < M && ecol[h] < N ? gload1(P.bias + ecol[h]) : 0.0f;
     }
-    if (dep.ndep > 0 && !dep.poll) wait_deps(dep.tile, dep.ndep, dep.cnt, dep.abort_flag);
+    if (dep.ndep > 0 && !dep.poll) wait_deps(dep.tile, dep.ndep, dep.cnt, dep.abort_flag, dep.spin_ticks);
+    // the residual: requested by EVERY emitting thread, ahead of the K loop - a wavefront whose share of a short K is empty
+    // (K < 256: wave_u >= nk32) never enters the loop and still emits rows (poll mode: checked again in the epilogue)
+    if (P.res) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (erow[h] < M && ecol[h] < N) eres[h] = act_ld(P.res + (size_t)erow[h] * P.ldr + ecol[h]);
+    }
     unsigned spins = 0;
     long long t_first = 0;
     for (int j0 = 0; wave_u + 8 * j0 < nk32; j0 += 4) {
@@ -2147,16 +2155,11 @@ __device__ __forceinline__ void lat_tile(ProbRef P, const int col0, float *smem,
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) missing |= act_missing(af[j][q][kk]);
-            if (!__any(missing) || poll_gave_up(spins, t_first, dep.abort_flag)) break;
+            if (!__any(missing) || poll_gave_up(spins, t_first, dep.abort_flag, dep.spin_ticks)) break;
         }
 #ifdef R3D_TIMING
         if (j0 == 0 && dep.tstamp && threadIdx.x == 0) dep.tstamp[1] = wall_clock64();      // (this wavefront's first operand round has arrived)
 #endif
-        if (j0 == 0 && P.res) {                                     // the residual: on its way while the matrix cores work (checked below)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                if (erow[h] < M && ecol[h] < N) eres[h] = act_ld(P.res + (size_t)erow[h] * P.ldr + ecol[h]);
-        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (wave_u + 8 * (j0 + j) >= nk32) break;               // (uniform; a 256-deep layer is ONE K tile per wavefront, not four - three
@@ -2185,7 +2188,7 @@ __device__ __forceinline__ void lat_tile(ProbRef P, const int col0, float *smem,
                 float rv = eres[h];
                 unsigned rspins = 0;
                 long long rt = 0;
-                while (dep.poll && act_missing(rv) && !poll_gave_up(rspins, rt, dep.abort_flag)) rv = act_ld(P.res + (size_t)row * P.ldr + col);
+                while (dep.poll && act_missing(rv) && !poll_gave_up(rspins, rt, dep.abort_flag, dep.spin_ticks)) rv = act_ld(P.res + (size_t)row * P.ldr + col);
                 v += rv;
             }
             act_st(P.c + (size_t)row * P.ldc + col, v);
@@ -2204,7 +2207,7 @@ __device__ __forceinline__ void lat_tile(ProbRef P, const int col0, float *smem,
 // Spins are bounded: after ~1 s without progress the wavefront raises the launch's abort flag and goes on; every later
 // wait sees the flag and returns at once, the decoder kernel turns the outputs into NaN, nothing hangs.
 typedef const FwdArgs __attribute__((address_space(4))) *FwdArgsPtr;
-__device__ __forceinline__ void wait_deps(const int4 *tile, const int ndep, const gu32 cnt, const gu32 abort_flag) {
+__device__ __forceinline__ void wait_deps(const int4 *tile, const int ndep, const gu32 cnt, const gu32 abort_flag, const long long spin_ticks) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         const int *ti = reinterpret_cast<const int *>(tile);
@@ -2228,7 +2231,7 @@ __device__ __forceinline__ void wait_deps(const int4 *tile, const int ndep, cons
                     if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
                     const long long now = wall_clock64();                       // 100 MHz
                     if (t_first == 0) t_first = now;
-                    else if (now - t_first > 100000000LL) {
+                    else if (now - t_first > spin_ticks) {
                         if (lane == 0) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
@@ -2249,6 +2252,7 @@ __device__ __forceinline__ void wait_deps(const int4 *tile, const int ndep, cons
 constexpr int FWD_TILE_NOSIGNAL = 1;      // descriptor int 7, bit 0 (r3d_schedule.cpp)
 __device__ __forceinline__ void gemv_run(FwdArgsPtr fargs, const int4 *tl, const int TS, const int n, float *smem, const gu32 cnt,
                                          const gu32 abort_flag, int &gemv_seen, long long *dbg_arg, const int t_first_tile) {
+    const long long spin_ticks = fargs->spin_ticks;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -2287,7 +2291,7 @@ __device__ __forceinline__ void gemv_run(FwdArgsPtr fargs, const int4 *tl, const
         const int er = tid >> 5, ecol = col0 + (tid & 31);
         const bool emit = tid < M * 32 && ecol < N;
         const float ebias = emit ? gload1(P.bias + ecol) : 0.0f;
-        if (ndep > 0 && !poll) wait_deps(tile, ndep, cnt, abort_flag);
+        if (ndep > 0 && !poll) wait_deps(tile, ndep, cnt, abort_flag, spin_ticks);
         {
             const int e0 = P.kend[0], e1 = P.kend[1], e2 = P.kend[2];
             const float *a0 = P.a[0], *a1 = P.a[1], *a2 = P.a[2], *a3 = P.a[3];
@@ -2304,7 +2308,7 @@ __device__ __forceinline__ void gemv_run(FwdArgsPtr fargs, const int4 *tl, const
                         missing |= act_missing(v);
                         As[r * ldA + k] = v;
                     }
-                if (!poll || !__any(missing) || poll_gave_up(spins, t_first, abort_flag)) break;
+                if (!poll || !__any(missing) || poll_gave_up(spins, t_first, abort_flag, spin_ticks)) break;
             }
         }
         float eres = 0.0f;
@@ -2312,7 +2316,7 @@ __device__ __forceinline__ void gemv_run(FwdArgsPtr fargs, const int4 *tl, const
             unsigned spins = 0;
             long long t_first = 0;
             do eres = act_ld(P.res + (size_t)er * P.ldr + ecol);
-            while (poll && act_missing(eres) && !poll_gave_up(spins, t_first, abort_flag));
+            while (poll && act_missing(eres) && !poll_gave_up(spins, t_first, abort_flag, spin_ticks));
         }
         if (i + 1 < n) request(prob_of(i + 1), __builtin_amdgcn_readfirstlane(tl[(i + 1) * TS].z), 0, wnext);
         __syncthreads();
@@ -2378,7 +2382,12 @@ __device__ __forceinline__ void gemv_run(FwdArgsPtr fargs, const int4 *tl, const
     if (i < n) body(i, wa, wb);
 }
 
-template <bool ENC, bool UV, bool DEP = false>
+// B3: the kernel carries the tiles that run fp32 GEMMs on the bf16 matrix cores (r3d_config.bf16x3); NARROW: the GEMV /
+// latency tiles of calls of a few windows (and their data-as-its-own-flag hand-off).  The single-launch forward exists in
+// three specialisations - r3d_forward_f32 (neither: the fp32 throughput tiles only), r3d_forward_b3, r3d_forward_lat - picked
+// on the host by what the schedule's tile lists hold, so that the headline kernel pays neither registers nor scratch for
+// code it never runs and a trace names the mode.
+template <bool ENC, bool UV, bool DEP = false, bool B3 = true, bool NARROW = true>
 __device__ __forceinline__ void gemm_persistent(float *smem) {
     LaunchArgsPtr args = (LaunchArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     FwdArgsPtr fargs = (FwdArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();      // (DEP: the same segment holds a FwdArgs)
@@ -2405,7 +2414,7 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
             for (int j = blockIdx.x * GEMM_THREADS + threadIdx.x; j < fargs->ncnt + 4; j += gridDim.x * GEMM_THREADS) nx[j] = 0u;
         // ... and the other bank of activations (poll mode): sentinels
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 *arm = reinterpret_cast<u32x4 *>(fargs->arm);
+        u32x4 *arm = NARROW ? reinterpret_cast<u32x4 *>(fargs->arm) : nullptr;
         if (arm != nullptr) {
             const u32x4 sv = {ACT_SENTINEL, ACT_SENTINEL, ACT_SENTINEL, ACT_SENTINEL};
             for (long long j = blockIdx.x * GEMM_THREADS + threadIdx.x; j < fargs->arm_vec4; j += gridDim.x * GEMM_THREADS) arm[j] = sv;
@@ -2432,7 +2441,7 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
         const int col0 = __builtin_amdgcn_readfirstlane(td.z);
         const int ks = __builtin_amdgcn_readfirstlane(td.w);      // split-K factor of this tile (1, 2 or 4)
         int sig_base = 0, sig_add = 0, tflags = 0;
-        TileDeps tdep{nullptr, 0, nullptr, nullptr, false, nullptr};
+        TileDeps tdep{nullptr, 0, nullptr, nullptr, false, nullptr, 0};
         if constexpr (DEP) {
             const int4 te = tiles[t * TS + 1];
             const int ndep = __builtin_amdgcn_readfirstlane(te.x);
@@ -2443,11 +2452,11 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
             if (dbg_arg && threadIdx.x == 0) dbg_arg[16384 + (long long)t * 4 + 0] = wall_clock64();      // tile fetched
 #endif
             // (GEMV / latency tiles wait themselves, behind their weight requests)
-            if (ndep > 0 && ks < 8) wait_deps(tiles + t * TS, ndep, cnt, abort_flag);
+            if (ndep > 0 && (!NARROW || ks < 8)) wait_deps(tiles + t * TS, ndep, cnt, abort_flag, fargs->spin_ticks);
 #ifdef R3D_TIMING
             if (dbg_arg && threadIdx.x == 0) dbg_arg[16384 + (long long)t * 4 + 1] = wall_clock64();      // producers ready
 #endif
-            tdep = TileDeps{tiles + t * TS, ks >= 8 ? ndep : 0, cnt, abort_flag, fargs->poll != 0, nullptr};
+            tdep = TileDeps{tiles + t * TS, NARROW && ks >= 8 ? ndep : 0, cnt, abort_flag, NARROW && fargs->poll != 0, nullptr, fargs->spin_ticks};
 #ifdef R3D_TIMING
             if (dbg_arg) tdep.tstamp = dbg_arg + 16384 + (long long)t * 4;
 #endif
@@ -2475,7 +2484,8 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                 long long *run_dbg = nullptr;
 #endif
                 const int4 *tl = tiles + t * TS;
-                if (P.wb3 != nullptr) {   // fp32 on the bf16 matrix cores
+                if (B3 && P.wb3 != nullptr) {   // fp32 on the bf16 matrix cores
+                  if constexpr (B3) {
                     if (P.K <= 64) {
                         if (mi >= 2) first_level_taps_b3<2, false, UV>(P, tl, TS, n, new_prob, smem, cnt, run_dbg);
                         else first_level_taps_b3<1, false, UV>(P, tl, TS, n, new_prob, smem, cnt, run_dbg);
@@ -2483,6 +2493,7 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                         if (mi >= 2) first_level_taps_b3<2, true, UV>(P, tl, TS, n, new_prob, smem, cnt, run_dbg);
                         else first_level_taps_b3<1, true, UV>(P, tl, TS, n, new_prob, smem, cnt, run_dbg);
                     }
+                  }
                 } else if (P.K <= 64) {
                     if (mi >= 2) first_level_taps<2, false, UV>(P, tl, TS, n, new_prob, smem, cnt, run_dbg);
                     else first_level_taps<1, false, UV>(P, tl, TS, n, new_prob, smem, cnt, run_dbg);
@@ -2508,6 +2519,7 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                 }
                 break;
             }
+            if constexpr (B3) {
             if (P.wb3 != nullptr && P.w2 != nullptr) {   // a fused pair on the bf16 matrix cores (tiles of <= 96 rows)
                 if (mi >= 3) gemm_tile_b3t<3>(P, row0, smem, dbg);
                 else if (mi == 2) gemm_tile_b3t<2>(P, row0, smem, dbg);
@@ -2523,6 +2535,8 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                 }
                 break;
             }
+            }
+            if constexpr (NARROW) {
             if (ks == 8) {               // a problem of a few rows: one 32-column block, K split over the wavefronts, no MFMA
                 if constexpr (DEP) {     // ... this workgroup's consecutive tiles of the kind as one run (weights requested a tile ahead)
                     int n = 1;
@@ -2543,6 +2557,7 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
             if (ks == 16) {              // ... of up to 32 rows: the same shape on the matrix cores
                 lat_tile(P, col0, smem, tdep);
                 break;
+            }
             }
             if (ks > 1) {
                 if (ks == 4) gemm_tile<1, 4>(P, row0, col0, smem, dbg);
@@ -2570,7 +2585,7 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
         }
         } while (false);
         if constexpr (DEP) {
-            if (!signalled && fargs->poll != 0 && (tflags & FWD_TILE_NOSIGNAL)) {   // (a latency tile nobody counts on)
+            if (NARROW && !signalled && fargs->poll != 0 && (tflags & FWD_TILE_NOSIGNAL)) {   // (a latency tile nobody counts on)
                 signalled = true;
 #ifdef R3D_TIMING
                 if (dbg_arg && threadIdx.x == 0) {
@@ -2617,16 +2632,18 @@ extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_uv_f32(const
 // The whole forward in one launch: every level's tiles, ordered by ready counters (wait_deps above).  One workgroup per
 // CU, all of them resident (grid <= CU count: a waiting workgroup can only wait for tiles of resident workgroups or of
 // its own past).
-extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_forward_f32(const FwdArgs args_) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    (void)args_;
-    gemm_persistent<false, false, true>(smem);
-}
-extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_forward_uv_f32(const FwdArgs args_) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    (void)args_;
-    gemm_persistent<false, true, true>(smem);
-}
+#define R3D_FORWARD_KERNEL(name, UV_, B3_, NARROW_)                                                     \
+    extern "C" __global__ __launch_bounds__(GEMM_THREADS) void name(const FwdArgs args_) {             \
+        extern __shared__ __attribute__((aligned(16))) float smem[];                                    \
+        (void)args_;                                                                                    \
+        gemm_persistent<false, UV_, true, B3_, NARROW_>(smem);                                          \
+    }
+R3D_FORWARD_KERNEL(r3d_forward_f32, false, false, false)        // the fp32 throughput tiles only (the headline kernel)
+R3D_FORWARD_KERNEL(r3d_forward_uv_f32, true, false, false)
+R3D_FORWARD_KERNEL(r3d_forward_b3, false, true, false)          // + the bf16x3 tiles (r3d_config.bf16x3, calls of >= 96 windows)
+R3D_FORWARD_KERNEL(r3d_forward_uv_b3, true, true, false)
+R3D_FORWARD_KERNEL(r3d_forward_lat, false, false, true)         // + GEMV / latency tiles (calls of <= 32 windows)
+R3D_FORWARD_KERNEL(r3d_forward_uv_lat, true, false, true)
 
 // Ahead of r3d_forward_f32 on the same stream: zero the call's ready counters and abort flag, and turn the schedule's
 // relative problem table (pointer fields = byte offsets, one base tag per field) into this call's absolute one - the
@@ -2665,12 +2682,12 @@ extern "C" __global__ __launch_bounds__(256) void r3d_bind_f32(const BindArgs b)
 extern "C" __global__ __launch_bounds__(GEMM_THREADS, 4) void r3d_gemm_enc_f32(const LaunchArgs args_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     (void)args_;
-    gemm_persistent<true, false>(smem);
+    gemm_persistent<true, false, false, false, false>(smem);
 }
 extern "C" __global__ __launch_bounds__(GEMM_THREADS, 4) void r3d_gemm_enc_uv_f32(const LaunchArgs args_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     (void)args_;
-    gemm_persistent<true, true>(smem);
+    gemm_persistent<true, true, false, false, false>(smem);
 }
 
 hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, int kind, bool uv, hipStream_t stream) {
@@ -2699,20 +2716,47 @@ hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, int kind, bool uv,
     return hipGetLastError();
 }
 
-hipError_t launch_forward(const FwdArgs &args, int nwg, bool uv, hipStream_t stream) {
+typedef void (*FwdKernel)(const FwdArgs);
+static FwdKernel forward_kernel(int kind, bool uv) {
+    switch (kind) {
+        case FWD_KERNEL_B3: return uv ? r3d_forward_uv_b3 : r3d_forward_b3;
+        case FWD_KERNEL_LAT: return uv ? r3d_forward_uv_lat : r3d_forward_lat;
+        default: return uv ? r3d_forward_uv_f32 : r3d_forward_f32;
+    }
+}
+const char *forward_kernel_name(int kind, bool uv) {
+    switch (kind) {
+        case FWD_KERNEL_B3: return uv ? "r3d_forward_uv_b3" : "r3d_forward_b3";
+        case FWD_KERNEL_LAT: return uv ? "r3d_forward_uv_lat" : "r3d_forward_lat";
+        default: return uv ? "r3d_forward_uv_f32" : "r3d_forward_f32";
+    }
+}
+
+hipError_t launch_forward(const FwdArgs &args, int nwg, int kind, bool uv, hipStream_t stream) {
     static bool attr_done_dev[64] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_done_dev[dev]) {
-        for (const void *f : {reinterpret_cast<const void *>(r3d_forward_f32), reinterpret_cast<const void *>(r3d_forward_uv_f32)}) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-            if (e != hipSuccess) return e;
-        }
+        for (int k = 0; k < FWD_KERNEL_COUNT; ++k)
+            for (int u = 0; u < 2; ++u) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(forward_kernel(k, u != 0)), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+                if (e != hipSuccess) return e;
+            }
         attr_done_dev[dev] = true;
     }
-    if (uv) r3d_forward_uv_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
-    else r3d_forward_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
+    forward_kernel(kind, uv)<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
     return hipGetLastError();
+}
+
+// Workgroups of the single-launch forward that can be resident at once on the current device (it needs ALL of its grid
+// resident: a waiting workgroup spins for tiles of workgroups that must be running).
+int forward_resident_capacity(int kind, bool uv) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(forward_kernel(kind, uv)), GEMM_THREADS, GEMM_LDS_BYTES) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return per_cu * device_cu_count();
 }
 
 hipError_t launch_bind(const BindArgs &args, hipStream_t stream) {
@@ -2783,6 +2827,8 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a) {
     // (single-launch forward: a dependency spin that gave up leaves garbage behind - make it loud)
     const bool poisoned = a.abort_flag != nullptr && __hip_atomic_load((gu32)a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     const float poison = poisoned ? __builtin_nanf("") : 0.0f;
+    // ... and visible to the host: the handle's status word (pinned host memory), read by r3d_status
+    if (poisoned && a.status != nullptr && gw == 0 && lane == 0) __hip_atomic_store((gu32)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const int jf = (int)(gw % per_win);              // joint in flat decoder order
     const int ts = a.nsrc - 1;
     int s = 0, o = 0;

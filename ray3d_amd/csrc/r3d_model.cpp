@@ -134,6 +134,7 @@ Model::~Model() {
     plans_drop(this);
     if (d_arena) (void)hipFree(d_arena);
     if (d_iarena) (void)hipFree(d_iarena);
+    if (status_host) (void)hipHostFree(status_host);
     for (auto &r : recs) {
         (void)hipEventDestroy(r.e0);
         (void)hipEventDestroy(r.e1);
@@ -463,6 +464,10 @@ int model_finalize(Model *m) {
         plans_drop(m);
     }
     m->device = dev;
+    if (!m->status_host) {             // the word the decoder kernel raises when a dependency wait gave up (r3d_status)
+        if ((e = hipHostMalloc((void **)&m->status_host, 64, hipHostMallocDefault)) != hipSuccess) return hip_fail(e, "hipHostMalloc(status)");
+        *m->status_host = 0u;
+    }
     if (!m->d_arena) {
         if ((e = hipMalloc((void **)&m->d_arena, m->arena.size() * sizeof(float))) != hipSuccess) return hip_fail(e, "hipMalloc(weights)");
         if ((e = hipMalloc((void **)&m->d_iarena, m->iarena.size() * sizeof(int))) != hipSuccess) return hip_fail(e, "hipMalloc(luts)");

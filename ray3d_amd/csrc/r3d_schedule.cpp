@@ -768,6 +768,30 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
             }
             bool narrow = false;       // GEMV / latency tiles in the lists: activation banks of the library's own (poll mode)
             for (size_t t = 0; t * FWD_TILE_INT4 * 4 < ft.size(); ++t) narrow |= ft[t * FWD_TILE_INT4 * 4 + 3] >= 8;
+            // which specialisation of the persistent kernel runs these lists (r3d_kernels.hip, R3D_FORWARD_KERNEL)
+            const bool b3_tiles = B >= b3_min_batch() && ((pl->m[0] && pl->m[0]->use_b3) || (pl->m[1] && pl->m[1]->use_b3));
+            fw.kernel = narrow ? FWD_KERNEL_LAT : b3_tiles ? FWD_KERNEL_B3 : FWD_KERNEL_F32;
+            // The single launch is only correct with ALL its workgroups resident.  Checked here against what the device
+            // holds of that kernel; a CU mask (which the occupancy query does not see) or a lists-mix no specialisation
+            // carries sends the size to the launch-by-launch form instead.
+            if (ok) {
+                const int cap = forward_resident_capacity(fw.kernel, false);
+                const bool masked = getenv("HSA_CU_MASK") != nullptr || getenv("ROC_GLOBAL_CU_MASK") != nullptr;
+                if ((narrow && b3_tiles) || (cap > 0 && fw.grid > cap) || masked) {
+                    if (fw.d_tiles) (void)hipFree(fw.d_tiles);
+                    if (fw.d_wgoff) (void)hipFree(fw.d_wgoff);
+                    if (fw.d_ctrl) (void)hipFree(fw.d_ctrl);
+                    for (int i = 0; i < 2; ++i) {
+                        if (fw.d_rel[i]) (void)hipFree(fw.d_rel[i]);
+                        if (fw.d_tags[i]) (void)hipFree(fw.d_tags[i]);
+                    }
+                    fw = Schedule::Fwd();
+                    s->pinned = pin;
+                    pl->schedules[B] = s;
+                    pl->schedule_lru.push_back(B);
+                    return s;
+                }
+            }
             // (up to 16 windows: at 32 the sentinel fill of a 10 MB bank costs more than the hops save - 0.219 against 0.213 ms)
             if (ok && narrow && pl->kind == PLAN_SMALL && B <= 16 && !env_on("R3D_NO_POLL")) {     // (that plan writes no activation twice: r3d_plan.cpp, single_assign)
                 fw.act_bytes = (((size_t)pl->floats_per_window * (size_t)B + (size_t)pl->tail_floats + 64) * sizeof(float) + 255) / 256 * 256;

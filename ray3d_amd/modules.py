@@ -90,6 +90,7 @@ class LiftModule(nn.Module):
         _grow_tree(self, cfg)
         self._handle: Optional[_capi.Handle] = None
         self._synced = False
+        self._staged = False
         self._ws = _Workspace()
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
 
@@ -125,10 +126,30 @@ class LiftModule(nn.Module):
             state_dict = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
+    def set_staged(self, on: bool = True):
+        """r3d_set_option(R3D_OPT_STAGED): this module's forwards run as one launch per level of the network instead of one
+        persistent launch - the form that needs no co-residency of its workgroups (a GPU shared with other processes)."""
+        self._staged = bool(on)
+        if self._handle is not None:
+            self._handle.set_option(_capi.R3D_OPT_STAGED, 1 if self._staged else 0)
+
+    def check_status(self, device=None) -> None:
+        """Synchronises the current stream of `device` and raises when a forward of this module since the last check
+        gave up waiting for its own tiles (r3d_status: its outputs are NaN).  The reference's seam reports errors as
+        Python exceptions; a forward is asynchronous, so this is where a device-side failure surfaces."""
+        dev = torch.device(device) if device is not None else getattr(self, "_device", None)
+        if self._handle is None or dev is None:
+            return
+        with torch.cuda.device(dev):
+            if not self._handle.status(torch.cuda.current_stream(dev).cuda_stream):
+                raise _capi.Ray3DHipError("forward aborted: " + _capi.load().r3d_last_error().decode())
+
     def handle(self, device: torch.device) -> _capi.Handle:
         """The finalized C handle for `device`, re-uploading weights when they changed."""
         if self._handle is None:
             self._handle = _capi.Handle(self.cfg)
+            if self._staged:
+                self._handle.set_option(_capi.R3D_OPT_STAGED, 1)
         if not self._synced or getattr(self, "_device", None) != device:
             sd = self.state_dict()
             for key in self._handle.keys():
@@ -251,6 +272,35 @@ class Ray3DLifter(nn.Module):
 
     def receptive_field(self) -> int:
         return self.pos.receptive_field()
+
+    def set_staged(self, on: bool = True):
+        """Both networks level by level (R3D_OPT_STAGED) instead of one persistent launch: see LiftModule.set_staged."""
+        self.pos.set_staged(on)
+        self.trj.set_staged(on)
+
+    def check_status(self, device=None) -> None:
+        """Synchronise and raise if a forward of the pair gave up waiting for its own tiles (the pair's flag lives in the
+        pos handle)."""
+        self.pos.check_status(device)
+
+    def checked(self, fn, device=None):
+        """`fn()` (forwards through this lifter) followed by a synchronisation and the status check.  When a forward gave
+        up waiting for its own tiles - the single persistent launch needs all its workgroups resident, which another
+        process's kernel on the same GPU can prevent - the pair is switched to the level-by-level form for good, `fn` runs
+        once more, and only a second failure raises: two processes lifting on one device both get correct outputs."""
+        out = fn()
+        dev = device if device is not None else (out.device if torch.is_tensor(out) else getattr(self.pos, "_device", None))
+        try:
+            self.check_status(dev)
+            return out
+        except _capi.Ray3DHipError:
+            import warnings
+            warnings.warn("ray3d_amd: a single-launch forward could not get all its workgroups resident (GPU shared?); "
+                          "switching this lifter to the level-by-level form (R3D_OPT_STAGED) and repeating the call")
+            self.set_staged(True)
+        out = fn()
+        self.check_status(dev)
+        return out
 
     def _run(self, mode, x, window_stride, B, param, param_stride, cam=None, cam_stride=0,
              return_trj=False, out=None, workspace=None):

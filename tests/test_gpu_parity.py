@@ -1,6 +1,6 @@
 """-m gpu: the HIP path (through the C ABI) against the reference-generated golden fixtures and
-the CPU oracle.  Tolerance: 1e-4 abs on fp32 3D joint positions of metre scale (BASELINE.json
-north_star); for the deliberately over-scaled '_big' fixture the same bound relative to 10 m."""
+the CPU oracle.  Tolerance: the literal 1e-4 abs on fp32 3D joint positions (BASELINE.json north_star),
+the deliberately over-scaled '_big' fixture (outputs of up to 108 m) included."""
 import os
 import numpy as np
 import pytest
@@ -14,7 +14,7 @@ ATOL = 1e-4
 
 
 def tol_for(ref):
-    return ATOL * max(1.0, float(np.abs(ref).max()) / 10.0)
+    return ATOL
 
 
 def build_modules(mc, out_scale=1.0, device="cuda:0"):
@@ -679,6 +679,28 @@ def test_other_widths_match_oracle(over):
     with torch.no_grad():
         out = lifter(torch.from_numpy(x).cuda(), pt).cpu().numpy()
     ref = oracle.forward(cp, sp, x, p if cp.camera_embedding else None) + oracle.forward(ct, st, x, p if cp.camera_embedding else None)
+    check_parity(out, ref)
+
+
+@pytest.mark.parametrize("no_lat", [False, True], ids=["latency-tiles", "split-k-tiles"])
+@pytest.mark.parametrize("batch", [5, 11, 32])
+@pytest.mark.parametrize("channels", [64, 96, 128])
+def test_narrow_channels_at_5_to_32_windows_keep_the_residual(channels, batch, no_lat, monkeypatch):
+    """A pyramid level's un-fused 1x1 convolution (K = CHANNELS < 256, residual = the level's input) on the latency tiles:
+    with K < 256 some wavefronts have no K tile of their own and must still add the residual to the rows they emit
+    (round-3 advisor finding: they added 0).  Checked against the oracle with and without the latency tiles."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    from oracle import oracle
+    monkeypatch.setenv("R3D_NO_LAT", "1" if no_lat else "0")
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3", CHANNELS=channels, LATENT_FEATURES_DIM=128)
+    pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    x = synth.synth_rays(batch, cp, seed=41)
+    p = synth.synth_param(batch, seed=42)
+    with torch.no_grad():
+        out = lifter(torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()).cpu().numpy()
+    ref = oracle.forward(cp, sp, x, p) + oracle.forward(ct, st, x, p)
     check_parity(out, ref)
 
 

@@ -91,7 +91,7 @@ def test_create_rejects_unsupported_configs():
     old = _capi.Config(0, 17, 3, 2, 256, 256, 3, 2, 64, 0, 0, 0, 0)
     with pytest.raises(_capi.Ray3DHipError, match="struct_size"):
         _capi.check(_capi.load().r3d_create(_capi.C.byref(old), _capi.C.byref(_capi.C.c_void_p())), "r3d_create")
-    assert _capi.load().r3d_abi_version() == _capi.ABI_VERSION and b"ABI 3" in _capi.load().r3d_version()
+    assert _capi.load().r3d_abi_version() == _capi.ABI_VERSION and ("ABI %d" % _capi.ABI_VERSION).encode() in _capi.load().r3d_version()
 
 
 def test_forward_before_finalize_fails():
