@@ -372,7 +372,8 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         fa.spin_ticks = (long long)std::max(a->spin_timeout_ms, 1) * 100000LL;          // 100 MHz wall clock
         if (const char *ft = getenv("R3D_FAULT_TILE")) fa.fault_tile1 = atoi(ft) + 1;   // test hook: see FwdArgs
         const bool uv_launch = uv && fw.uses_gather;
-        if ((e = rec.begin(forward_kernel_name(fw.kernel, uv_launch), stage_no, fw.grid, fw.flops, fw.bytes)) != hipSuccess)
+        const char *fwd_name = fw.kernel == FWD_KERNEL_W4 ? (uv_launch ? "r3d_forward4_uv_f32" : "r3d_forward4_f32") : forward_kernel_name(fw.kernel, uv_launch);
+        if ((e = rec.begin(fwd_name, stage_no, fw.grid, fw.flops, fw.bytes)) != hipSuccess)
             return hip_fail(e, "hipEventRecord");
 #ifdef R3D_TIMING
         static long long *timing_buf1 = nullptr;
@@ -383,7 +384,8 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             if (fw.ntiles <= 65536) fa.dbg = timing_buf1;
         }
 #endif
-        if ((e = launch_forward(fa, fw.grid, fw.kernel, uv_launch, stream)) != hipSuccess) return hip_fail(e, "launch r3d_forward_f32");
+        if ((e = fw.kernel == FWD_KERNEL_W4 ? launch_forward4(fa, fw.grid, uv_launch, stream) : launch_forward(fa, fw.grid, fw.kernel, uv_launch, stream)) != hipSuccess)
+            return hip_fail(e, "launch r3d_forward_f32");
         if ((e = order_single_launch(stream, false)) != hipSuccess) return hip_fail(e, "hipEventRecord");
         if (own) {                     // the next call on these buffers needs no bind
             bd.valid = true;
@@ -456,10 +458,11 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             if (rc != R3D_OK) return rc;
         }
         if (n_enc != 0 && n_enc != la.nprob) { set_error("internal: launch mixes encoded and plain operands"); return R3D_ERR_STATE; }
-        if ((n_enc != 0) != (ss.kind == STAGE_ENC)) { set_error("internal: schedule and plan disagree on the launch kind"); return R3D_ERR_STATE; }
+        if ((n_enc != 0) != (ss.kind == STAGE_ENC) && ss.kind != STAGE_W4) { set_error("internal: schedule and plan disagree on the launch kind"); return R3D_ERR_STATE; }
         bool uv_launch = false;                             // UV mode: only the launches that gather from the input
         for (int i = 0; i < la.nprob; ++i) uv_launch = uv_launch || la.p[i].cam != nullptr;
-        const char *kname = ss.kind == STAGE_ENC ? (uv_launch ? "r3d_gemm_enc_uv_f32" : "r3d_gemm_enc_f32")
+        const char *kname = ss.kind == STAGE_W4 ? (uv_launch ? "r3d_gemm4_uv_f32" : "r3d_gemm4_f32")
+                          : ss.kind == STAGE_ENC ? (uv_launch ? "r3d_gemm_enc_uv_f32" : "r3d_gemm_enc_f32")
                                                  : (uv_launch ? "r3d_gemm_uv_f32" : "r3d_gemm_f32");
         if ((e = rec.begin(kname, stage_no, ss.nwg, ss.flops, ss.bytes)) != hipSuccess) return hip_fail(e, "hipEventRecord");
 #ifdef R3D_TIMING
@@ -473,7 +476,8 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             la.dbg = timing_buf;
         }
 #endif
-        if ((e = launch_gemm_stage(la, ss.nwg, ss.kind, uv_launch, stream)) != hipSuccess) return hip_fail(e, "launch r3d_gemm_f32");
+        if ((e = ss.kind == STAGE_W4 ? launch_gemm4_stage(la, ss.nwg, uv_launch, stream) : launch_gemm_stage(la, ss.nwg, ss.kind, uv_launch, stream)) != hipSuccess)
+            return hip_fail(e, "launch r3d_gemm_f32");
 #ifdef R3D_TIMING
         if (timed) {
             (void)hipStreamSynchronize(stream);
@@ -704,7 +708,7 @@ int r3d_debug_schedule_check(int nprob, const int *M, const int *N, const int *n
     std::vector<std::vector<int>> cover(nprob);
     for (int i = 0; i < nprob; ++i) cover[i].assign((size_t)((M[i] + 31) / 32) * ((N[i] + COL_GRANULE - 1) / COL_GRANULE), 0);
     for (const int4 &t : tiles) {
-        const int pi = t.x & 0xff, mi = t.x >> 8, ks = t.w;
+        const int pi = t.x & 0xff, mi = t.x >> 8, ks = tile_code(t.w);
         if (pi >= nprob || mi < 1 || (ks != 1 && ks != 2 && ks != 4 && ks != 8 && ks != 16)) return -4;
         if (ks < 8 && ks > max_ks[pi]) return -5;
         if ((ks == 1 && mi > (max_units[pi] > 0 ? std::min(max_units[pi], GEMM_SCHED_MAX_UNITS) : GEMM_SCHED_MAX_UNITS)) || (ks == 2 && mi > 2) || (ks >= 4 && mi != 1)) return -6;
@@ -735,7 +739,8 @@ int r3d_debug_plan_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg,
     std::vector<int4> tiles;
     std::vector<int> wgoff;
     std::vector<StageSchedule> stages;
-    const std::vector<std::vector<int>> &levels = *schedule_build_host(pl, batch, nwg, spill_row0, tiles, wgoff, stages);
+    const bool w4 = use_w4(pl, batch);
+    const std::vector<std::vector<int>> &levels = *schedule_build_host(pl, batch, nwg, spill_row0, tiles, wgoff, stages, w4);
     if (launches) *launches = (int)stages.size();
     if (spilled) *spilled = 0;
     const int np = (int)pl->probs.size();
@@ -758,7 +763,7 @@ int r3d_debug_plan_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg,
         }
         for (int t = 0; t < ss.ntiles; ++t) {
             const int4 &tl = tiles[ss.tiles_off + t];
-            const int slot = tl.x & 0xff, mi = tl.x >> 8, ks = tl.w;
+            const int slot = tl.x & 0xff, mi = tl.x >> 8, ks = tl.w;      // (ks: the whole code word - tile_cols reads the width from it)
             if (slot >= (int)st.size() || mi < 1) return -4;
             const int id = st[slot] & ~STAGE_SPILL_IN;
             const ProbSpec &q = pl->probs[id];
@@ -772,7 +777,7 @@ int r3d_debug_plan_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg,
             const int gcols = (N + COL_GRANULE - 1) / COL_GRANULE;
             for (int u = tl.y / 32; u < tl.y / 32 + mi; ++u) {
                 if (u * 32 >= M) return -7;
-                for (int g = tl.z / COL_GRANULE; g < (tl.z + tile_width(ks)) / COL_GRANULE && g < gcols; ++g) ++cover[id][(size_t)u * gcols + g];
+                for (int g = tl.z / COL_GRANULE; g < (tl.z + tile_cols(ks)) / COL_GRANULE && g < gcols; ++g) ++cover[id][(size_t)u * gcols + g];
             }
             last_launch[id] = std::max(last_launch[id], (int)si);
             first_launch[id] = std::min(first_launch[id], (int)si);
@@ -802,10 +807,11 @@ int r3d_debug_forward_check(r3d_model *pos, r3d_model *trj, int64_t batch, int n
     std::vector<int4> tiles;
     std::vector<int> wgoff;
     std::vector<StageSchedule> stages;
-    const std::vector<std::vector<int>> &levels = *schedule_build_host(pl, batch, nwg, spill_row0, tiles, wgoff, stages);
+    const bool w4 = use_w4(pl, batch);
+    const std::vector<std::vector<int>> &levels = *schedule_build_host(pl, batch, nwg, spill_row0, tiles, wgoff, stages, w4);
     Schedule::Fwd fw;
     std::vector<int> ft, fo;
-    if (!schedule_build_fwd(pl, batch, nwg, levels, stages, tiles, wgoff, fw, ft, fo)) return 1;
+    if (!schedule_build_fwd(pl, batch, w4 ? 2 * nwg : nwg, levels, stages, tiles, wgoff, fw, ft, fo)) return 1;
     if (out_tiles) *out_tiles = fw.ntiles;
     if (out_counters) *out_counters = fw.ncnt;
     const int np = (int)pl->probs.size(), TI = FWD_TILE_INT4 * 4;

@@ -91,6 +91,7 @@ class LiftModule(nn.Module):
         self._handle: Optional[_capi.Handle] = None
         self._synced = False
         self._staged = False
+        self._spin_timeout_ms: Optional[int] = None
         self._ws = _Workspace()
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
 
@@ -133,6 +134,13 @@ class LiftModule(nn.Module):
         if self._handle is not None:
             self._handle.set_option(_capi.R3D_OPT_STAGED, 1 if self._staged else 0)
 
+    def set_spin_timeout_ms(self, ms: int):
+        """r3d_set_option(R3D_OPT_SPIN_TIMEOUT_MS): how long a tile of the single-launch forward waits for its producers
+        before the forward gives up (default 1000)."""
+        self._spin_timeout_ms = int(ms)
+        if self._handle is not None:
+            self._handle.set_option(_capi.R3D_OPT_SPIN_TIMEOUT_MS, self._spin_timeout_ms)
+
     def check_status(self, device=None) -> None:
         """Synchronises the current stream of `device` and raises when a forward of this module since the last check
         gave up waiting for its own tiles (r3d_status: its outputs are NaN).  The reference's seam reports errors as
@@ -150,6 +158,8 @@ class LiftModule(nn.Module):
             self._handle = _capi.Handle(self.cfg)
             if self._staged:
                 self._handle.set_option(_capi.R3D_OPT_STAGED, 1)
+            if self._spin_timeout_ms is not None:
+                self._handle.set_option(_capi.R3D_OPT_SPIN_TIMEOUT_MS, self._spin_timeout_ms)
         if not self._synced or getattr(self, "_device", None) != device:
             sd = self.state_dict()
             for key in self._handle.keys():
@@ -277,6 +287,10 @@ class Ray3DLifter(nn.Module):
         """Both networks level by level (R3D_OPT_STAGED) instead of one persistent launch: see LiftModule.set_staged."""
         self.pos.set_staged(on)
         self.trj.set_staged(on)
+
+    def set_spin_timeout_ms(self, ms: int):
+        self.pos.set_spin_timeout_ms(ms)
+        self.trj.set_spin_timeout_ms(ms)
 
     def check_status(self, device=None) -> None:
         """Synchronise and raise if a forward of the pair gave up waiting for its own tiles (the pair's flag lives in the
