@@ -211,10 +211,19 @@ __device__ __forceinline__ void g4_tile(ProbRef P, const int row0, const int col
         const float *s = smem + st_cur * SF + a_frag;
         auto mfma_q = [&](int q) {
             f32x4 av[MI];
+            if constexpr (PRE) {
+                // a wavefront that is alone on its SIMD waits out every LDS round trip it starts just in time: the A fragments of
+                // quad q + 1 are requested BEFORE quad q's matrix work (av0 carries quad 0 across the barrier)
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                if (PRE && q == 0) av[mi] = av0[mi];
-                else av[mi] = *reinterpret_cast<const f32x4 *>(s + mi * 32 * LDS_LD + q * 4);
+                for (int mi = 0; mi < MI; ++mi) av[mi] = av0[mi];
+                // (quad 3: the NEXT K tile's quad 0 - its stage was committed a barrier ago - so that nothing is in flight at the barrier)
+                const float *nx = q < 3 ? s + (q + 1) * 4 : smem + st_next * SF + a_frag;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) av0[mi] = *reinterpret_cast<const f32x4 *>(nx + mi * 32 * LDS_LD);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) av[mi] = *reinterpret_cast<const f32x4 *>(s + mi * 32 * LDS_LD + q * 4);
             }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
@@ -244,11 +253,6 @@ __device__ __forceinline__ void g4_tile(ProbRef P, const int row0, const int col
         }
         mfma_q(2);
         mfma_q(3);
-        if (PRE) {
-            const float *sn = smem + st_next * SF + a_frag;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) av0[mi] = *reinterpret_cast<const f32x4 *>(sn + mi * 32 * LDS_LD);
-        }
         __syncthreads();
         st_cur = st_next;
     };

@@ -448,7 +448,11 @@ void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units,
     Packed big;
     const Packed *best = &big;
     out.kind = w4 ? STAGE_W4 : enc ? STAGE_ENC : STAGE_BIG;
-    pack(probs, nwg, max_units, big);
+    // (experiment, R3D_W4_SOLO=1: launches of plain layers only get ONE bin per CU - bins [0, nwg / 2) are the workgroups
+    //  that come first on their CU - so that an M = B layer runs as 64 x 128 tiles that have their CU to themselves)
+    bool solo = w4 && env_on("R3D_W4_SOLO");
+    for (const SchedProb &p : probs) solo = solo && p.colw == 128 && p.nk2 == 0;
+    pack(probs, solo ? nwg / 2 : nwg, max_units, big);
     out.ks = 1;
     out.tiles_off = tiles.size();
     out.wgoff_off = wgoff.size();

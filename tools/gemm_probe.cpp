@@ -31,6 +31,11 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < (size_t)N * K; ++i) hWr[i] = (float)((i * 40503u) % 2001) / 1000.f - 1.f;
     for (int o = 0; o < N; ++o)
         for (int k = 0; k < K; ++k) hW[frag_index(o, k, K / BK)] = hWr[(size_t)o * K + k];
+    if (getenv("PROBE_ZERO")) {      // all-zero operands: the same instruction stream at the clock a quiet datapath allows (DVFS)
+        std::fill(hA.begin(), hA.end(), 0.f);
+        std::fill(hW.begin(), hW.end(), 0.f);
+        std::fill(hWr.begin(), hWr.end(), 0.f);
+    }
     LaunchArgs la;
     memset(&la, 0, sizeof la);
     la.nprob = nprob;
@@ -64,17 +69,22 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(dW[i], hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
         GemmProb &g = la.p[i];
         for (int s = 0; s < MAX_SEG; ++s) { g.a[s] = dA[i]; g.lda[s] = K; g.kend[s] = 0x7fffffff; }
-        g.w = dW[i]; g.bias = dbias; g.res = nullptr; g.c = dC[i]; g.ldr = 0; g.ldc = N;
+        g.w = dW[getenv("PROBE_SHARE_W") ? 0 : i]; g.bias = dbias;   // PROBE_SHARE_W: every problem streams problem 0's weights (L2-resident)
+        if (getenv("PROBE_SHARE_A")) for (int s = 0; s < MAX_SEG; ++s) g.a[s] = dA[0];
+        g.res = nullptr; g.c = dC[i]; g.ldr = 0; g.ldc = N;
         g.M = M; g.N = N; g.K = K; g.slope = 0.2f;
         if (getenv("PROBE_B3")) g.wb3 = dW[i];   // timing only: the bf16x3 tile on weights that are not in its operand order
         if (enc) { g.lut = dlut; g.x = dx; g.enc_ws = 243 * 51; g.enc_rows = 81; g.enc_jf = 51; g.enc_cur = 81 * 51; g.enc_step = 3; g.enc_bytes = (unsigned)(hx.size() * 4); }
         sp.push_back({M, N, K / BK, enc ? 1 : 4, enc ? std::max(1, std::min(3, (64 * 1024) / ((K + 4) * 4 * 32))) : 0});
+        if (getenv("PROBE_W4")) { sp.back().max_ks = 1; sp.back().max_units = 4; sp.back().colw = 128; }   // four-wave tiles (r3d_kernels4.hip)
     }
     std::vector<int4> tiles;
     std::vector<int> wgoff;
     StageSchedule ss{};
     const int nwg = getenv("PROBE_NWG") ? atoi(getenv("PROBE_NWG")) : device_cu_count();
-    schedule_stage(sp, enc ? 2 * nwg : nwg, 6, tiles, wgoff, ss, enc != 0);
+    const bool w4 = getenv("PROBE_W4") != nullptr;
+    schedule_stage(sp, enc || w4 ? 2 * nwg : nwg, 6, tiles, wgoff, ss, enc != 0, w4);
+    auto launch = [&]() { return w4 ? launch_gemm4_stage(la, ss.nwg, false, 0) : launch_gemm_stage(la, ss.nwg, ss.kind, false, 0); };
     int4 *dt; int *dwg; long long *ddbg;
     CK(hipMalloc((void **)&dt, tiles.size() * sizeof(int4)));
     CK(hipMalloc((void **)&dwg, wgoff.size() * sizeof(int)));
@@ -86,12 +96,12 @@ int main(int argc, char **argv) {
     printf("grid %d tiles %d ks %d kind %d imbalance %.3f (CUs %d)\n", ss.nwg, ss.ntiles, ss.ks, ss.kind, ss.imbalance, nwg);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) CK(launch_gemm_stage(la, ss.nwg, ss.kind, false, 0));
+    for (int i = 0; i < 3; ++i) CK(launch());
     CK(hipDeviceSynchronize());
     float best = 1e9, sum = 0;
     for (int i = 0; i < reps; ++i) {
         CK(hipEventRecord(e0, 0));
-        CK(launch_gemm_stage(la, ss.nwg, ss.kind, false, 0));
+        CK(launch());
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
