@@ -167,18 +167,35 @@ def timed_steps(fn, steps, warmup, barrier, dev):
     return elapsed, e0.elapsed_time(e1) * 1e-3, out
 
 
-def roofline(lifter, x, p, step_ms, reps=5, fn=None, batch=None):
+def pmc_figures(key, kernel):
+    """What the committed rocprofv3 PMC passes say about `kernel` on workload `key` (profiles/pmc.json, written from
+    profiles/<round>_<key>/ by profiles/make_pmc_json.py): HBM bytes per launch, MFMA-busy fraction, executed FLOPs."""
+    f = os.path.join(ROOT, "profiles", "pmc.json")
+    try:
+        return json.load(open(f))["workloads"][key]["kernels"][kernel]
+    except Exception:                                  # noqa: BLE001 - no profile of this workload: the line says null
+        return None
+
+
+def roofline(lifter, x, p, step_ms, reps=5, fn=None, batch=None, key=None):
     """Per-launch HIP events (bracketing each launch on its stream) -> the dominant kernel's rate.
     `step_ms`: device time of one step of the timed region; the launch durations are scaled to sum to it.
-    `fn`: the forward to profile when it is not lifter(x, p) (UV mode).  The peak is the one of the arithmetic the
-    handles actually run (r3d_precision): an environment override cannot label a bf16x3 run f32."""
+    `fn`: the forward to profile when it is not lifter(x, p) (UV mode); `key`: the workload's name in profiles/pmc.json.
+    The peak is the one of the arithmetic the handles actually run (r3d_precision): an environment override cannot label a
+    bf16x3 run f32.  Besides the rate against the datasheet peak (2.4 GHz) the object carries the shader clock the forward
+    ran at (r3d_last_clock: cycle counter against the wall clock inside the kernel, of a free-running forward) and the rate
+    against the peak AT that clock, and - from the committed PMC passes of the same workload - the HBM traffic per launch,
+    the MFMA-busy fraction and the executed (as opposed to algorithmic) FLOP rate."""
     agg = {}
     dev = x.device
-    custom = fn is not None
     fn = fn or (lambda: lifter(x, p))
     batch = batch if batch is not None else x.shape[0]
+    key = key or ("b%d" % batch)
     prec = lifter.precision(dev)
     peak = PEAK_FP32_MFMA_TFLOPS if prec == "f32" else PEAK_BF16X3_TFLOPS
+    for _ in range(3):
+        fn()
+    clk = lifter.last_clock_ghz(dev)                   # (before the bracketed launches: those run at another clock)
     lifter.profile_call(fn, dev)
     pair_ms = []
     for _ in range(reps):
@@ -208,19 +225,22 @@ def roofline(lifter, x, p, step_ms, reps=5, fn=None, batch=None):
     d = agg[name]
     ms = d["ms"] * scale
     achieved = d["flops"] / (ms * 1e-3) / 1e12
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if measured
-    if os.path.exists(tfile):
-        try:
-            tj = json.load(open(tfile))
-            # (PMC-measured for the RF-243 rays workload at that batch size only; other workloads: tj["workloads"][key])
-            traffic = tj.get("workloads", {}).get(custom, {}).get(name) if isinstance(custom, str) else \
-                (None if custom else tj.get("batches", {}).get(str(batch), {}).get(name))
-        except Exception:
-            traffic = None
+    pmc = pmc_figures(key, name)
+    launch_s = ms / d["launches"] * 1e-3
     out = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
            "peak_of": "fp32 MFMA (v_mfma_f32_32x32x2_f32)" if prec == "f32" else "bf16 MFMA / 6 products (bf16x3)",
-           "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+           "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+           "traffic": pmc["traffic_bytes"] if pmc else None,
+           # the clock the kernel ran at (live) and what the peak is at that clock: the datasheet peak assumes 2.4 GHz
+           "clk_ghz": round(clk, 3) if clk > 0 else None,
+           "peak_at_clk": round(peak * clk / 2.4, 1) if clk > 0 else None,
+           "frac_at_clk": round(achieved / (peak * clk / 2.4), 4) if clk > 0 else None,
+           # from the committed PMC passes of this workload (profiles/pmc.json): SQ_VALU_MFMA_BUSY_CYCLES over the SIMD-cycles
+           # of the launch, and the FLOPs those busy cycles executed over this run's launch time
+           "mfma_busy_frac": pmc["mfma_busy_frac"] if pmc else None,
+           "executed_tflops": round(pmc["executed_flops"] / launch_s / 1e12, 2) if pmc else None,
+           "pmc": {"table": "profiles/pmc.json[%s][%s]" % (key, name), "clk_ghz_pmc_pass": pmc["clk_ghz_pmc_pass"],
+                   "l2_hit_pct": pmc["l2_hit_pct"], "fetch_bytes": pmc["fetch_bytes"], "write_bytes": pmc["write_bytes"]} if pmc else None,
            "launches_per_step": d["launches"] // reps,
            "avg_launch_us": round(ms / d["launches"] * 1e3, 2),
            "avg_launch_us_bracketed": round(d["ms"] / d["launches"] * 1e3, 2),
@@ -353,7 +373,7 @@ def uv_workload(name, dev, world, rank, steps, warmup, barrier, want_rays_delta=
         el, dev_s, _ = timed_steps(run_uv, steps, warmup, barrier, dev)
         res.update({"value": round(world * B * steps / el, 1), "unit": "poses/s", "ms_per_step": round(el / steps * 1e3, 4),
                     "steps": steps})
-        rl = roofline(lifter, uvd, pard, dev_s / steps * 1e3, fn=run_uv, batch=B)
+        rl = roofline(lifter, uvd, pard, dev_s / steps * 1e3, fn=run_uv, batch=B, key=name)
         flops_step = rl["flops_per_launch"] * rl["launches_per_step"]
         # which roof binds: the GEMMs have M = B rows (MLPs are 95 % of the FLOPs at RF 9) - matrix-bound when the
         # weights' HBM stream (once per step) is shorter than the matrix time, weight-bandwidth-bound at small B

@@ -42,7 +42,7 @@ extern "C" {
 
 /* Mirrors the constructor arguments the reference factory passes
  * (lib/model/__init__.py:23-46 -> lib/model/rie.py:178-181 / :443-446). */
-#define R3D_ABI_VERSION 4 /* bumped whenever a struct below changes size or layout: r3d_abi_version() returns the
+#define R3D_ABI_VERSION 5 /* bumped whenever a struct below changes size or layout: r3d_abi_version() returns the
                            * library's; a binding compares it with the header it was written against       */
 
 typedef struct {
@@ -192,6 +192,14 @@ typedef struct {
 } r3d_launch_record;
 int r3d_profile_enable(r3d_model *m, int on);
 int r3d_profile_read(r3d_model *m, r3d_launch_record *records, int capacity);
+
+/* The shader clock the handle's last single-launch forward ran at, in GHz (for a pair: ask the pos handle): the kernel's
+ * first workgroup stamps its cycle counter and the 100 MHz wall clock at both ends.  Synchronises `hip_stream`.  What the
+ * chip sustains under the fp32 matrix work on real operands is below the 2.4 GHz the datasheet peak is quoted at
+ * (measured: DESIGN.md), so a roofline needs it next to the rate (north_star: counters against the gfx950 peak - there is
+ * no reference counterpart).  *ghz = 0 when the last forward ran level by level (R3D_OPT_STAGED, plans the single launch
+ * cannot hold) or none ran yet. */
+int r3d_last_clock(r3d_model *m, void *hip_stream, double *ghz);
 
 /* ---- per-clip error sums: the host side of Trainer.evaluate_core after the forward ---- */
 

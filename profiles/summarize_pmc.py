@@ -1,60 +1,97 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 output of profiles/prof_recipe.sh (per-dispatch PMC table of one forward).
-usage: python profiles/summarize_pmc.py gpurun_out/prof1 > profiles/<round>/pmc_table.txt"""
+"""Summarise the rocprofv3 output of profiles/prof_recipe.sh: the PMC table of the kernels the traced bench line times.
+
+usage: python profiles/summarize_pmc.py gpurun_out/<name> > profiles/<name>/pmc_table.txt
+       (also writes <dir>/pmc_summary.json: the figures bench.py merges into `roofline` through profiles/pmc.json)
+
+The kernel is picked BY NAME - `roofline.kernel` of the run's bench_line.json (r3d_forward_uv_f32 for the pixel-keypoint
+workloads, which also run the rays mode's r3d_forward_f32 for comparison) - and the last dispatch of that name in each PMC
+pass is taken; one table row per r3d_* kernel name of the pass.  Units as MI355X_MICROARCH.md prescribes: SQ_* quad-cycle
+counters x4, SQ_VALU_MFMA_BUSY_CYCLES in cycles, FETCH_SIZE x2 (gfx950 tallies 128-byte requests as 64), KiB -> bytes;
+clock = GRBM_GUI_ACTIVE / 8 XCDs / duration."""
 import collections
 import csv
 import glob
+import json
 import os
 import sys
 
+SIMDS = 256 * 4
+FLOP_PER_BUSY_CYCLE = {"f32": 64.0, "bf16x3": 1024.0 / 6.0}    # per SIMD: v_mfma_f32_32x32x2_f32 4096 FLOP / 64 cycles; bf16 32x32x16 / 6 products
+
+
+def base_name(n):
+    return n.split('(')[0].split('.')[0].strip()
+
 
 def load(d):
-    f = max(glob.glob(d + '/runc/*_counter_collection.csv'), key=os.path.getmtime)   # newest run
+    files = glob.glob(d + '/**/*_counter_collection.csv', recursive=True)
+    f = max(files, key=os.path.getmtime)
     per = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
         k = int(r['Dispatch_Id'])
-        per.setdefault(k, {'name': r['Kernel_Name'], 'grid': r['Grid_Size'], 't0': int(r['Start_Timestamp']),
+        per.setdefault(k, {'name': base_name(r['Kernel_Name']), 'grid': r['Grid_Size'], 't0': int(r['Start_Timestamp']),
                            't1': int(r['End_Timestamp'])})
         per[k][r['Counter_Name']] = float(r['Counter_Value'])
     return per
 
 
-def one_forward(per):
-    """Dispatches of the last complete forward: everything after the previous decoder launch up to and
-    including the last one (r3d_decode_f32 closes every forward)."""
-    ids = sorted(per)
-    ends = [i for i in ids if per[i]['name'].startswith('r3d_decode')]
-    s, e = ends[-2], ends[-1]
-    return [per[i] for i in ids if s < i <= e and per[i]['name'].startswith('r3d')]
+def last_by_name(per):
+    """{kernel name: its last dispatch of the pass} for the library's kernels, in order of first appearance."""
+    out = collections.OrderedDict()
+    for i in sorted(per):
+        if per[i]['name'].startswith('r3d'):
+            out[per[i]['name']] = per[i]
+    return out
 
 
-root = sys.argv[1]
-batch = '?'
-try:
-    import json
-    batch = json.load(open(root + '/bench_line.json'))['config']['batch_per_gpu']
-except Exception:
-    pass
-f1, f2, f3, f4 = (one_forward(load('%s/pmc%d' % (root, i))) for i in (1, 2, 3, 4))
-print('# one forward (B=%s, RF 243, pos+trj); cycles in millions (SQ_* quad-cycle counters x4); FETCH_SIZE x2 per '
-      'MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); clk = GRBM_GUI_ACTIVE / 8 XCDs / duration' % batch)
-print('%-20s %9s %8s %8s %8s %8s %8s %8s | %7s %6s | %8s %8s %5s' % (
-    'kernel', 'grid', 'dur_us', 'waveMcy', 'mfmaMcy', 'waitAny', 'waitInst', 'active', 'ldsIdxM', 'clkGHz', 'fetchMB',
-    'writeMB', 'L2hit'))
-for a, b, c, d in zip(f1, f2, f3, f4):
-    dur = (a['t1'] - a['t0']) / 1e3
-    print('%-20s %9s %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f | %7.2f %6.2f | %8.1f %8.1f %5.1f' % (
-        a['name'][:20], a['grid'], dur, a['SQ_WAVE_CYCLES'] * 4 / 1e6, a['SQ_VALU_MFMA_BUSY_CYCLES'] / 1e6,
-        a['SQ_WAIT_ANY'] * 4 / 1e6, a['SQ_WAIT_INST_ANY'] * 4 / 1e6, a['SQ_ACTIVE_INST_ANY'] * 4 / 1e6,
-        b['SQ_LDS_IDX_ACTIVE'] / 1e6, b['GRBM_GUI_ACTIVE'] / 8 / (b['t1'] - b['t0']), c['FETCH_SIZE'] * 2 / 1e3,
-        d['WRITE_SIZE'] / 1e3, 100 * d['TCC_HIT_sum'] / max(1, d['TCC_HIT_sum'] + d['TCC_MISS_sum'])))
+def main():
+    root = sys.argv[1]
+    line = {}
+    try:
+        line = json.load(open(root + '/bench_line.json'))
+    except Exception:
+        pass
+    cfg = line.get('config', {})
+    rl = line.get('roofline', {})
+    main_kernel = rl.get('kernel', 'r3d_forward_f32')
+    dtype = line.get('dtype', 'f32')
+    p1, p2, p3, p4 = (last_by_name(load('%s/pmc%d' % (root, i))) for i in (1, 2, 3, 4))
+    print('# one forward: %s windows, RF %s, %s joints (%s); timed kernel %s; cycles in millions (SQ_* quad-cycle counters x4); '
+          'FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B); clk = GRBM_GUI_ACTIVE / 8 XCDs / duration; busy = MFMA-busy '
+          'cycles / (1024 SIMDs x duration x clk)' % (cfg.get('batch_per_gpu', '?'), cfg.get('receptive_field', '?'), cfg.get('joints', '?'),
+                                                       str(cfg.get('workload', ''))[:40], main_kernel))
+    print('%-22s %9s %8s %8s %8s %8s %8s %8s %5s | %7s %6s | %8s %8s %5s' % (
+        'kernel', 'grid', 'dur_us', 'waveMcy', 'mfmaMcy', 'waitAny', 'waitInst', 'active', 'busy', 'ldsIdxM', 'clkGHz', 'fetchMB',
+        'writeMB', 'L2hit'))
+    summary = {}
+    for name, a in p1.items():
+        b, c, d = p2.get(name), p3.get(name), p4.get(name)
+        if not (b and c and d):
+            continue
+        dur = (a['t1'] - a['t0']) / 1e3                                   # us, pass 1 (the pass the SQ counters come from)
+        clk = b['GRBM_GUI_ACTIVE'] / 8 / (b['t1'] - b['t0'])              # cycles per ns = GHz (pass 2's own duration)
+        busy_frac = a['SQ_VALU_MFMA_BUSY_CYCLES'] / (SIMDS * dur * 1e3 * clk)
+        fetch, write = c['FETCH_SIZE'] * 2 * 1e3, d['WRITE_SIZE'] * 1e3   # bytes
+        l2 = 100 * d['TCC_HIT_sum'] / max(1, d['TCC_HIT_sum'] + d['TCC_MISS_sum'])
+        print('%-22s %9s %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f %5.2f | %7.2f %6.2f | %8.1f %8.1f %5.1f' % (
+            name[:22], a['grid'], dur, a['SQ_WAVE_CYCLES'] * 4 / 1e6, a['SQ_VALU_MFMA_BUSY_CYCLES'] / 1e6,
+            a['SQ_WAIT_ANY'] * 4 / 1e6, a['SQ_WAIT_INST_ANY'] * 4 / 1e6, a['SQ_ACTIVE_INST_ANY'] * 4 / 1e6, busy_frac,
+            b['SQ_LDS_IDX_ACTIVE'] / 1e6, clk, fetch / 1e6, write / 1e6, l2))
+        summary[name] = {"dur_us_pmc_pass": round(dur, 1), "clk_ghz_pmc_pass": round(clk, 3),
+                         "mfma_busy_cycles": a['SQ_VALU_MFMA_BUSY_CYCLES'], "mfma_busy_frac": round(busy_frac, 4),
+                         "executed_flops": a['SQ_VALU_MFMA_BUSY_CYCLES'] * FLOP_PER_BUSY_CYCLE.get(dtype, 64.0),
+                         "traffic_bytes": int(fetch + write), "fetch_bytes": int(fetch), "write_bytes": int(write),
+                         "l2_hit_pct": round(l2, 1)}
+    m = summary.get(main_kernel)
+    if m:
+        print('# %s: fetch %.1f MB + write %.1f MB = %d bytes per launch; MFMA-busy %.1f M SIMD-cycles over %.1f us at %.2f GHz = %.2f '
+              'of the SIMD-cycles; executed %.2f GFLOP' % (main_kernel, m['fetch_bytes'] / 1e6, m['write_bytes'] / 1e6, m['traffic_bytes'],
+                                                           m['mfma_busy_cycles'] / 1e6, m['dur_us_pmc_pass'], m['clk_ghz_pmc_pass'],
+                                                           m['mfma_busy_frac'], m['executed_flops'] / 1e9))
+    json.dump({"timed_kernel": main_kernel, "dtype": dtype, "batch_per_gpu": cfg.get('batch_per_gpu'),
+               "receptive_field": cfg.get('receptive_field'), "kernels": summary}, open(root + '/pmc_summary.json', 'w'), indent=1)
 
-MAIN = ('r3d_gemm', 'r3d_forward')      # the GEMM launches of the staged form / the single launch that holds all of them
-tot_f = sum(c['FETCH_SIZE'] * 2 / 1e3 for c in f3 if c['name'].startswith(MAIN))
-tot_w = sum(d['WRITE_SIZE'] / 1e3 for d in f4 if d['name'].startswith(MAIN))
-n = sum(1 for c in f3 if c['name'].startswith(MAIN))
-busy = sum(a['SQ_VALU_MFMA_BUSY_CYCLES'] for a in f1 if a['name'].startswith(MAIN))
-dur = sum((a['t1'] - a['t0']) / 1e3 for a in f1 if a['name'].startswith(MAIN))
-print('# %s: %d launch(es), fetch %.1f MB + write %.1f MB per forward = %.0f bytes per launch (profiles/traffic.json); '
-      'MFMA-busy %.1f M SIMD-cycles over %.1f us' % ('/'.join(sorted(set(c['name'].split('(')[0][:18] for c in f3 if c['name'].startswith(MAIN)))),
-                                                     n, tot_f, tot_w, (tot_f + tot_w) * 1e6 / max(n, 1), busy / 1e6, dur))
+
+if __name__ == '__main__':
+    main()

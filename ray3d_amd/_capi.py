@@ -23,9 +23,9 @@ EXPORTS = (
     "r3d_set_weight", "r3d_finalize", "r3d_workspace_bytes", "r3d_forward", "r3d_forward_pair",
     "r3d_profile_enable", "r3d_profile_read", "r3d_clip_metrics", "r3d_last_error", "r3d_version",
     "r3d_prepare", "r3d_release", "r3d_abi_version", "r3d_precision", "r3d_debug_schedule_check", "r3d_debug_plan_check",
-    "r3d_debug_forward_check", "r3d_status", "r3d_set_option",
+    "r3d_debug_forward_check", "r3d_status", "r3d_set_option", "r3d_last_clock",
 )
-ABI_VERSION = 4                                                          # R3D_ABI_VERSION of the header this binding follows
+ABI_VERSION = 5                                                          # R3D_ABI_VERSION of the header this binding follows
 METRIC_NAMES = ("mpjpe", "p_mpjpe", "n_mpjpe", "velocity", "root")     # R3D_METRIC_* order
 METRIC_OUT_DOUBLES = 5 * (1 + 128)                                      # R3D_METRIC_OUT_DOUBLES
 
@@ -82,6 +82,7 @@ def load():
     lib.r3d_precision.argtypes = [vp]
     lib.r3d_status.argtypes = [vp, vp]
     lib.r3d_set_option.argtypes = [vp, C.c_int32, C.c_int64]
+    lib.r3d_last_clock.argtypes = [vp, vp, C.POINTER(C.c_double)]
     lib.r3d_profile_enable.argtypes = [vp, C.c_int]
     lib.r3d_profile_read.argtypes = [vp, C.POINTER(LaunchRecord), C.c_int]
     lib.r3d_clip_metrics.argtypes = [vp, vp, C.c_int64, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp, vp]
@@ -151,6 +152,12 @@ class Handle:
             return False
         check(rc, "r3d_status")
         return True
+
+    def last_clock_ghz(self, stream: int) -> float:
+        """r3d_last_clock: the shader clock the handle's last single-launch forward ran at (0.0: none / level by level)."""
+        ghz = C.c_double(0.0)
+        check(load().r3d_last_clock(self.ptr, stream, C.byref(ghz)), "r3d_last_clock")
+        return float(ghz.value)
 
     def profile_enable(self, on: bool):
         check(load().r3d_profile_enable(self.ptr, 1 if on else 0), "r3d_profile_enable")

@@ -372,8 +372,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         fa.spin_ticks = (long long)std::max(a->spin_timeout_ms, 1) * 100000LL;          // 100 MHz wall clock
         if (const char *ft = getenv("R3D_FAULT_TILE")) fa.fault_tile1 = atoi(ft) + 1;   // test hook: see FwdArgs
         const bool uv_launch = uv && fw.uses_gather;
-        const char *fwd_name = fw.kernel == FWD_KERNEL_W4 ? (uv_launch ? "r3d_forward4_uv_f32" : "r3d_forward4_f32") : forward_kernel_name(fw.kernel, uv_launch);
-        if ((e = rec.begin(fwd_name, stage_no, fw.grid, fw.flops, fw.bytes)) != hipSuccess)
+        if ((e = rec.begin(forward_kernel_name(fw.kernel, uv_launch), stage_no, fw.grid, fw.flops, fw.bytes)) != hipSuccess)
             return hip_fail(e, "hipEventRecord");
 #ifdef R3D_TIMING
         static long long *timing_buf1 = nullptr;
@@ -384,8 +383,8 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             if (fw.ntiles <= 65536) fa.dbg = timing_buf1;
         }
 #endif
-        if ((e = fw.kernel == FWD_KERNEL_W4 ? launch_forward4(fa, fw.grid, uv_launch, stream) : launch_forward(fa, fw.grid, fw.kernel, uv_launch, stream)) != hipSuccess)
-            return hip_fail(e, "launch r3d_forward_f32");
+        if ((e = launch_forward(fa, fw.grid, fw.kernel, uv_launch, stream)) != hipSuccess) return hip_fail(e, "launch r3d_forward_f32");
+        a->last_clk_dev = cap == hipStreamCaptureStatusNone ? cnt + fw.ncnt + 2 : nullptr;   // (a captured call runs later, maybe never)
         if ((e = order_single_launch(stream, false)) != hipSuccess) return hip_fail(e, "hipEventRecord");
         if (own) {                     // the next call on these buffers needs no bind
             bd.valid = true;
@@ -440,6 +439,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         ++stage_no;
         abort_flag = cnt + fw.ncnt;
     }
+    if (!single) a->last_clk_dev = nullptr;
     // ---- (staged form) persistent GEMM launches, one per DAG level
     for (size_t si = 0; !single && si < sched->levels->size(); ++si) {
         const auto &st = (*sched->levels)[si];
@@ -458,11 +458,10 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             if (rc != R3D_OK) return rc;
         }
         if (n_enc != 0 && n_enc != la.nprob) { set_error("internal: launch mixes encoded and plain operands"); return R3D_ERR_STATE; }
-        if ((n_enc != 0) != (ss.kind == STAGE_ENC) && ss.kind != STAGE_W4) { set_error("internal: schedule and plan disagree on the launch kind"); return R3D_ERR_STATE; }
+        if ((n_enc != 0) != (ss.kind == STAGE_ENC)) { set_error("internal: schedule and plan disagree on the launch kind"); return R3D_ERR_STATE; }
         bool uv_launch = false;                             // UV mode: only the launches that gather from the input
         for (int i = 0; i < la.nprob; ++i) uv_launch = uv_launch || la.p[i].cam != nullptr;
-        const char *kname = ss.kind == STAGE_W4 ? (uv_launch ? "r3d_gemm4_uv_f32" : "r3d_gemm4_f32")
-                          : ss.kind == STAGE_ENC ? (uv_launch ? "r3d_gemm_enc_uv_f32" : "r3d_gemm_enc_f32")
+        const char *kname = ss.kind == STAGE_ENC ? (uv_launch ? "r3d_gemm_enc_uv_f32" : "r3d_gemm_enc_f32")
                                                  : (uv_launch ? "r3d_gemm_uv_f32" : "r3d_gemm_f32");
         if ((e = rec.begin(kname, stage_no, ss.nwg, ss.flops, ss.bytes)) != hipSuccess) return hip_fail(e, "hipEventRecord");
 #ifdef R3D_TIMING
@@ -476,8 +475,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             la.dbg = timing_buf;
         }
 #endif
-        if ((e = ss.kind == STAGE_W4 ? launch_gemm4_stage(la, ss.nwg, uv_launch, stream) : launch_gemm_stage(la, ss.nwg, ss.kind, uv_launch, stream)) != hipSuccess)
-            return hip_fail(e, "launch r3d_gemm_f32");
+        if ((e = launch_gemm_stage(la, ss.nwg, ss.kind, uv_launch, stream)) != hipSuccess) return hip_fail(e, "launch r3d_gemm_f32");
 #ifdef R3D_TIMING
         if (timed) {
             (void)hipStreamSynchronize(stream);
@@ -708,7 +706,7 @@ int r3d_debug_schedule_check(int nprob, const int *M, const int *N, const int *n
     std::vector<std::vector<int>> cover(nprob);
     for (int i = 0; i < nprob; ++i) cover[i].assign((size_t)((M[i] + 31) / 32) * ((N[i] + COL_GRANULE - 1) / COL_GRANULE), 0);
     for (const int4 &t : tiles) {
-        const int pi = t.x & 0xff, mi = t.x >> 8, ks = tile_code(t.w);
+        const int pi = t.x & 0xff, mi = t.x >> 8, ks = t.w;
         if (pi >= nprob || mi < 1 || (ks != 1 && ks != 2 && ks != 4 && ks != 8 && ks != 16)) return -4;
         if (ks < 8 && ks > max_ks[pi]) return -5;
         if ((ks == 1 && mi > (max_units[pi] > 0 ? std::min(max_units[pi], GEMM_SCHED_MAX_UNITS) : GEMM_SCHED_MAX_UNITS)) || (ks == 2 && mi > 2) || (ks >= 4 && mi != 1)) return -6;
@@ -739,8 +737,7 @@ int r3d_debug_plan_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg,
     std::vector<int4> tiles;
     std::vector<int> wgoff;
     std::vector<StageSchedule> stages;
-    const bool w4 = use_w4(pl, batch);
-    const std::vector<std::vector<int>> &levels = *schedule_build_host(pl, batch, nwg, spill_row0, tiles, wgoff, stages, w4);
+    const std::vector<std::vector<int>> &levels = *schedule_build_host(pl, batch, nwg, spill_row0, tiles, wgoff, stages);
     if (launches) *launches = (int)stages.size();
     if (spilled) *spilled = 0;
     const int np = (int)pl->probs.size();
@@ -763,7 +760,7 @@ int r3d_debug_plan_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg,
         }
         for (int t = 0; t < ss.ntiles; ++t) {
             const int4 &tl = tiles[ss.tiles_off + t];
-            const int slot = tl.x & 0xff, mi = tl.x >> 8, ks = tl.w;      // (ks: the whole code word - tile_cols reads the width from it)
+            const int slot = tl.x & 0xff, mi = tl.x >> 8, ks = tl.w;
             if (slot >= (int)st.size() || mi < 1) return -4;
             const int id = st[slot] & ~STAGE_SPILL_IN;
             const ProbSpec &q = pl->probs[id];
@@ -777,7 +774,7 @@ int r3d_debug_plan_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg,
             const int gcols = (N + COL_GRANULE - 1) / COL_GRANULE;
             for (int u = tl.y / 32; u < tl.y / 32 + mi; ++u) {
                 if (u * 32 >= M) return -7;
-                for (int g = tl.z / COL_GRANULE; g < (tl.z + tile_cols(ks)) / COL_GRANULE && g < gcols; ++g) ++cover[id][(size_t)u * gcols + g];
+                for (int g = tl.z / COL_GRANULE; g < (tl.z + tile_width(ks)) / COL_GRANULE && g < gcols; ++g) ++cover[id][(size_t)u * gcols + g];
             }
             last_launch[id] = std::max(last_launch[id], (int)si);
             first_launch[id] = std::min(first_launch[id], (int)si);
@@ -807,11 +804,10 @@ int r3d_debug_forward_check(r3d_model *pos, r3d_model *trj, int64_t batch, int n
     std::vector<int4> tiles;
     std::vector<int> wgoff;
     std::vector<StageSchedule> stages;
-    const bool w4 = use_w4(pl, batch);
-    const std::vector<std::vector<int>> &levels = *schedule_build_host(pl, batch, nwg, spill_row0, tiles, wgoff, stages, w4);
+    const std::vector<std::vector<int>> &levels = *schedule_build_host(pl, batch, nwg, spill_row0, tiles, wgoff, stages);
     Schedule::Fwd fw;
     std::vector<int> ft, fo;
-    if (!schedule_build_fwd(pl, batch, w4 ? 2 * nwg : nwg, levels, stages, tiles, wgoff, fw, ft, fo)) return 1;
+    if (!schedule_build_fwd(pl, batch, nwg, levels, stages, tiles, wgoff, fw, ft, fo)) return 1;
     if (out_tiles) *out_tiles = fw.ntiles;
     if (out_counters) *out_counters = fw.ncnt;
     const int np = (int)pl->probs.size(), TI = FWD_TILE_INT4 * 4;
@@ -938,6 +934,19 @@ int r3d_set_option(r3d_model *m, int32_t option, int64_t value) {
     }
 }
 
+int r3d_last_clock(r3d_model *m, void *stream, double *ghz) {
+    Model *mm = reinterpret_cast<Model *>(m);
+    if (!mm || !ghz) { r3d::set_error("r3d_last_clock: null argument"); return R3D_ERR_ARG; }
+    *ghz = 0.0;
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return r3d::hip_fail(e, "hipStreamSynchronize");
+    if (!mm->last_clk_dev) return R3D_OK;
+    unsigned w[2] = {0u, 0u};
+    if ((e = hipMemcpy(w, mm->last_clk_dev, sizeof w, hipMemcpyDeviceToHost)) != hipSuccess) return r3d::hip_fail(e, "hipMemcpy(clock stamp)");
+    if (w[1] > 0u) *ghz = (double)w[0] / ((double)w[1] * 10.0);      // cycles per 10 ns tick
+    return R3D_OK;
+}
+
 int r3d_status(r3d_model *m, void *stream) {
     Model *mm = reinterpret_cast<Model *>(m);
     if (!mm) { r3d::set_error("r3d_status: null model"); return R3D_ERR_ARG; }
@@ -954,7 +963,7 @@ int r3d_status(r3d_model *m, void *stream) {
 }
 
 const char *r3d_last_error(void) { return r3d::last_error(); }
-const char *r3d_version(void) { return "ray3d_hip 0.4 (gfx950, ABI 4)"; }
+const char *r3d_version(void) { return "ray3d_hip 0.5 (gfx950, ABI 5)"; }
 int r3d_abi_version(void) { return R3D_ABI_VERSION; }
 int r3d_precision(const r3d_model *m) {
     if (!m) { r3d::set_error("r3d_precision: null model"); return R3D_ERR_ARG; }

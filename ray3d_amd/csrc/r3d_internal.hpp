@@ -108,8 +108,7 @@ struct FwdArgs {
                               // its n-th GEMV tile neither stores nor reports (0: none; n + 1 stored)
     long long *dbg;
 };
-enum { FWD_KERNEL_F32 = 0, FWD_KERNEL_B3 = 1, FWD_KERNEL_LAT = 2, FWD_KERNEL_COUNT = 3, FWD_KERNEL_W4 = 3 };   // specialisations of the single-launch forward
-                                                                                             // (W4: r3d_kernels4.hip, 256-thread workgroups, two per CU)
+enum { FWD_KERNEL_F32 = 0, FWD_KERNEL_B3 = 1, FWD_KERNEL_LAT = 2, FWD_KERNEL_COUNT = 3 };   // specialisations of the single-launch forward
 constexpr int BIND_NPTR = 18;  // pointer fields of a GemmProb, in the order r3d_bind_f32 walks them
 enum { BIND_NULL = 0, BIND_WS, BIND_ARENA0, BIND_ARENA1, BIND_IARENA0, BIND_IARENA1, BIND_X, BIND_PARAM, BIND_CAM, BIND_NBASE };
 struct BindArgs {
@@ -229,6 +228,7 @@ struct Model {
     // r3d_set_option
     bool opt_staged = false;          // this handle's forwards run one launch per level (no co-residency assumption)
     int spin_timeout_ms = 1000;       // bound of a dependency wait of the single-launch forward
+    const unsigned *last_clk_dev = nullptr;   // the clock stamp of the last single-launch forward (two words of its counter bank: r3d_last_clock)
     unsigned *status_host = nullptr;  // pinned host word the decoder kernel raises when a wait gave up (r3d_status reads and clears it)
     // profiling
     bool profiling = false;
@@ -286,7 +286,6 @@ struct StageSchedule {
 
 struct Schedule {
     int64_t B = 0;
-    bool w4 = false;       // built for the four-wave kernels (r3d_kernels4.hip): 2 x CUs bins, tiles of 128 / 256 columns
     bool pinned = false;   // named in r3d_prepare: never evicted (a captured hipGraph holds its device pointers) until r3d_release
     int spill_row0 = -1;   // rows [spill_row0, M) of Plan::spill_prob run in the following launch; -1: the plain
                            // level assignment (Plan::stages / stages_alt) is in use, else Plan::stages_spill / _alt
@@ -402,38 +401,19 @@ struct SchedProb {
     int row0 = 0;    // first row this launch computes (a multiple of 32): rows [row0, M)
     bool gemv = false;   // M <= GEMV_ROWS rows of a plain layer: 32-column GEMV tiles (tile code ks == 8), r3d_kernels.hip gemv_tile
     bool lat = false;    // ... of up to 32 rows: 32-column latency tiles on the matrix cores (tile code 16), lat_tile
-    int colw = 256;      // width of the problem's column blocks = of its whole tiles (four-wave mode: 128 for plain layers)
 };
-constexpr int FWD_W4_LUT_BYTES = 320 * 4;   // first-layer tables at the end of a four-wave workgroup's LDS (FL_LUT_INTS ints)
 constexpr int GEMV_ROWS = 4;          // == GEMV_MAX_M of the kernels (at eight rows the MFMA split-K tiles are the faster ones: 0.207 against 0.222 ms)
 constexpr int COL_GRANULE = 32;       // ready counters and cover checks count columns in granules of this many
 inline int tile_width(int ks) { return ks >= 8 ? 32 : 256 / ks; }     // columns of a tile by its split code (8: a GEMV tile, 16: a latency tile)
-// A tile descriptor's fourth int: the split code in the low byte; above it, in four-wave mode (r3d_kernels4.hip), the tile's
-// width in 32-column granules (4: a wavefront owns one column block, 8: two).
-inline int tile_code(int w) { return w & 0xff; }
-// Four-wave mode: which chunk (bin of the packer) workgroup b of a grid of n = 2 x CUs runs.  Observed on MI355X (tools/
-// wgmap_probe.cpp; speed only, nothing depends on it for correctness): workgroup b runs on XCD b % 8, and b and b + n / 2
-// share a CU.  The packer fills its bins from 0 upwards, so bins [0, n / 2) go to the workgroups that come first on their
-// CU - a launch of <= n / 2 tiles gets a CU per tile - and within each half an XCD gets a contiguous run of bins
-// (neighbouring bins share weights through that XCD's L2).
-__host__ __device__ inline int w4_chunk_of(int b, int n) {
-    const int per = n / 16, xcd = b & 7, idx = b >> 3;           // per: CUs per XCD
-    if (per < 1 || n % 16) return b;
-    return (idx < per ? 0 : n / 2) + xcd * per + (idx < per ? idx : idx - per);
-}
-inline int tile_cols(int w) { return (w >> 8) ? (w >> 8) * 32 : tile_width(w & 0xff); }
 void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units, std::vector<int4> &tiles,
-                    std::vector<int> &wgoff, StageSchedule &out, bool enc = false, bool w4 = false);
+                    std::vector<int> &wgoff, StageSchedule &out, bool enc = false);
 // index of weight element (output channel o, GEMM column k) in the fragment-ordered packing
 inline size_t frag_index(int o, int k, int nk) {
     const int nb = o >> 5, li = o & 31, kt = k >> 5, kin = k & 31, lh = kin >> 4, q = (kin & 15) >> 2, e = kin & 3;
     return ((((size_t)nb * nk + kt) * 4 + q) * 64 + (lh * 32 + li)) * 4 + e;
 }
 const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t B, int nwg, int &spill_row0, std::vector<int4> &tiles,
-                                                        std::vector<int> &wgoff, std::vector<StageSchedule> &stages, bool w4 = false);
-// Four-wave mode (r3d_kernels4.hip): the call's tiles run in 256-thread workgroups, two per CU, scheduled as 2 x CUs bins.
-// For the fp32 arithmetic of calls that run no GEMV / latency tiles, on plans whose first level is fused (<= 256 channels).
-bool use_w4(const Plan *pl, int64_t B);
+                                                        std::vector<int> &wgoff, std::vector<StageSchedule> &stages);
 bool schedule_build_fwd(const Plan *pl, int64_t B, int nwg, const std::vector<std::vector<int>> &levels, const std::vector<StageSchedule> &stages,
                         const std::vector<int4> &tiles, const std::vector<int> &wgoff, Schedule::Fwd &fw, std::vector<int> &out_tiles,
                         std::vector<int> &out_wgoff);
@@ -441,15 +421,12 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin = false);   // nul
 int device_cu_count();
 
 // kernel launchers (r3d_kernels.hip)
-enum { STAGE_BIG = 0, STAGE_ENC = 1, STAGE_W4 = 2 };   // r3d_gemm_f32 / r3d_gemm_enc_f32 / r3d_gemm4_f32
+enum { STAGE_BIG = 0, STAGE_ENC = 1 };   // r3d_gemm_f32 / r3d_gemm_enc_f32
 hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, int kind, bool uv, hipStream_t stream);   // uv: the launch gathers pixel keypoints
 hipError_t launch_decode(const DecodeArgs &args, hipStream_t stream);
 hipError_t launch_forward(const FwdArgs &args, int nwg, int kind, bool uv, hipStream_t stream);
 const char *forward_kernel_name(int kind, bool uv);
 int forward_resident_capacity(int kind, bool uv);      // workgroups of that kernel the current device holds at once (0: unknown)
-hipError_t launch_gemm4_stage(const LaunchArgs &args, int nwg, bool uv, hipStream_t stream);      // r3d_kernels4.hip
-hipError_t launch_forward4(const FwdArgs &args, int nwg, bool uv, hipStream_t stream);
-int forward4_resident_capacity();
 hipError_t launch_bind(const BindArgs &args, hipStream_t stream);
 bool forward_single_launch();   // the single-launch form is in use (R3D_STAGED=1 turns it off)
 size_t fwd_ctrl_bytes(const Plan *pl, int64_t B);   // workspace bytes behind the activations: counters + problem table

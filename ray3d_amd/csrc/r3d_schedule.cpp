@@ -68,20 +68,7 @@ static void dump_fwd(const Plan *pl, int64_t B, int grid, const std::vector<int>
 }
 
 static int64_t units_of(int64_t B, const ProbSpec &q) { return (B * q.rows_per_window + 31) / 32; }
-static SchedProb sched_prob_of(const Plan *pl, const ProbSpec &q, int64_t B, bool w4);
-
-bool use_w4(const Plan *pl, int64_t B) {
-    static const bool on = env_on("R3D_W4");
-    if (!on || pl->kind == PLAN_SMALL || B < 64) return false;
-    for (const Model *m : pl->m)
-        if (m && ((m->use_b3 && B >= b3_min_batch()) || m->cfg.dense || m->cfg.channels > N_ALIGN)) return false;
-    bool fused_first = false;
-    for (const auto &q : pl->probs) {
-        if (q.enc_kernel) return false;               // (a first level the fused tile does not cover)
-        fused_first = fused_first || q.layer3 >= 0;
-    }
-    return fused_first;
-}
+static SchedProb sched_prob_of(const Plan *pl, const ProbSpec &q, int64_t B);
 
 size_t fwd_ctrl_bytes(const Plan *pl, int64_t B) {
     int64_t ncnt = 0;
@@ -101,7 +88,7 @@ bool schedule_build_fwd(const Plan *pl, int64_t B, int nwg, const std::vector<st
     const int np = (int)pl->probs.size();
     if (np > 255) return false;
     for (const auto &ss : stages)
-        if (ss.kind != STAGE_BIG && ss.kind != STAGE_W4) return false;
+        if (ss.kind != STAGE_BIG) return false;
     for (const Model *m : pl->m)
         if (m && m->cfg.dense) return false;      // (the dense ablation's overlapping operand rows are not row-local per 32-row unit)
     fw.nprob = np;
@@ -123,7 +110,7 @@ bool schedule_build_fwd(const Plan *pl, int64_t B, int nwg, const std::vector<st
     for (size_t si = 0; si < stages.size(); ++si)
         for (int t = 0; t < stages[si].ntiles; ++t) {
             const int4 &tl = tiles[stages[si].tiles_off + t];
-            if (tile_code(tl.w) >= 8) narrow[levels[si][tl.x & 0xff] & ~STAGE_SPILL_IN] = 1;
+            if (tl.w >= 8) narrow[levels[si][tl.x & 0xff] & ~STAGE_SPILL_IN] = 1;
         }
     for (int i = 0; i < np; ++i)
         for (int dp : pl->probs[i].deps)
@@ -140,7 +127,7 @@ bool schedule_build_fwd(const Plan *pl, int64_t B, int nwg, const std::vector<st
         for (int b = 0; b < n; ++b) {
             // the chunk workgroup b takes in the staged launch of this level (XCD-aware order, r3d_kernels.hip)
             const int xcd = b & 7, idx = b >> 3;
-            const int c = ss.kind == STAGE_W4 ? w4_chunk_of(b, n) : (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + idx;
+            const int c = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + idx;
             if (c >= n) continue;                  // (n < 8: workgroups b >= n do not exist in the staged launch either)
             for (int t = wgoff[ss.wgoff_off + c]; t < wgoff[ss.wgoff_off + c + 1]; ++t) {
                 const int4 &tl = tiles[ss.tiles_off + t];
@@ -154,7 +141,7 @@ bool schedule_build_fwd(const Plan *pl, int64_t B, int nwg, const std::vector<st
                 d[3] = ks;
                 d[5] = fw.cnt_base[id] + tl.y / 32;
                 {   // granules of 64 columns this tile completes for each of its units
-                    const int g0 = tl.z / COL_GRANULE, g1 = std::min(gcols[id], (tl.z + tile_cols(ks)) / COL_GRANULE);
+                    const int g0 = tl.z / COL_GRANULE, g1 = std::min(gcols[id], (tl.z + tile_width(ks)) / COL_GRANULE);
                     d[6] = std::max(g1 - g0, 0);
                     if (d[6] <= 0) return false;
                 }
@@ -391,9 +378,9 @@ void pack(const std::vector<SchedProb> &probs, int nbins_max, int max_units, Pac
         const SchedProb &p = probs[i];
         const int units = (std::max(p.M - p.row0, 0) + 31) / 32;
         const double c1 = unit_cycles(p.nk + p.nk2, 1);
-        for (int c0 = 0; c0 < p.N; c0 += p.colw) {
+        for (int c0 = 0; c0 < p.N; c0 += 256) {
             Seg sg{i, c0, units, p.nk, p.max_units > 0 ? std::min(p.max_units, max_units) : max_units, p.max_ks, c1,
-                   std::min(p.colw, p.N - c0)};
+                   std::min(256, p.N - c0)};
             sg.gemv = (p.gemv || p.lat) && units == 1 && p.row0 == 0;
             sg.code = p.gemv ? 8 : 16;
             segs.push_back(sg);
@@ -444,15 +431,11 @@ void pack(const std::vector<SchedProb> &probs, int nbins_max, int max_units, Pac
 }  // namespace
 
 void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units, std::vector<int4> &tiles,
-                    std::vector<int> &wgoff, StageSchedule &out, bool enc, bool w4) {
+                    std::vector<int> &wgoff, StageSchedule &out, bool enc) {
     Packed big;
     const Packed *best = &big;
-    out.kind = w4 ? STAGE_W4 : enc ? STAGE_ENC : STAGE_BIG;
-    // (experiment, R3D_W4_SOLO=1: launches of plain layers only get ONE bin per CU - bins [0, nwg / 2) are the workgroups
-    //  that come first on their CU - so that an M = B layer runs as 64 x 128 tiles that have their CU to themselves)
-    bool solo = w4 && env_on("R3D_W4_SOLO");
-    for (const SchedProb &p : probs) solo = solo && p.colw == 128 && p.nk2 == 0;
-    pack(probs, solo ? nwg / 2 : nwg, max_units, big);
+    out.kind = enc ? STAGE_ENC : STAGE_BIG;
+    pack(probs, nwg, max_units, big);
     out.ks = 1;
     out.tiles_off = tiles.size();
     out.wgoff_off = wgoff.size();
@@ -460,15 +443,14 @@ void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units,
     int grid = 0;
     wgoff.push_back(0);
     for (const auto &bin : best->a.bins) {
-        if (bin.empty() && !w4) continue;          // (four-wave mode: bin i IS chunk i of a grid of nwg workgroups, empty or not)
+        if (bin.empty()) continue;
         for (const Run &r : bin) {
             // emit the run as evenly sized tiles of <= cap units
             const int nt = (r.n + r.cap - 1) / r.cap;
             int done = 0;
             for (int k = 0; k < nt; ++k) {
                 const int sz = (r.n - done + (nt - k) - 1) / (nt - k);
-                tiles.push_back(make_int4(r.prob | (sz << 8), probs[r.prob].row0 + (r.u0 + done) * 32, r.col0,
-                                          r.ks | (w4 ? (probs[r.prob].colw / 32) << 8 : 0)));
+                tiles.push_back(make_int4(r.prob | (sz << 8), probs[r.prob].row0 + (r.u0 + done) * 32, r.col0, r.ks));
                 done += sz;
             }
             out.ks = std::max(out.ks, r.ks);
@@ -476,8 +458,6 @@ void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units,
         wgoff.push_back((int)(tiles.size() - t0));
         ++grid;
     }
-    if (w4)
-        for (; grid < nwg; ++grid) wgoff.push_back((int)(tiles.size() - t0));
     if (grid == 0) { wgoff.push_back(0); grid = 1; }
     if (const char *e = getenv("R3D_SCHED_DUMP")) {   // development aid: the chunks of every launch, one line per workgroup
         (void)e;
@@ -503,32 +483,8 @@ void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units,
 
 // What the packers need to know about one problem of the plan at B windows: K-loop iterations of a 32-row unit (nk, plus
 // nk2 for the further layers of fused tiles and for measured extras), how far it may be cut along K, the tile height cap.
-static SchedProb sched_prob_of(const Plan *pl, const ProbSpec &q, int64_t B, bool w4) {
+static SchedProb sched_prob_of(const Plan *pl, const ProbSpec &q, int64_t B) {
         const Layer &L = pl->m[q.model]->layers[q.layer];
-        if (w4) {
-            // Four-wave mode: a bin is a 256-thread workgroup that shares its CU with another one.  A plain layer's unit is
-            // 32 rows x 128 columns - in such a workgroup about the time of a 32 x 256 unit on a whole CU, so the cost model's
-            // cycles stand - in tiles of up to four units; fused pairs (<= 64 rows) and the fused first level (32 rows) span
-            // all 256 columns: twice the cycles.  No split-K, no GEMV / latency tiles (calls of >= 64 windows).
-            const Model *mm = pl->m[q.model];
-            SchedProb sp{(int)(B * q.rows_per_window), L.N, L.Kpad / BK, 1, 4};
-            sp.colw = 128;
-            if (q.layer3 >= 0) {
-                sp.colw = 256;
-                sp.max_units = 1;
-                sp.nk2 = 2 * sp.nk + mm->layers[q.layer2].Kpad / BK + mm->layers[q.layer3].Kpad / BK + (int)(L.Kpad <= 64 ? cost_model().first_extra : cost_model().first_extra_wide);
-                sp.nk2 = 2 * (sp.nk + sp.nk2) - sp.nk;
-            } else if (q.layer2 >= 0) {
-                sp.colw = 256;
-                sp.max_units = 2;
-                sp.nk2 = (int)(mm->layers[q.layer2].Kpad / BK * cost_model().pair_scale + 0.5);
-                sp.nk2 = 2 * (sp.nk + sp.nk2) - sp.nk;
-            } else if (q.enc_lut >= 0) {
-                sp.max_units = std::max(1, std::min(4, (80 * 1024 - FWD_W4_LUT_BYTES) / ((L.Kpad + 4) * 4 * 32)));
-                sp.nk2 = 2;
-            }
-            return sp;
-        }
         const int M = (int)(B * q.rows_per_window);
         // fused-prologue tiles hold the whole encoded operand in 64 KiB of LDS: rows * (K + 4) floats
         const int enc_cap = q.enc_lut >= 0 ? std::max(1, std::min(3, (64 * 1024) / ((L.Kpad + 4) * 4 * 32))) : 0;
@@ -596,7 +552,7 @@ struct StageMemo {
 static thread_local std::map<std::vector<int>, StageMemo> g_stage_memo;     // per schedule_build_host call
 
 static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, int nwg, int spill_row0, std::vector<int4> &tiles,
-                        std::vector<int> &wgoff, StageSchedule &out, bool w4) {
+                        std::vector<int> &wgoff, StageSchedule &out) {
     std::vector<SchedProb> probs;
     double flops = 0, bytes = 0;
     for (int i = 0; i < (int)st.size(); ++i) {
@@ -608,7 +564,7 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
         if (st[i] & STAGE_SPILL_IN) row0 = spill_row0 >= 0 ? spill_row0 : M_all;
         else if (id == pl->spill_prob && spill_row0 >= 0) M = spill_row0;
         const double share = M_all > 0 ? (double)(M - row0) / M_all : 0.0;
-        SchedProb sp = sched_prob_of(pl, q, B, w4);
+        SchedProb sp = sched_prob_of(pl, q, B);
         sp.M = M;
         sp.row0 = row0;
         probs.push_back(sp);
@@ -622,14 +578,14 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
     for (int e : st) enc = enc || pl->probs[e & ~STAGE_SPILL_IN].enc_kernel;
     // The level assignments and spill candidates schedule_build_host compares differ in two or three launches only: a
     // launch's packing is a function of its problems' shapes, so it is computed once per distinct launch of a build.
-    std::vector<int> key{enc ? 1 : 0, nwg, w4 ? 1 : 0};
+    std::vector<int> key{enc ? 1 : 0, nwg};
     for (const SchedProb &sp : probs)
-        key.insert(key.end(), {sp.M, sp.N, sp.nk, sp.max_ks, sp.max_units, sp.nk2, sp.row0, sp.gemv ? 1 : sp.lat ? 2 : 0, sp.colw});
+        key.insert(key.end(), {sp.M, sp.N, sp.nk, sp.max_ks, sp.max_units, sp.nk2, sp.row0, sp.gemv ? 1 : sp.lat ? 2 : 0});
     auto hit = g_stage_memo.find(key);
     if (hit == g_stage_memo.end()) {
         StageMemo m;
         // the fused-prologue kernel runs two workgroups per CU (one encodes while the other multiplies)
-        schedule_stage(probs, enc || w4 ? 2 * nwg : nwg, GEMM_SCHED_MAX_UNITS, m.tiles, m.wgoff, m.ss, enc, w4);
+        schedule_stage(probs, enc ? 2 * nwg : nwg, GEMM_SCHED_MAX_UNITS, m.tiles, m.wgoff, m.ss, enc);
         hit = g_stage_memo.emplace(key, std::move(m)).first;
     }
     const StageMemo &m = hit->second;
@@ -645,7 +601,7 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
 // Host part of schedule_get: picks the level assignment and the row spill for this batch size by the modelled
 // length of the launches (sum over launches of the longest chunk), then builds every launch's tile lists.
 const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t B, int nwg, int &spill_row0, std::vector<int4> &tiles,
-                                                        std::vector<int> &wgoff, std::vector<StageSchedule> &stages, bool w4) {
+                                                        std::vector<int> &wgoff, std::vector<StageSchedule> &stages) {
     spill_row0 = -1;
     g_stage_memo.clear();
     const std::vector<std::vector<int>> *levels = &pl->stages;
@@ -656,7 +612,7 @@ const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t
         double sum = 0;
         for (const auto &st : lv) {
             StageSchedule a{};
-            build_stage(pl, st, B, nwg, row0, t, w, a, w4);
+            build_stage(pl, st, B, nwg, row0, t, w, a);
             ss.push_back(a);
             sum += a.makespan;
         }
@@ -685,14 +641,13 @@ const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t
         long long fl_tiles = 0;
         for (int e : lv[std::max(s0, 0)])
             if (!(e & STAGE_SPILL_IN) && pl->probs[e].layer3 >= 0) fl_tiles += (B * pl->probs[e].rows_per_window + 31) / 32;
-        if (!(s0 >= 0 && s1 >= 0 && fl_tiles > (w4 ? 2 * nwg : nwg))) return;
+        if (!(s0 >= 0 && s1 >= 0 && fl_tiles > nwg)) return;
         // candidates for the tiles that run late: none, the remainder of the division of the first-level tiles by
         // the CU count, and multiples of 32 up to half a round
-        const int nslots = w4 ? 2 * nwg : nwg;
-        const long long rem = fl_tiles % nslots;
+        const long long rem = fl_tiles % nwg;
         std::vector<long long> cands{0};
-        if (rem > 0 && rem <= nslots / 2) cands.push_back(rem);
-        for (long long r = 32; r <= nslots / 2; r += 32)
+        if (rem > 0 && rem <= nwg / 2) cands.push_back(rem);
+        for (long long r = 32; r <= nwg / 2; r += 32)
             if (r != rem) cands.push_back(r);
         double best = 0;
         int best_row0 = M_all;
@@ -705,8 +660,8 @@ const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t
             std::vector<int4> t;
             std::vector<int> w;
             StageSchedule a{}, b{};
-            build_stage(pl, lv[s0], B, nwg, row0, t, w, a, w4);
-            build_stage(pl, lv[s1], B, nwg, row0, t, w, b, w4);
+            build_stage(pl, lv[s0], B, nwg, row0, t, w, a);
+            build_stage(pl, lv[s1], B, nwg, row0, t, w, b);
             const double cost = a.makespan + b.makespan;
             if (r == 0 || cost < best * 0.995) { best = cost; best_row0 = row0; }
         }
@@ -758,6 +713,8 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
             if (victim != pl->schedule_lru.end() && hipDeviceSynchronize() == hipSuccess) {
                 const int64_t old = *victim;
                 pl->schedule_lru.erase(victim);
+                for (const Model *mm : pl->m)                  // (r3d_last_clock must not read a freed control region)
+                    if (mm) const_cast<Model *>(mm)->last_clk_dev = nullptr;
                 delete pl->schedules[old];
                 pl->schedules.erase(old);
             } else {
@@ -767,10 +724,9 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
     }
     Schedule *s = new Schedule();
     s->B = B;
-    s->w4 = use_w4(pl, B);
     std::vector<int4> tiles;
     std::vector<int> wgoff;
-    s->levels = schedule_build_host(pl, B, nwg, s->spill_row0, tiles, wgoff, s->stages, s->w4);
+    s->levels = schedule_build_host(pl, B, nwg, s->spill_row0, tiles, wgoff, s->stages);
     hipError_t e;
     if ((e = hipMalloc((void **)&s->d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(int4))) != hipSuccess ||
         (e = hipMalloc((void **)&s->d_wgoff, std::max<size_t>(wgoff.size(), 1) * sizeof(int))) != hipSuccess ||
@@ -784,7 +740,7 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
     if (forward_single_launch()) {
         std::vector<int> ft, fo;
         Schedule::Fwd &fw = s->fwd;
-        if (schedule_build_fwd(pl, B, s->w4 ? 2 * nwg : nwg, *s->levels, s->stages, tiles, wgoff, fw, ft, fo)) {
+        if (schedule_build_fwd(pl, B, nwg, *s->levels, s->stages, tiles, wgoff, fw, ft, fo)) {
             const Model *a = pl->m[0];
             bool ok = (e = hipMalloc((void **)&fw.d_tiles, ft.size() * sizeof(int))) == hipSuccess &&
                       (e = hipMalloc((void **)&fw.d_wgoff, fo.size() * sizeof(int))) == hipSuccess &&
@@ -813,15 +769,15 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
                 ok = (e = hipMalloc((void **)&fw.d_ctrl, 2 * fw.bank_bytes + 2 * (size_t)fw.nprob * sizeof(GemmProb))) == hipSuccess;
             }
             bool narrow = false;       // GEMV / latency tiles in the lists: activation banks of the library's own (poll mode)
-            for (size_t t = 0; t * FWD_TILE_INT4 * 4 < ft.size(); ++t) narrow |= tile_code(ft[t * FWD_TILE_INT4 * 4 + 3]) >= 8;
+            for (size_t t = 0; t * FWD_TILE_INT4 * 4 < ft.size(); ++t) narrow |= ft[t * FWD_TILE_INT4 * 4 + 3] >= 8;
             // which specialisation of the persistent kernel runs these lists (r3d_kernels.hip, R3D_FORWARD_KERNEL)
             const bool b3_tiles = B >= b3_min_batch() && ((pl->m[0] && pl->m[0]->use_b3) || (pl->m[1] && pl->m[1]->use_b3));
-            fw.kernel = s->w4 ? FWD_KERNEL_W4 : narrow ? FWD_KERNEL_LAT : b3_tiles ? FWD_KERNEL_B3 : FWD_KERNEL_F32;
+            fw.kernel = narrow ? FWD_KERNEL_LAT : b3_tiles ? FWD_KERNEL_B3 : FWD_KERNEL_F32;
             // The single launch is only correct with ALL its workgroups resident.  Checked here against what the device
             // holds of that kernel; a CU mask (which the occupancy query does not see) or a lists-mix no specialisation
             // carries sends the size to the launch-by-launch form instead.
             if (ok) {
-                const int cap = s->w4 ? forward4_resident_capacity() : forward_resident_capacity(fw.kernel, false);
+                const int cap = forward_resident_capacity(fw.kernel, false);
                 const bool masked = getenv("HSA_CU_MASK") != nullptr || getenv("ROC_GLOBAL_CU_MASK") != nullptr;
                 if ((narrow && b3_tiles) || (cap > 0 && fw.grid > cap) || masked) {
                     if (fw.d_tiles) (void)hipFree(fw.d_tiles);

@@ -509,6 +509,13 @@ class Ray3DLifter(nn.Module):
         finally:
             h.profile_enable(False)
 
+    def last_clock_ghz(self, device) -> float:
+        """The shader clock the pair's last single-launch forward ran at on `device`, in GHz (r3d_last_clock; 0.0 when it
+        ran level by level).  Synchronises the current stream."""
+        dev = torch.device(device)
+        with torch.cuda.device(dev):
+            return self.pos.handle(dev).last_clock_ghz(torch.cuda.current_stream(dev).cuda_stream)
+
     def precision(self, device) -> str:
         """'f32' or 'bf16x3': the arithmetic the large GEMMs of this pair run in on `device` (r3d_precision)."""
         kinds = {self.pos.handle(torch.device(device)).precision(), self.trj.handle(torch.device(device)).precision()}

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 F="-O3 -std=c++17 --offload-arch=gfx950 -Iinclude -Iray3d_amd/csrc -Wno-unused-result"
-S="tools/gemm_probe.cpp ray3d_amd/csrc/r3d_kernels.hip ray3d_amd/csrc/r3d_kernels4.hip ray3d_amd/csrc/r3d_metrics.hip ray3d_amd/csrc/r3d_schedule.cpp ray3d_amd/csrc/r3d_model.cpp ray3d_amd/csrc/r3d_plan.cpp ray3d_amd/csrc/r3d_api.cpp"
+S="tools/gemm_probe.cpp ray3d_amd/csrc/r3d_kernels.hip ray3d_amd/csrc/r3d_metrics.hip ray3d_amd/csrc/r3d_schedule.cpp ray3d_amd/csrc/r3d_model.cpp ray3d_amd/csrc/r3d_plan.cpp ray3d_amd/csrc/r3d_api.cpp"
 /opt/rocm/bin/hipcc $F -x hip $S -o tools/gemm_probe.bin
 /opt/rocm/bin/hipcc $F -DR3D_TIMING -x hip $S -o tools/gemm_probe_timing.bin
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/bf16x3_probe.cpp -o tools/bf16x3_probe.bin

@@ -76,15 +76,13 @@ int main(int argc, char **argv) {
         if (getenv("PROBE_B3")) g.wb3 = dW[i];   // timing only: the bf16x3 tile on weights that are not in its operand order
         if (enc) { g.lut = dlut; g.x = dx; g.enc_ws = 243 * 51; g.enc_rows = 81; g.enc_jf = 51; g.enc_cur = 81 * 51; g.enc_step = 3; g.enc_bytes = (unsigned)(hx.size() * 4); }
         sp.push_back({M, N, K / BK, enc ? 1 : 4, enc ? std::max(1, std::min(3, (64 * 1024) / ((K + 4) * 4 * 32))) : 0});
-        if (getenv("PROBE_W4")) { sp.back().max_ks = 1; sp.back().max_units = 4; sp.back().colw = 128; }   // four-wave tiles (r3d_kernels4.hip)
     }
     std::vector<int4> tiles;
     std::vector<int> wgoff;
     StageSchedule ss{};
     const int nwg = getenv("PROBE_NWG") ? atoi(getenv("PROBE_NWG")) : device_cu_count();
-    const bool w4 = getenv("PROBE_W4") != nullptr;
-    schedule_stage(sp, enc || w4 ? 2 * nwg : nwg, 6, tiles, wgoff, ss, enc != 0, w4);
-    auto launch = [&]() { return w4 ? launch_gemm4_stage(la, ss.nwg, false, 0) : launch_gemm_stage(la, ss.nwg, ss.kind, false, 0); };
+    schedule_stage(sp, enc ? 2 * nwg : nwg, 6, tiles, wgoff, ss, enc != 0);
+    auto launch = [&]() { return launch_gemm_stage(la, ss.nwg, ss.kind, false, 0); };
     int4 *dt; int *dwg; long long *ddbg;
     CK(hipMalloc((void **)&dt, tiles.size() * sizeof(int4)));
     CK(hipMalloc((void **)&dwg, wgoff.size() * sizeof(int)));
