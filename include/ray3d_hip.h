@@ -232,7 +232,10 @@ int r3d_abi_version(void);                 /* R3D_ABI_VERSION the library was bu
  * the R3D_BF16X3 environment override read at r3d_create).  bench.py labels its line with this, not with the field. */
 int r3d_precision(const r3d_model *m);
 
-/* ---- test hooks (tests/test_host.py; host only, no device needed) ---- */
+/* ---- test hooks: ONLY in libray3d_hip_hooks.so (the same sources built with -DR3D_TEST_HOOKS; tests/test_host.py, host
+ * only, no device needed).  That build also reads the development switches (plan / tile-kind A/Bs, schedule dumps, fault
+ * injection) from the environment; the product library has neither. ---- */
+#ifdef R3D_TEST_HOOKS
 
 /* Builds the static tile schedule of ONE launch for `nprob` GEMM problems (rows M[i], columns N[i], nk[i] K tiles of
  * 32, largest split-K factor max_ks[i], cap on 32-row units per tile max_units[i]) on `nwg` workgroups and verifies
@@ -252,6 +255,7 @@ int r3d_debug_plan_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg,
  * runs every earlier problem that touches the same buffer columns is complete for the tile's windows.  Returns 0, 1 when
  * the plan of this batch size runs launch by launch (nothing to check), or a negative code. */
 int r3d_debug_forward_check(r3d_model *pos, r3d_model *trj, int64_t batch, int nwg, int *tiles, int *counters);
+#endif /* R3D_TEST_HOOKS */
 
 #ifdef __cplusplus
 }

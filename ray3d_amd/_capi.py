@@ -11,6 +11,9 @@ from typing import List, Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libray3d_hip.so")
+# The hooks build (the same sources with -DR3D_TEST_HOOKS): the r3d_debug_* exports and the development switches read from
+# the environment.  tests/ and tools/ select it with use_hooks(True); nothing in this package does.
+HOOKS_LIB_PATH = os.path.join(_HERE, "libray3d_hip_hooks.so")
 
 R3D_KIND_POS, R3D_KIND_TRJ = 0, 1
 R3D_INPUT_RAYS, R3D_INPUT_UV = 0, 1
@@ -22,9 +25,9 @@ EXPORTS = (
     "r3d_create", "r3d_destroy", "r3d_num_weights", "r3d_weight_key", "r3d_weight_shape",
     "r3d_set_weight", "r3d_finalize", "r3d_workspace_bytes", "r3d_forward", "r3d_forward_pair",
     "r3d_profile_enable", "r3d_profile_read", "r3d_clip_metrics", "r3d_last_error", "r3d_version",
-    "r3d_prepare", "r3d_release", "r3d_abi_version", "r3d_precision", "r3d_debug_schedule_check", "r3d_debug_plan_check",
-    "r3d_debug_forward_check", "r3d_status", "r3d_set_option", "r3d_last_clock",
+    "r3d_prepare", "r3d_release", "r3d_abi_version", "r3d_precision", "r3d_status", "r3d_set_option", "r3d_last_clock",
 )
+HOOK_EXPORTS = ("r3d_debug_schedule_check", "r3d_debug_plan_check", "r3d_debug_forward_check")   # libray3d_hip_hooks.so only
 ABI_VERSION = 5                                                          # R3D_ABI_VERSION of the header this binding follows
 METRIC_NAMES = ("mpjpe", "p_mpjpe", "n_mpjpe", "velocity", "root")     # R3D_METRIC_* order
 METRIC_OUT_DOUBLES = 5 * (1 + 128)                                      # R3D_METRIC_OUT_DOUBLES
@@ -51,19 +54,27 @@ class Ray3DHipError(RuntimeError):
     pass
 
 
-_lib = None
+_libs = {}
+_hooks = os.environ.get("R3D_USE_HOOKS_LIB", "0") not in ("", "0")   # (tools/: A/B runs of bench.py on the hooks build)
+
+
+def use_hooks(on: bool) -> None:
+    """Tests / tools: make load() return libray3d_hip_hooks.so (True) or the product library (False, the default).  Handles
+    belong to the library that created them: switch before building modules, and do not carry them across a switch."""
+    global _hooks
+    _hooks = bool(on)
 
 
 def load():
-    """Load libray3d_hip.so; raise (never fall back) when it is not there."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    """Load libray3d_hip.so (or, after use_hooks(True), its hooks build); raise (never fall back) when it is not there."""
+    path = HOOKS_LIB_PATH if _hooks else LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise Ray3DHipError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path)
+    lib = C.CDLL(path)
     vp, i64p = C.c_void_p, C.POINTER(C.c_int64)
     lib.r3d_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     lib.r3d_destroy.argtypes = [vp]
@@ -88,14 +99,14 @@ def load():
     lib.r3d_clip_metrics.argtypes = [vp, vp, C.c_int64, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp, vp]
     lib.r3d_last_error.restype = C.c_char_p
     lib.r3d_version.restype = C.c_char_p
-    for name in EXPORTS:
+    for name in EXPORTS + (HOOK_EXPORTS if _hooks else ()):
         fn = getattr(lib, name)
         if fn.restype is C.c_int or fn.restype is None:
             fn.restype = C.c_int
     if lib.r3d_abi_version() != ABI_VERSION:
         raise Ray3DHipError("%s has ABI version %d, this binding was written for %d: rebuild the library"
-                            % (LIB_PATH, lib.r3d_abi_version(), ABI_VERSION))
-    _lib = lib
+                            % (path, lib.r3d_abi_version(), ABI_VERSION))
+    _libs[path] = lib
     return lib
 
 
@@ -109,7 +120,7 @@ class Handle:
     """Owns one r3d_model*."""
 
     def __init__(self, cfg):
-        lib = load()
+        lib = self._lib = load()          # (a handle stays with the library that created it: see use_hooks)
         c = Config(C.sizeof(Config), R3D_KIND_POS if cfg.kind == "pos" else R3D_KIND_TRJ, cfg.num_joints,
                    cfg.in_features, len(cfg.filter_widths), cfg.channels, cfg.latent, cfg.stage,
                    cfg.extrinsic_dim if cfg.camera_embedding else 0,
@@ -119,35 +130,35 @@ class Handle:
         check(lib.r3d_create(C.byref(c), C.byref(self.ptr)), "r3d_create")
 
     def keys(self) -> List[str]:
-        lib = load()
+        lib = self._lib
         return [lib.r3d_weight_key(self.ptr, i).decode() for i in range(lib.r3d_num_weights(self.ptr))]
 
     def shape(self, index: int):
         shp = (C.c_int64 * 4)()
         rank = C.c_int()
-        check(load().r3d_weight_shape(self.ptr, index, shp, C.byref(rank)), "r3d_weight_shape")
+        check(self._lib.r3d_weight_shape(self.ptr, index, shp, C.byref(rank)), "r3d_weight_shape")
         return tuple(int(shp[i]) for i in range(rank.value))
 
     def set_weight(self, key: str, array):
         """array: C-contiguous float32 numpy array in torch layout."""
         shp = (C.c_int64 * 4)(*([int(d) for d in array.shape] + [1] * (4 - array.ndim)))
-        check(load().r3d_set_weight(self.ptr, key.encode(), array.ctypes.data_as(C.c_void_p), shp,
+        check(self._lib.r3d_set_weight(self.ptr, key.encode(), array.ctypes.data_as(C.c_void_p), shp,
                                     array.ndim), "r3d_set_weight(%s)" % key)
 
     def finalize(self):
-        check(load().r3d_finalize(self.ptr), "r3d_finalize")
+        check(self._lib.r3d_finalize(self.ptr), "r3d_finalize")
 
     def precision(self) -> str:
         """'f32' or 'bf16x3': what the handle's large GEMMs run in (r3d_config.bf16x3 or the R3D_BF16X3 override)."""
-        return "bf16x3" if check(load().r3d_precision(self.ptr), "r3d_precision") == 1 else "f32"
+        return "bf16x3" if check(self._lib.r3d_precision(self.ptr), "r3d_precision") == 1 else "f32"
 
     def set_option(self, option: int, value: int):
-        check(load().r3d_set_option(self.ptr, option, value), "r3d_set_option")
+        check(self._lib.r3d_set_option(self.ptr, option, value), "r3d_set_option")
 
     def status(self, stream: int) -> bool:
         """r3d_status: synchronises `stream`; True when every forward of this handle since the last call finished, False
         when one gave up waiting for its own tiles (outputs NaN; the flag is cleared)."""
-        rc = load().r3d_status(self.ptr, stream)
+        rc = self._lib.r3d_status(self.ptr, stream)
         if rc == R3D_ERR_ABORTED:
             return False
         check(rc, "r3d_status")
@@ -156,22 +167,22 @@ class Handle:
     def last_clock_ghz(self, stream: int) -> float:
         """r3d_last_clock: the shader clock the handle's last single-launch forward ran at (0.0: none / level by level)."""
         ghz = C.c_double(0.0)
-        check(load().r3d_last_clock(self.ptr, stream, C.byref(ghz)), "r3d_last_clock")
+        check(self._lib.r3d_last_clock(self.ptr, stream, C.byref(ghz)), "r3d_last_clock")
         return float(ghz.value)
 
     def profile_enable(self, on: bool):
-        check(load().r3d_profile_enable(self.ptr, 1 if on else 0), "r3d_profile_enable")
+        check(self._lib.r3d_profile_enable(self.ptr, 1 if on else 0), "r3d_profile_enable")
 
     def profile_read(self):
         cap = 128
         recs = (LaunchRecord * cap)()
-        n = check(load().r3d_profile_read(self.ptr, recs, cap), "r3d_profile_read")
+        n = check(self._lib.r3d_profile_read(self.ptr, recs, cap), "r3d_profile_read")
         return [dict(kernel=recs[i].kernel.decode(), stage=recs[i].stage, blocks=recs[i].blocks,
                      ms=recs[i].ms, flops=recs[i].flops, bytes=recs[i].bytes) for i in range(min(n, cap))]
 
     def close(self):
-        if getattr(self, "ptr", None) and self.ptr.value and _lib is not None:
-            _lib.r3d_destroy(self.ptr)
+        if getattr(self, "ptr", None) and self.ptr.value and getattr(self, "_lib", None) is not None:
+            self._lib.r3d_destroy(self.ptr)
             self.ptr = C.c_void_p()
 
     def __del__(self):
@@ -181,18 +192,26 @@ class Handle:
             pass
 
 
+def _lib_of(*handles):
+    """The library the given handles belong to (the selected one when there is none)."""
+    for h in handles:
+        if h is not None:
+            return h._lib
+    return load()
+
+
 def workspace_bytes(pos: Optional[Handle], trj: Optional[Handle], batch: int) -> int:
-    return int(load().r3d_workspace_bytes(pos.ptr if pos else None, trj.ptr if trj else None, batch))
+    return int(_lib_of(pos, trj).r3d_workspace_bytes(pos.ptr if pos else None, trj.ptr if trj else None, batch))
 
 
 def prepare(pos: Optional[Handle], trj: Optional[Handle], batch: int):
     """r3d_prepare: plan + tile schedule of this batch size, uploaded (outside of any stream capture)."""
-    check(load().r3d_prepare(pos.ptr if pos else None, trj.ptr if trj else None, batch), "r3d_prepare")
+    check(_lib_of(pos, trj).r3d_prepare(pos.ptr if pos else None, trj.ptr if trj else None, batch), "r3d_prepare")
 
 
 def release(pos: Optional[Handle], trj: Optional[Handle], batch: int):
     """r3d_release: un-pin a batch size named in prepare() (after the hipGraph that captured it is gone)."""
-    check(load().r3d_release(pos.ptr if pos else None, trj.ptr if trj else None, batch), "r3d_release")
+    check(_lib_of(pos, trj).r3d_release(pos.ptr if pos else None, trj.ptr if trj else None, batch), "r3d_release")
 
 
 def make_input(mode, x_ptr, window_stride, param_ptr, param_stride, cam_ptr=None, cam_stride=0) -> Input:
@@ -200,7 +219,7 @@ def make_input(mode, x_ptr, window_stride, param_ptr, param_stride, cam_ptr=None
 
 
 def forward(handle: Handle, inp: Input, batch: int, out_ptr: int, ws_ptr: int, ws_bytes: int, stream: int):
-    check(load().r3d_forward(handle.ptr, C.byref(inp), batch, out_ptr, ws_ptr, ws_bytes, stream),
+    check(handle._lib.r3d_forward(handle.ptr, C.byref(inp), batch, out_ptr, ws_ptr, ws_bytes, stream),
           "r3d_forward")
 
 
@@ -213,5 +232,5 @@ def clip_metrics(pred_ptr: int, gt_ptr: int, n_frames: int, num_joints: int, rn2
 
 def forward_pair(pos: Handle, trj: Handle, inp: Input, batch: int, out_ptr: int,
                  out_trj_ptr: Optional[int], ws_ptr: int, ws_bytes: int, stream: int):
-    check(load().r3d_forward_pair(pos.ptr, trj.ptr, C.byref(inp), batch, out_ptr, out_trj_ptr,
+    check(pos._lib.r3d_forward_pair(pos.ptr, trj.ptr, C.byref(inp), batch, out_ptr, out_trj_ptr,
                                   ws_ptr, ws_bytes, stream), "r3d_forward_pair")

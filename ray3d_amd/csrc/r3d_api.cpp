@@ -201,8 +201,6 @@ static FwdOrder g_fwd_order;
 
 static hipError_t order_single_launch(hipStream_t stream, bool before) {
     int dev = 0;
-    static const bool off = env_on("R3D_NO_STREAM_ORDER");       // (development: what happens without it - DESIGN.md 4.0)
-    if (off) return hipSuccess;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipSuccess;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }
@@ -298,8 +296,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         // bank of counters, and skips r3d_bind_f32 (4-5 us per call; R3D_BIND_ALWAYS=1: never)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
-        static const bool bind_always = env_on("R3D_BIND_ALWAYS");
-        const bool own = cap == hipStreamCaptureStatusNone && fw.d_ctrl != nullptr && !bind_always;
+        const bool own = cap == hipStreamCaptureStatusNone && fw.d_ctrl != nullptr;
         char *ctrl = own ? fw.d_ctrl : reinterpret_cast<char *>(ws) + workspace_act_bytes(pl, B);
         const size_t bank_bytes = ((size_t)(fw.ncnt + 4) * sizeof(unsigned) + 255) / 256 * 256;
         GemmProb *tables = reinterpret_cast<GemmProb *>(ctrl + (own ? 2 : 1) * bank_bytes);   // (own: one table per activation bank)
@@ -370,7 +367,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             fa.arm_vec4 = (long long)(fw.act_bytes / 16);
         }
         fa.spin_ticks = (long long)std::max(a->spin_timeout_ms, 1) * 100000LL;          // 100 MHz wall clock
-        if (const char *ft = getenv("R3D_FAULT_TILE")) fa.fault_tile1 = atoi(ft) + 1;   // test hook: see FwdArgs
+        if (const char *ft = hook_env("R3D_FAULT_TILE")) fa.fault_tile1 = atoi(ft) + 1;   // (hooks build only: see FwdArgs)
         const bool uv_launch = uv && fw.uses_gather;
         if ((e = rec.begin(forward_kernel_name(fw.kernel, uv_launch), stage_no, fw.grid, fw.flops, fw.bytes)) != hipSuccess)
             return hip_fail(e, "hipEventRecord");
@@ -688,6 +685,7 @@ int r3d_profile_read(r3d_model *m, r3d_launch_record *records, int capacity) {
 // Test hook: build the static schedule of one launch on the host and verify
 // that its tiles cover every (32-row unit, 32-column granule) of every problem exactly once within the
 // kernel's tile-shape limits.  Returns 0 or a negative code naming the first violated rule.
+#ifdef R3D_TEST_HOOKS      // (libray3d_hip_hooks.so only)
 int r3d_debug_schedule_check(int nprob, const int *M, const int *N, const int *nk, const int *max_ks, const int *max_units,
                              int nwg, int enc, int *out_grid, int *out_tiles, double *out_imbalance) {
     std::vector<SchedProb> probs;
@@ -908,6 +906,8 @@ int r3d_debug_forward_check(r3d_model *pos, r3d_model *trj, int64_t batch, int n
             if (cnt[fw.cnt_base[i] + u] != (unsigned)gcols[i]) return -24;
     return 0;
 }
+
+#endif  // R3D_TEST_HOOKS
 
 int r3d_clip_metrics(const float *pred_dev, const float *gt_dev, int64_t n_frames, int32_t num_joints,
                      const double *rn2w, const double *tn2w, double *out_dev, void *stream) {

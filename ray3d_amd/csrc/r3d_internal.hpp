@@ -163,14 +163,25 @@ struct TensorSpec {
 // fixed cost is the larger one, and with a handful of tiles per launch nothing else counts - 0.325 against 0.288 ms at
 // 64 windows, 0.370 against 0.386 at 128 (bench.py --batch).
 inline int64_t b3_min_batch() {
-    static const int64_t v = [] { const char *e = getenv("R3D_B3_MIN_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)96; }();
-    return v;
+    return 96;
 }
 
-inline bool env_on(const char *name) {      // set and not "0" (development switches)
+inline bool env_on(const char *name) {      // set and not "0"
     const char *e = getenv(name);
     return e && atoi(e) != 0;
 }
+// Development and test switches (plan / tile-kind A/Bs, schedule dumps, fault injection) exist only in the hooks build of the
+// library - libray3d_hip_hooks.so, the same sources with -DR3D_TEST_HOOKS, which tests/ and tools/ load when they need one
+// (ray3d_amd/_capi.py, use_hooks).  In the product library they are compile-time constants: no getenv on any call path.
+// What the product reads from the environment: R3D_BF16X3 (r3d_create) and R3D_STAGED (first use), both documented in
+// include/ray3d_hip.h, and the CU-mask variables of the runtime (schedule_get).
+#ifdef R3D_TEST_HOOKS
+inline bool hook_on(const char *name) { return env_on(name); }
+inline const char *hook_env(const char *name) { return getenv(name); }
+#else
+inline bool hook_on(const char *) { return false; }
+inline const char *hook_env(const char *) { return nullptr; }
+#endif
 
 struct Layer {
     std::string weight_key;   // "<prefix>.weight"

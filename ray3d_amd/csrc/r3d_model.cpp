@@ -171,7 +171,7 @@ Model *model_create(const r3d_config &cfg) {
         m->use_b3 = e ? atoi(e) != 0 : cfg.bf16x3 != 0;
     }
     // shrink folds into the Linears that read it when that does not widen them (Layer::pre)
-    m->fold_shrink = cfg.channels <= cfg.latent && !env_on("R3D_NO_SHRINK_FOLD");
+    m->fold_shrink = cfg.channels <= cfg.latent && !hook_on("R3D_NO_SHRINK_FOLD");
     if (!emb) m->cfg.extrinsic_dim = m->cfg.embed_dim = 0;
     m->RF = 1;
     for (int i = 0; i < cfg.num_levels; ++i) m->RF *= 3;

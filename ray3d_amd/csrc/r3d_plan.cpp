@@ -236,10 +236,10 @@ static Plan *build_plan(const Model *a, const Model *b, int kind) {
             bool all = true;
             for (const Model *mm : pl->m)
                 if (mm) all = all && can_fuse(mm);
-            B.first_level_fused = all && !small && !env_on("R3D_NO_FIRST_FUSE");
-            B.enc_in_gemm = small && !env_on("R3D_SMALL_ENC_KERNEL");
+            B.first_level_fused = all && !small;
+            B.enc_in_gemm = small;
             B.single_assign = small;
-            B.fuse_pairs = (kind == PLAN_FUSED || kind == PLAN_LARGE) && !env_on("R3D_NO_PAIR_FUSE");
+            B.fuse_pairs = (kind == PLAN_FUSED || kind == PLAN_LARGE);
             B.fuse_top = kind == PLAN_LARGE;
         }
         const int lat = m->cfg.latent, D = m->cfg.embed_dim;
@@ -394,7 +394,7 @@ static Plan *build_plan(const Model *a, const Model *b, int kind) {
         std::vector<std::vector<int>> lv(maxd + 1);
         for (int i = 0; i < n; ++i) lv[pl->probs[i].depth].push_back(i);
         if (spill) lv[pl->probs[pt].depth + 1].push_back(pt | STAGE_SPILL_IN);
-        if (getenv("R3D_PLAN_DUMP"))
+        if (hook_env("R3D_PLAN_DUMP"))
             for (size_t s = 0; s < lv.size(); ++s) {
                 fprintf(stderr, "[plan%s] launch %zu:", spill ? " spill" : "", s);
                 for (int e : lv[s]) {
@@ -411,7 +411,7 @@ static Plan *build_plan(const Model *a, const Model *b, int kind) {
         if (spill) pl->spill_prob = pt;
         return true;
     };
-    const bool can_spill = pl->m[0] && pl->m[1] && !env_on("R3D_NO_SPILL");
+    const bool can_spill = pl->m[0] && pl->m[1] && !hook_on("R3D_NO_SPILL");
     if (!(can_spill && levelise(true, false, pl->stages_spill))) pl->stages_spill.clear();
     if (!(can_spill && levelise(true, true, pl->stages_spill_alt)) || pl->stages_spill_alt == pl->stages_spill) pl->stages_spill_alt.clear();
     levelise(false, false, pl->stages);
@@ -444,21 +444,14 @@ static std::map<std::pair<std::pair<uint64_t, uint64_t>, int>, Plan *> g_plans;
 // (0.379 against 0.383; 0.608 against 0.627 at 256).  From 1024 windows on the top pyramid level (one row per window)
 // has enough rows to run as a fused pair too (11 launches): 1.977 against 1.986 ms at 1024, 3.765 against 3.817 at 2048,
 // 7.430 against 7.459 at 4096; at 512 it loses (1.092 against 1.083).  bench.py --batch.
-static int64_t plan_env(const char *name, int64_t dflt) { const char *e = getenv(name); return e ? (int64_t)atoll(e) : dflt; }
+constexpr int64_t SMALL_PLAN_MAX = 48, MEDIUM_PLAN_MAX = 96, LARGE_PLAN_MIN = 1024;
 
-std::vector<int64_t> plan_kind_edges() {
-    std::vector<int64_t> e{plan_env("R3D_SMALL_PLAN_MAX", 48), plan_env("R3D_MEDIUM_PLAN_MAX", 96), plan_env("R3D_LARGE_PLAN_MIN", 1024) - 1};
-    e.erase(std::remove_if(e.begin(), e.end(), [](int64_t v) { return v < 1; }), e.end());
-    return e;
-}
+std::vector<int64_t> plan_kind_edges() { return {SMALL_PLAN_MAX, MEDIUM_PLAN_MAX, LARGE_PLAN_MIN - 1}; }
 
 int plan_kind(int64_t B) {
-    static const int64_t small_max = [] { const char *e = getenv("R3D_SMALL_PLAN_MAX"); return e ? (int64_t)atoll(e) : (int64_t)48; }();
-    static const int64_t medium_max = [] { const char *e = getenv("R3D_MEDIUM_PLAN_MAX"); return e ? (int64_t)atoll(e) : (int64_t)96; }();
-    static const int64_t large_min = [] { const char *e = getenv("R3D_LARGE_PLAN_MIN"); return e ? (int64_t)atoll(e) : (int64_t)1024; }();
-    if (B >= large_min) return PLAN_LARGE;
-    if (env_on("R3D_NO_SMALL_PLAN")) return PLAN_FUSED;
-    return B <= small_max ? PLAN_SMALL : B <= medium_max ? PLAN_MEDIUM : PLAN_FUSED;
+    if (B >= LARGE_PLAN_MIN) return PLAN_LARGE;
+    if (hook_on("R3D_NO_SMALL_PLAN")) return PLAN_FUSED;       // (hooks build: the parity tests run small calls on the fused plan too)
+    return B <= SMALL_PLAN_MAX ? PLAN_SMALL : B <= MEDIUM_PLAN_MAX ? PLAN_MEDIUM : PLAN_FUSED;
 }
 
 Plan *plan_get(Model *a, Model *b, int kind) {

@@ -46,7 +46,7 @@ static void dump_fwd(const Plan *pl, int64_t B, int grid, const std::vector<int>
     const int np = (int)pl->probs.size();
     std::vector<int> M(np);
     for (int i = 0; i < np; ++i) M[i] = (int)(B * pl->probs[i].rows_per_window);
-    if (const char *dump = getenv("R3D_FWD_DUMP")) {             // development aid: problems (with producers) and every workgroup's tiles
+    if (const char *dump = hook_env("R3D_FWD_DUMP")) {             // development aid: problems (with producers) and every workgroup's tiles
         if (FILE *f = fopen(dump, "w")) {
             for (int i = 0; i < np; ++i) {
                 const ProbSpec &q = pl->probs[i];
@@ -216,7 +216,7 @@ struct CostModel {
 const CostModel &cost_model() {
     static const CostModel c = [] {
         CostModel m;
-        if (const char *e = getenv("R3D_COST"))
+        if (const char *e = hook_env("R3D_COST"))
             sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf,%lf", &m.iter, &m.fixed, &m.ks_iter, &m.ks_fixed, &m.first_extra, &m.first_extra_wide, &m.pair_scale);
         return m;
     }();
@@ -459,7 +459,7 @@ void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units,
         ++grid;
     }
     if (grid == 0) { wgoff.push_back(0); grid = 1; }
-    if (const char *e = getenv("R3D_SCHED_DUMP")) {   // development aid: the chunks of every launch, one line per workgroup
+    if (const char *e = hook_env("R3D_SCHED_DUMP")) {   // development aid: the chunks of every launch, one line per workgroup
         (void)e;
         fprintf(stderr, "[sched] launch of %zu problems: budget %.0f cycles, ideal %.0f, split-K %d\n", probs.size(), best->T,
                 best->total / std::max(grid, 1), best->ks);
@@ -498,9 +498,9 @@ static SchedProb sched_prob_of(const Plan *pl, const ProbSpec &q, int64_t B) {
         if (q.nseg == 1 && q.seg[0].width < L.Kpad) sp.max_ks = 1;   // an operand narrower than its padded K: one bounded descriptor
         // a plain layer of a few rows (calls of up to eight windows: the MLPs, the top of the pyramid): GEMV tiles
         const bool narrow_ok = q.enc_lut < 0 && q.layer2 < 0 && !(q.nseg == 1 && q.seg[0].width < L.Kpad) && L.Kpad >= 64;
-        sp.gemv = M <= GEMV_ROWS && narrow_ok && !env_on("R3D_NO_GEMV");
+        sp.gemv = M <= GEMV_ROWS && narrow_ok && !hook_on("R3D_NO_GEMV");
         // ... and of up to 32 rows (one unit): latency tiles on the matrix cores (not beside the bf16x3 tiles: B >= 96 there)
-        sp.lat = !sp.gemv && M <= 32 && narrow_ok && !env_on("R3D_NO_LAT");
+        sp.lat = !sp.gemv && M <= 32 && narrow_ok && !hook_on("R3D_NO_LAT");
         const bool b3 = B >= b3_min_batch();               // (r3d_api.cpp passes the bf16x3 operands under the same condition)
         if (b3 && L.bf3 && q.layer2 < 0 && q.enc_lut < 0) {   // bf16-matrix-core tiles: whole tiles of <= 128 rows, ~1.5x the iteration rate
             sp.max_ks = 1;
@@ -605,7 +605,7 @@ const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t
     spill_row0 = -1;
     g_stage_memo.clear();
     const std::vector<std::vector<int>> *levels = &pl->stages;
-    const bool dump = getenv("R3D_PLAN_DUMP") != nullptr;
+    const bool dump = hook_env("R3D_PLAN_DUMP") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto build_all = [&](const std::vector<std::vector<int>> &lv, int row0, std::vector<int4> &t, std::vector<int> &w,
                          std::vector<StageSchedule> &ss) {
@@ -795,7 +795,7 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
                 }
             }
             // (up to 16 windows: at 32 the sentinel fill of a 10 MB bank costs more than the hops save - 0.219 against 0.213 ms)
-            if (ok && narrow && pl->kind == PLAN_SMALL && B <= 16 && !env_on("R3D_NO_POLL")) {     // (that plan writes no activation twice: r3d_plan.cpp, single_assign)
+            if (ok && narrow && pl->kind == PLAN_SMALL && B <= 16) {     // (that plan writes no activation twice: r3d_plan.cpp, single_assign)
                 fw.act_bytes = (((size_t)pl->floats_per_window * (size_t)B + (size_t)pl->tail_floats + 64) * sizeof(float) + 255) / 256 * 256;
                 ok = (e = hipMalloc((void **)&fw.d_act, 2 * fw.act_bytes)) == hipSuccess;
             }

@@ -150,7 +150,7 @@ class LiftModule(nn.Module):
             return
         with torch.cuda.device(dev):
             if not self._handle.status(torch.cuda.current_stream(dev).cuda_stream):
-                raise _capi.Ray3DHipError("forward aborted: " + _capi.load().r3d_last_error().decode())
+                raise _capi.Ray3DHipError("forward aborted: " + self._handle._lib.r3d_last_error().decode())
 
     def handle(self, device: torch.device) -> _capi.Handle:
         """The finalized C handle for `device`, re-uploading weights when they changed."""

@@ -10,6 +10,30 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+@pytest.fixture(autouse=True)
+def _product_library_by_default():
+    """Every test starts on the product library (ray3d_amd/libray3d_hip.so).  A test that needs a development switch or an
+    r3d_debug_* entry point switches itself to the hooks build (dev_switch / hooks_library below) BEFORE it creates handles;
+    the choice ends with the test."""
+    from ray3d_amd import _capi
+    _capi.use_hooks(False)
+    yield
+    _capi.use_hooks(False)
+
+
+def hooks_library():
+    """libray3d_hip_hooks.so (the same sources with -DR3D_TEST_HOOKS) for the rest of this test; returns the CDLL."""
+    from ray3d_amd import _capi
+    _capi.use_hooks(True)
+    return _capi.load()
+
+
+def dev_switch(monkeypatch, name, value):
+    """Set a development switch (R3D_NO_SMALL_PLAN, R3D_NO_GEMV, R3D_FAULT_TILE, ...): only the hooks build reads them."""
+    hooks_library()
+    monkeypatch.setenv(name, str(value))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

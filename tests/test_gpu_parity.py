@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import MODEL_CASES, case_out_scale, check_parity, load_model_fixture, synth_states
+from conftest import MODEL_CASES, case_out_scale, check_parity, dev_switch, load_model_fixture, synth_states
 
 pytestmark = pytest.mark.gpu
 
@@ -36,7 +36,8 @@ PLANS = [pytest.param(False, id="small-plan"), pytest.param(True, id="fused-plan
 @pytest.mark.parametrize("fused", PLANS)
 @pytest.mark.parametrize("name", MODEL_CASES)
 def test_modules_match_reference_fixture(name, fused, monkeypatch):
-    monkeypatch.setenv("R3D_NO_SMALL_PLAN", "1" if fused else "0")
+    if fused:
+        dev_switch(monkeypatch, "R3D_NO_SMALL_PLAN", "1")
     z, mc = load_model_fixture(name)
     pos, trj, _, _ = build_modules(mc, case_out_scale(name))
     x = torch.from_numpy(z["x"]).cuda()
@@ -53,7 +54,8 @@ def test_modules_match_reference_fixture(name, fused, monkeypatch):
 @pytest.mark.parametrize("name", MODEL_CASES)
 def test_lifter_pair_matches_reference_fixture(name, fused, monkeypatch):
     import ray3d_amd
-    monkeypatch.setenv("R3D_NO_SMALL_PLAN", "1" if fused else "0")
+    if fused:
+        dev_switch(monkeypatch, "R3D_NO_SMALL_PLAN", "1")
     z, mc = load_model_fixture(name)
     pos, trj, _, _ = build_modules(mc, case_out_scale(name))
     lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
@@ -110,7 +112,8 @@ def test_lifter_matches_oracle_ragged_batches(arch, batch, fused, monkeypatch):
     import ray3d_amd
     from ray3d_amd import synth
     from oracle import oracle
-    monkeypatch.setenv("R3D_NO_SMALL_PLAN", "1" if fused else "0")
+    if fused:
+        dev_switch(monkeypatch, "R3D_NO_SMALL_PLAN", "1")
     mc = ray3d_amd.default_model_config(ARCHITECTURE=arch)
     pos, trj, (cp, sp), (ct, st) = build_modules(mc)
     lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
@@ -135,7 +138,7 @@ def test_calls_of_one_to_four_windows_run_the_gemv_tiles(over, monkeypatch):
     for B in (1, 2, 3, 4):
         outs = []
         for no_gemv in ("0", "1"):
-            monkeypatch.setenv("R3D_NO_GEMV", no_gemv)
+            dev_switch(monkeypatch, "R3D_NO_GEMV", no_gemv)
             pos, trj, (cp, sp), (ct, st) = build_modules(mc)          # (the switch is read when a schedule is built: fresh handles)
             x, p = synth.synth_rays(B, cp, seed=91), synth.synth_param(B, seed=92)
             pt = torch.from_numpy(p).cuda() if cp.camera_embedding else None
@@ -159,7 +162,7 @@ def test_calls_of_five_to_32_windows_run_the_latency_tiles(over, monkeypatch):
     for B in (5, 11, 32):
         outs = []
         for no_lat in ("0", "1"):
-            monkeypatch.setenv("R3D_NO_LAT", no_lat)
+            dev_switch(monkeypatch, "R3D_NO_LAT", no_lat)
             pos, trj, (cp, sp), (ct, st) = build_modules(mc)
             x, p = synth.synth_rays(B, cp, seed=93), synth.synth_param(B, seed=94)
             with torch.no_grad():
@@ -266,7 +269,8 @@ def test_forward_uv_matches_oracle_on_reference_cameras(arch, B, fused, monkeypa
     import ray3d_amd
     from ray3d_amd import synth
     from oracle import oracle
-    monkeypatch.setenv("R3D_NO_SMALL_PLAN", "1" if fused else "0")     # (the gather inside the fused first level / inside r3d_gemm_enc_uv_f32)
+    if fused:
+        dev_switch(monkeypatch, "R3D_NO_SMALL_PLAN", "1")     # (the gather inside the fused first level / inside r3d_gemm_enc_uv_f32)
     cams, ocams, z, tags = _reference_cameras()
     mc = ray3d_amd.default_model_config(ARCHITECTURE=arch)
     pos, trj, (cp, sp), (ct, st) = build_modules(mc)
@@ -307,7 +311,8 @@ def test_forward_uv_overlapping_windows_each_with_its_own_camera(fused, monkeypa
     Also the sliding-clip form (stride 1, one camera) against forward_clip on host-encoded rays."""
     import ray3d_amd
     from ray3d_amd import synth
-    monkeypatch.setenv("R3D_NO_SMALL_PLAN", "1" if fused else "0")
+    if fused:
+        dev_switch(monkeypatch, "R3D_NO_SMALL_PLAN", "1")
     cams, _, _, _ = _reference_cameras()
     mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
     pos, trj, (cp, _), _ = build_modules(mc)
@@ -727,7 +732,7 @@ def test_narrow_channels_at_5_to_32_windows_keep_the_residual(channels, batch, n
     import ray3d_amd
     from ray3d_amd import synth
     from oracle import oracle
-    monkeypatch.setenv("R3D_NO_LAT", "1" if no_lat else "0")
+    dev_switch(monkeypatch, "R3D_NO_LAT", "1" if no_lat else "0")
     mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3", CHANNELS=channels, LATENT_FEATURES_DIM=128)
     pos, trj, (cp, sp), (ct, st) = build_modules(mc)
     lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
@@ -752,7 +757,7 @@ def test_shrink_folded_into_its_consumers_equals_the_separate_layer(over, monkey
     mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3", **over)
     outs = []
     for nofold in ("0", "1"):
-        monkeypatch.setenv("R3D_NO_SHRINK_FOLD", nofold)
+        dev_switch(monkeypatch, "R3D_NO_SHRINK_FOLD", nofold)
         pos, trj, (cp, sp), (ct, st) = build_modules(mc)
         x, p = synth.synth_rays(75, cp, seed=71), synth.synth_param(75, seed=72)
         pt = torch.from_numpy(p).cuda() if cp.camera_embedding else None
@@ -1223,7 +1228,7 @@ def test_a_tile_that_never_reports_ends_in_nan_not_in_a_hang(monkeypatch):
     with torch.no_grad():
         good = lifter(x, p)
         torch.cuda.synchronize()
-        monkeypatch.setenv("R3D_FAULT_TILE", "0")
+        dev_switch(monkeypatch, "R3D_FAULT_TILE", "0")
         t0 = time.perf_counter()
         bad = lifter(x, p)
         torch.cuda.synchronize()
@@ -1241,7 +1246,7 @@ def test_a_tile_that_never_reports_ends_in_nan_not_in_a_hang(monkeypatch):
     lifter.check_status()                           # (cleared by the call that reported it)
     lifter.set_spin_timeout_ms(100)
     with torch.no_grad():
-        monkeypatch.setenv("R3D_FAULT_TILE", "0")
+        dev_switch(monkeypatch, "R3D_FAULT_TILE", "0")
         t0 = time.perf_counter()
         bad = lifter(x, p)
         with pytest.raises(_capi_error(), match="gave up after 100 ms"):
@@ -1251,7 +1256,7 @@ def test_a_tile_that_never_reports_ends_in_nan_not_in_a_hang(monkeypatch):
     assert torch.isnan(bad).all() and dt < 0.9, dt
     # checked(): notices, switches the pair to the level-by-level form, repeats - the caller gets correct poses
     with torch.no_grad(), pytest.warns(UserWarning, match="level-by-level"):
-        monkeypatch.setenv("R3D_FAULT_TILE", "0")
+        dev_switch(monkeypatch, "R3D_FAULT_TILE", "0")
         fixed = lifter.checked(lambda: lifter(x, p))
         monkeypatch.delenv("R3D_FAULT_TILE")
     assert torch.equal(fixed, good) and lifter.pos._staged
@@ -1363,7 +1368,7 @@ def test_calls_of_a_few_windows_take_data_as_its_own_ready_flag(B, monkeypatch):
             return
         # a GEMV tile of workgroup 0 that never stores
         torch.cuda.synchronize()
-        monkeypatch.setenv("R3D_FAULT_TILE", "0")
+        dev_switch(monkeypatch, "R3D_FAULT_TILE", "0")
         t0 = time.perf_counter()
         bad = lifter(x, p)
         torch.cuda.synchronize()

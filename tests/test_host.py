@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, MODEL_CASES, ROOT, load_model_fixture, synth_states
+from conftest import GOLDEN, MODEL_CASES, ROOT, dev_switch, hooks_library, load_model_fixture, synth_states
 
 import ray3d_amd
 from ray3d_amd import _capi, evaluate, metrics, synth
@@ -19,18 +19,29 @@ from ray3d_amd.spec import config_from_dicts, default_model_config, state_entrie
 # ------------------------------------------------------------------ C ABI surface
 
 def test_library_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "ray3d_hip.h")).read()
-    declared = set(re.findall(r"\b(r3d_[a-z_]+)\s*\(", hdr))
-    assert declared == set(_capi.EXPORTS), declared ^ set(_capi.EXPORTS)
-    lib = ctypes.CDLL(_capi.LIB_PATH)
-    for name in declared:
-        assert hasattr(lib, name), name
-    assert b"gfx950" in _capi.load().r3d_version()
-    # ... and exports nothing under the r3d_ prefix that the header does not declare
+    """The product library exports exactly what include/ray3d_hip.h declares outside its R3D_TEST_HOOKS block; the hooks
+    build (tests / tools only) the r3d_debug_* entry points on top."""
     import subprocess
-    out = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
-    exported = set(re.findall(r"\b[TW] (r3d_[a-z_0-9]+)$", out, flags=re.M))
-    assert exported == declared, exported ^ declared
+    hdr = open(os.path.join(ROOT, "include", "ray3d_hip.h")).read()
+    m = re.search(r"#ifdef R3D_TEST_HOOKS(.*?)#endif /\* R3D_TEST_HOOKS \*/", hdr, flags=re.S)
+    assert m, "the header keeps its test hooks in an #ifdef R3D_TEST_HOOKS block"
+    hooks_declared = set(re.findall(r"\b(r3d_[a-z_]+)\s*\(", m.group(1)))
+    declared = set(re.findall(r"\b(r3d_[a-z_]+)\s*\(", hdr.replace(m.group(0), "")))
+    assert declared == set(_capi.EXPORTS), declared ^ set(_capi.EXPORTS)
+    assert hooks_declared == set(_capi.HOOK_EXPORTS), hooks_declared ^ set(_capi.HOOK_EXPORTS)
+    for path, want in ((_capi.LIB_PATH, declared), (_capi.HOOKS_LIB_PATH, declared | hooks_declared)):
+        lib = ctypes.CDLL(path)
+        for name in want:
+            assert hasattr(lib, name), (path, name)
+        # ... and nothing else under the r3d_ prefix
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        exported = set(re.findall(r"\b[TW] (r3d_[a-z_0-9]+)$", out, flags=re.M))
+        assert exported == want, (path, exported ^ want)
+    assert b"gfx950" in _capi.load().r3d_version()
+    # the product library reads no development switch: none of their names is in its strings
+    blob = open(_capi.LIB_PATH, "rb").read()
+    for name in (b"R3D_FAULT_TILE", b"R3D_NO_SMALL_PLAN", b"R3D_NO_GEMV", b"R3D_NO_LAT", b"R3D_SCHED_DUMP", b"R3D_COST"):
+        assert name not in blob, name
 
 
 @pytest.mark.parametrize("name", MODEL_CASES)
@@ -364,7 +375,7 @@ def _schedule_check(probs, nwg=256, enc=False):
     (r3d_debug_schedule_check, r3d_api.cpp): exact cover + tile-shape rules."""
     import ctypes as C
     from ray3d_amd import _capi
-    lib = _capi.load()
+    lib = hooks_library()
     fn = lib.r3d_debug_schedule_check
     fn.restype = C.c_int
     n = len(probs)
@@ -517,7 +528,7 @@ def test_checkpoint_file_in_the_trainers_format(tmp_path):
 def _plan_check(mc, batches, nwg=256):
     """Whole-forward tile lists built on the host (r3d_debug_plan_check): every 32 x 64 cell of every problem once,
     producers' tiles in earlier launches than their consumers', spilled rows only in the launch that lists them."""
-    lib = _capi.load()
+    lib = hooks_library()
     fn = lib.r3d_debug_plan_check
     fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     fn.restype = ctypes.c_int
@@ -548,7 +559,7 @@ def test_plan_tile_lists_cover_every_problem_once(monkeypatch):
     _plan_check(mc, [256, 1000], nwg=64)
     _plan_check(default_model_config(ARCHITECTURE="3,3,3,3", CHANNELS=512), [3, 256])
     _plan_check(default_model_config(ARCHITECTURE="3,3,3", DENSE=True, DISABLE_OPTIMIZATIONS=True), [1, 50, 256])
-    monkeypatch.setenv("R3D_NO_SPILL", "1")
+    dev_switch(monkeypatch, "R3D_NO_SPILL", "1")
     assert all(s == 0 for _, s in _plan_check(mc, [100, 256, 1024]))
 
 
@@ -571,7 +582,7 @@ def test_workspace_bytes_is_monotonic_in_the_batch():
 def test_pairs_with_different_channel_counts_get_one_first_level_kind():
     """The first level is fused for the pair or for neither model: pos with 256 channels (fusable) next to a trajectory
     model with 512 (not) must not put r3d_gemm_f32 and r3d_gemm_enc_f32 problems into one launch."""
-    lib = _capi.load()
+    lib = hooks_library()
     fn = lib.r3d_debug_plan_check
     fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     fn.restype = ctypes.c_int
@@ -594,7 +605,7 @@ def test_single_launch_forward_is_a_sound_dependency_machine():
     writes what it reads or touches what it writes (same buffer, overlapping columns) is complete for its windows.  For the
     plan of calls of <= 48 windows it also checks that no workspace element is written twice in a call and that every
     element read is written - what the GEMV / latency tiles' "data as its own ready flag" mode relies on."""
-    lib = _capi.load()
+    lib = hooks_library()
     fn = lib.r3d_debug_forward_check
     fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     fn.restype = ctypes.c_int
@@ -626,7 +637,7 @@ def test_plans_do_not_outlive_a_partner_model():
     """A (pos, trj) plan holds the partner's layer indices and K paddings.  It is keyed by model ids that are never
     reused and dropped when either model is destroyed: a new trajectory model - which malloc may well place at the old
     one's address - gets a plan built for ITS configuration."""
-    lib = _capi.load()
+    lib = hooks_library()
     fn = lib.r3d_debug_plan_check
     fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     fn.restype = ctypes.c_int
