@@ -136,6 +136,22 @@ int fill_prob(const Plan *pl, const ProbSpec &q, int64_t B, const Model *a, cons
         g.enc_cur = (a->RF / a->cfg.in_features) * JF;   // quirk Q1: "current" frame is RF // in_features
         g.enc_bytes = (unsigned)((size_t)cs.frames * JF * sizeof(float));
         g.res_tap = 1 + m->cfg.causal;
+        if (cs.shared && q.layer3 >= 0 && q.frame_col >= 0) {
+            // clip call: the tile reads its expand_conv pre-activations from the per-frame buffer (Plan::frame_buf, written by
+            // the launch ahead of the forward) - `x` is this branch's [E | V] block, a row per input frame of enc_jf floats,
+            // enc_ws / enc_cur the window stride and the current frame's offset in those rows; no tables, no camera
+            g.lut = nullptr;
+            tg[15] = BIND_NULL;
+            g.x = ws_ptr(pl->frame_buf, q.frame_col);
+            tg[16] = BIND_WS;
+            g.cam = nullptr;
+            tg[17] = BIND_NULL;
+            g.cam_stride = 0;
+            g.enc_jf = pl->frame_ld;
+            g.enc_ws = cs.window_stride * pl->frame_ld;
+            g.enc_cur = (a->RF / a->cfg.in_features) * pl->frame_ld;
+            g.enc_bytes = (unsigned)(((size_t)cs.frames * pl->frame_ld - (size_t)q.frame_col) * sizeof(float));
+        }
     }
     g.w = arena_ptr(L.w_off);
     tg[4] = TA;
@@ -287,7 +303,60 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
     Schedule *sched = schedule_get(pl, B, device_cu_count());
     if (!sched) return R3D_ERR_HIP;
     const unsigned *abort_flag = nullptr;
-    const bool single = forward_single_launch() && !a->opt_staged && !(b && b->opt_staged) && sched->fwd.grid > 0 && !(uv && !sched->fwd.d_rel[1]);
+    // Clip calls (window stride one frame, lib/train_val/trainer.py:47-58): consecutive windows share all but one of their
+    // frames, and expand_conv is linear - its pre-activations are evaluated once per FRAME by a launch of gathered GEMMs
+    // ahead of the forward (Plan::frame_probs) and the first-level tiles read them instead of gathering and multiplying
+    // (r3d_kernels.hip, first_level_shared).  Where it pays (four times fewer rows), one camera for the
+    // clip, fp32 tiles.
+    bool b3_call = false;
+    for (const Model *mm : pl->m) b3_call = b3_call || (mm && mm->use_b3 && B >= b3_min_batch());
+    const bool shared = pl->frame_buf >= 0 && sched->d_frame_tiles != nullptr && in->window_stride == 1 && !b3_call &&
+                        (frames - 2) * 4 <= B * (int64_t)(a->RF / 3) && !(uv && in->cam_stride != 0) && !hook_on("R3D_NO_SHARED_L0");
+    shape.shared = shared;
+    const int variant = (uv ? 1 : 0) + (shared ? 2 : 0);
+    const bool single = forward_single_launch() && !a->opt_staged && !(b && b->opt_staged) && sched->fwd.grid > 0 && sched->fwd.d_rel[variant] != nullptr &&
+                        !(shared && sched->fwd.kernel != FWD_KERNEL_F32);
+    if (shared) {
+        const StageSchedule &fs = sched->frame_stage;
+        LaunchArgs la;
+        memset(&la, 0, sizeof la);
+        la.tiles = sched->d_frame_tiles;
+        la.wg_off = sched->d_frame_wgoff;
+        la.nprob = (int)pl->frame_probs.size();
+        la.ks = fs.ks;
+        const int JF = a->cfg.num_joints * (uv ? 2 : a->cfg.in_features);
+        float *fbase = reinterpret_cast<float *>(ws) + (size_t)pl->buffers[pl->frame_buf].offset_per_window * (size_t)B;
+        for (int i = 0; i < la.nprob; ++i) {
+            const Plan::FrameProb &f = pl->frame_probs[i];
+            const Model *mm = pl->m[f.model];
+            const Layer &L = mm->layers[f.layer];
+            GemmProb &g = la.p[i];
+            for (int sg = 0; sg < MAX_SEG; ++sg) g.kend[sg] = 0x7fffffff;
+            g.w = mm->d_arena + L.w_off;
+            g.bias = mm->d_arena + L.b_off;
+            g.c = fbase + f.col;
+            g.ldc = pl->frame_ld;
+            g.M = (int)(frames - 2);
+            g.N = L.N;
+            g.K = L.Kpad;
+            g.slope = 1.0f;
+            g.lut = mm->d_iarena + (uv ? f.lut_uv : f.lut);
+            g.x = reinterpret_cast<const float *>(in->x_dev);
+            g.cam = uv ? reinterpret_cast<const double *>(in->cam_dev) : nullptr;
+            g.cam_stride = 0;
+            g.enc_ws = 0;
+            g.enc_rows = g.M;                    // (one "window": operand row r starts at frame r)
+            g.enc_step = 1;
+            g.enc_jf = JF;
+            g.enc_cur = 0;
+            g.enc_bytes = (unsigned)((size_t)frames * JF * sizeof(float));
+            g.res_tap = 1;
+        }
+        if ((e = rec.begin(uv ? "r3d_gemm_uv_f32" : "r3d_gemm_f32", stage_no, fs.nwg, 0.0, 0.0)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        if ((e = launch_gemm_stage(la, fs.nwg, STAGE_BIG, uv, stream)) != hipSuccess) return hip_fail(e, "launch r3d_gemm_f32 (per-frame first layers)");
+        if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        ++stage_no;
+    }
     if (single) {
         // ---- the whole forward as ONE persistent launch: bind (zero the ready counters, resolve the problem table), run
         Schedule::Fwd &fw = sched->fwd;
@@ -304,8 +373,8 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         const bool poll = own && fw.d_act != nullptr;
         BindArgs ba;
         memset(&ba, 0, sizeof ba);
-        ba.rel = fw.d_rel[uv ? 1 : 0];
-        ba.tags = fw.d_tags[uv ? 1 : 0];
+        ba.rel = fw.d_rel[variant];
+        ba.tags = fw.d_tags[variant];
         ba.out = tables;
         ba.nprob = fw.nprob;
         ba.base[BIND_WS] = ws;
@@ -322,7 +391,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         ba.enc_bytes = (unsigned)((size_t)frames * JF * sizeof(float));
         ba.param_stride = (int)in->param_stride;
         Schedule::Fwd::Bound &bd = fw.bound;
-        bool bound = own && bd.valid && bd.uv == (uv ? 1 : 0) && bd.enc_ws == ba.enc_ws && bd.cam_stride == ba.cam_stride &&
+        bool bound = own && bd.valid && bd.uv == variant && bd.enc_ws == ba.enc_ws && bd.cam_stride == ba.cam_stride &&
                      bd.enc_bytes == ba.enc_bytes && bd.param_stride == ba.param_stride;
         for (int k = 0; bound && k < BIND_NBASE; ++k) bound = bd.base[k] == ba.base[k];
         const int bank = bound ? bd.bank ^ 1 : 0;
@@ -369,7 +438,8 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         fa.spin_ticks = (long long)std::max(a->spin_timeout_ms, 1) * 100000LL;          // 100 MHz wall clock
         if (const char *ft = hook_env("R3D_FAULT_TILE")) fa.fault_tile1 = atoi(ft) + 1;   // (hooks build only: see FwdArgs)
         const bool uv_launch = uv && fw.uses_gather;
-        if ((e = rec.begin(forward_kernel_name(fw.kernel, uv_launch), stage_no, fw.grid, fw.flops, fw.bytes)) != hipSuccess)
+        const int fwd_kernel = shared ? FWD_KERNEL_CLIP : fw.kernel;     // (shared: fw.kernel is FWD_KERNEL_F32 - `single` above)
+        if ((e = rec.begin(forward_kernel_name(fwd_kernel, uv_launch), stage_no, fw.grid, fw.flops, fw.bytes)) != hipSuccess)
             return hip_fail(e, "hipEventRecord");
 #ifdef R3D_TIMING
         static long long *timing_buf1 = nullptr;
@@ -380,13 +450,13 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
             if (fw.ntiles <= 65536) fa.dbg = timing_buf1;
         }
 #endif
-        if ((e = launch_forward(fa, fw.grid, fw.kernel, uv_launch, stream)) != hipSuccess) return hip_fail(e, "launch r3d_forward_f32");
+        if ((e = launch_forward(fa, fw.grid, fwd_kernel, uv_launch, stream)) != hipSuccess) return hip_fail(e, "launch r3d_forward_f32");
         a->last_clk_dev = cap == hipStreamCaptureStatusNone ? cnt + fw.ncnt + 2 : nullptr;   // (a captured call runs later, maybe never)
         if ((e = order_single_launch(stream, false)) != hipSuccess) return hip_fail(e, "hipEventRecord");
         if (own) {                     // the next call on these buffers needs no bind
             bd.valid = true;
             bd.bank = bank;
-            bd.uv = uv ? 1 : 0;
+            bd.uv = variant;
             bd.enc_ws = ba.enc_ws;
             bd.cam_stride = ba.cam_stride;
             bd.enc_bytes = ba.enc_bytes;

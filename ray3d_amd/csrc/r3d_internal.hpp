@@ -108,7 +108,7 @@ struct FwdArgs {
                               // its n-th GEMV tile neither stores nor reports (0: none; n + 1 stored)
     long long *dbg;
 };
-enum { FWD_KERNEL_F32 = 0, FWD_KERNEL_B3 = 1, FWD_KERNEL_LAT = 2, FWD_KERNEL_COUNT = 3 };   // specialisations of the single-launch forward
+enum { FWD_KERNEL_F32 = 0, FWD_KERNEL_B3 = 1, FWD_KERNEL_LAT = 2, FWD_KERNEL_CLIP = 3, FWD_KERNEL_COUNT = 4 };   // specialisations of the single-launch forward
 constexpr int BIND_NPTR = 18;  // pointer fields of a GemmProb, in the order r3d_bind_f32 walks them
 enum { BIND_NULL = 0, BIND_WS, BIND_ARENA0, BIND_ARENA1, BIND_IARENA0, BIND_IARENA1, BIND_X, BIND_PARAM, BIND_CAM, BIND_NBASE };
 struct BindArgs {
@@ -205,6 +205,15 @@ struct Layer {
     struct Pre { int ref_col0, ref_width, new_width, shrink_layer; };
     std::vector<Pre> pre;
     int cin_ref = 0;          // input width of the reference layer (== cin unless `pre` is used)
+    // Synthetic per-FRAME form of a first layer (shared_of >= 0; no state_dict tensor of its own): expand_conv is linear in
+    // its operand, whose columns are either relative to the operand row's first frame or to the window's current frame
+    // (tables above ENC_INVALID), so a row's pre-activation is E[first frame] + V[current frame] with
+    //   E[p] = W[:, row-relative columns] . gather(p) + b      V[q] = W[:, current-frame columns] . x(q)
+    // - two per-frame vectors that every window of a clip which contains the frame shares (trainer.py:47-58 makes N
+    // windows of a clip).  The layer has N = 2 C rows: [E | V], both gathered at the SAME frame
+    // (shared_split = first current-frame column of the source layer), linear (slope 1), bias in E.
+    int shared_of = -1;
+    int shared_split = 0;
 };
 
 struct Model {
@@ -223,6 +232,8 @@ struct Model {
         int cin, k0, k0pad;
         size_t lut_off;               // offset (ints) into the int arena
         size_t lut_uv_off;            // the same tables for the UV input mode (in_features == 3 only)
+        size_t lut_frame_off = 0, lut_frame_uv_off = 0;   // tables of the per-frame form (every column relative to the row's own frame)
+        int frame_layer = -1;         // the synthetic [E | V] layer (Layer::shared_of), -1: none
     };
     std::vector<Branch> branches;
     size_t global_lut_off = 0;        // LUT of GlobalInfo.fc_1's input (the current frame)
@@ -277,6 +288,7 @@ struct ProbSpec {
     bool enc_kernel;             // runs in r3d_gemm_enc_f32 (the model's first level is not fused), not in r3d_gemm_f32
     int enc_rows;
     int enc_step;                // frames between the operand rows of a window (3; 1 for the dense ablation's stride-1 expand_conv)
+    int frame_col = -1;          // fused first level: first column of this branch's [E | V] block in the plan's per-frame buffer (Plan::frame_buf), -1: none
     std::vector<int> deps;
     int depth;
     double flops_per_window;     // 2 * rows * K_true * N_true
@@ -304,14 +316,18 @@ struct Schedule {
     std::vector<StageSchedule> stages;
     int4 *d_tiles = nullptr;
     int *d_wgoff = nullptr;
+    // the launch of per-frame first layers a clip call runs ahead of its forward (Plan::frame_probs; B + RF - 3 rows each)
+    StageSchedule frame_stage{};
+    int4 *d_frame_tiles = nullptr;
+    int *d_frame_wgoff = nullptr;
     // single-launch form (empty / null when the plan has launches it cannot hold: r3d_gemm_enc_f32 stages)
     struct Fwd {
         int grid = 0, ntiles = 0, ncnt = 0, nprob = 0;
         std::vector<int> cnt_base;            // per table index: first ready counter
         int4 *d_tiles = nullptr;              // FWD_TILE_INT4 int4 per tile
         int *d_wgoff = nullptr;
-        GemmProb *d_rel[2] = {nullptr, nullptr};        // relative problem tables: rays mode / UV mode (built on first use)
-        unsigned char *d_tags[2] = {nullptr, nullptr};
+        GemmProb *d_rel[4] = {nullptr, nullptr, nullptr, nullptr};   // relative problem tables: rays / UV input, + 2: first levels on the per-frame buffer (CallShape::shared)
+        unsigned char *d_tags[4] = {nullptr, nullptr, nullptr, nullptr};
         std::vector<int> h_tiles, h_wgoff;    // host copies of the lists (diagnostics)
         double flops = 0, bytes = 0;
         bool uses_gather = false;             // some problem gathers from the input (UV mode selects the _uv kernel)
@@ -362,6 +378,14 @@ struct Plan {
     int kind = 0;                // PLAN_FUSED, or one of the less fused plans of small calls (plan_kind)
     int64_t floats_per_window = 0;
     int64_t tail_floats = 0;     // slack behind the last buffer (the dense ablation's overlapping operand rows read past a window's end)
+    // Clip calls (window stride one frame): the first layers evaluated once per input FRAME instead of once per window
+    // row (Layer::shared_of) by a launch of gathered GEMMs ahead of the forward, into one buffer of frame_ld floats per
+    // frame - the blocks [E | V] of every fused first level side by side - that the first-level tiles then read instead of
+    // gathering and multiplying (r3d_kernels.hip, first_level_shared).  The buffer holds B + RF - 1 rows: B of them from
+    // its per-window share, the rest from Plan::tail_floats.
+    int frame_buf = -1, frame_ld = 0;
+    struct FrameProb { int model, layer, col, lut, lut_uv; };
+    std::vector<FrameProb> frame_probs;
     int emb_buf[2] = {-1, -1};
     int param_buf = -1;          // pseudo-buffer standing for r3d_input::param_dev
     // fused decoder tail: (model, layer, hidden buffer) per Integration block
@@ -382,6 +406,7 @@ struct Bases {
 };
 struct CallShape {
     bool uv = false;
+    bool shared = false;    // the fused first levels read the per-frame buffer (Plan::frame_buf) instead of gathering
     int64_t window_stride = 0, param_stride = 0, cam_stride = 0;
     long long frames = 0;
 };

@@ -1353,6 +1353,7 @@ constexpr int FLT_G_LD = 64 + 4;                                         // a 64
 constexpr int FLT_G_FLOATS = FLT_MAX_MI * 32 * FLT_G_LD;                 //  4,352 per buffer
 constexpr int FLT_LUT_OFF = FLT_H_FLOATS + 2 * FLT_G_FLOATS;
 static_assert((FLT_LUT_OFF + FL_LUT_INTS) * 4 <= GEMM_LDS_BYTES, "the tap-wise first level fits the GEMM kernel's LDS allocation");
+static_assert((2 * FLT_H_FLOATS + 256) * 4 <= GEMM_LDS_BYTES, "first_level_shared: two activation tiles and the row tables");
 
 template <int MI, bool MULTI, bool UV>   // MULTI: K0 > 64 (several 64-column chunks per tap: the trajectory model)
 __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_list, const int tstride, const int ntiles, const bool new_prob, float *smem, const gu32 cnt,
@@ -1665,6 +1666,248 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
         R3D_TSTAMP(4);
     }
     (void)M0;
+}
+
+
+// ------------------------------------------------------------------------------------ first level of a clip call
+//
+// first_level_shared: first_level_taps for calls whose windows slide over a clip one frame at a time
+// (lib/train_val/trainer.py:47-58).  expand_conv is linear in its operand, so the pre-activation of expand_conv row t of
+// window w is E[f] + V[c]: E of the row's first frame f = w * stride + 3 t, V of the window's current frame c (quirk Q1) -
+// two C-vectors per input FRAME that a launch of gathered GEMMs ahead of the forward left in the per-frame buffer
+// (r3d_api.cpp: Plan::frame_probs; row = frame, this branch's block [E | V] at P.x, P.enc_jf floats per row).  The 81
+// windows that contain a frame share them: the tile neither gathers nor multiplies for expand_conv - every lane loads the
+// 16 (row, column) values of its accumulator registers straight into them (two 128-byte row segments per wavefront
+// instruction), one tap ahead of their use and behind the previous tap's matrix work; V once per tile.  The rest - the
+// tap-wise 3-tap convolution, the 1x1 convolution, the residual tap's activations kept in registers - is first_level_taps.
+template <int MI>
+__device__ __forceinline__ void first_level_shared(ProbRef P, const int4 *tile_list, const int tstride, const int ntiles, float *smem, const gu32 cnt,
+                                                   long long *dbg_base) {
+    static_assert(MI >= 1 && MI <= FLT_MAX_MI, "tile height");
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int w_voff = lane * 16;
+    const int M = P.M;
+    const int res_tap = P.res_tap;
+    const int rpw = P.enc_rows / 3;                           // output rows per window
+    const int ld4 = P.enc_jf * 4;                             // bytes per row of the per-frame buffer
+    float *H = smem;
+    int *rowtab = reinterpret_cast<int *>(smem + FLT_H_FLOATS);   // [2][2][64]: (E row offset, V row offset) of a tile's rows, double buffered
+    float *HR = smem + FLT_H_FLOATS + 256;                    // the residual tap's activations: operand of its matrix phase AND kept for the
+                                                              // epilogue (32 MI registers less than holding them, which is what spilled)
+    __syncthreads();                                          // (the previous tile is done with LDS)
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x), 0, P.enc_bytes, 0x00020000);
+    const int col = wave * 32 + li;
+    const unsigned ecol = col < P.N ? (unsigned)col * 4u : 0x7ffffff0u;             // (columns past C: beyond the descriptor's bound - zeros)
+    const unsigned vcol = col < P.N ? (unsigned)(P.N + col) * 4u : 0x7ffffff0u;
+    auto load_frag = [&](__amdgpu_buffer_rsrc_t rs, int kt, f32x4 (&dst)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            dst[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, w_voff + q * 1024, kt * 4096, 0));
+    };
+    const int nk1 = P.K2 / BK, tiles_per_tap = nk1 / 3, nk2 = P.K3 / BK;
+    __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.w2 + ((size_t)wave_u * nk1) * 1024), 0, nk1 * 4096, 0x00020000);
+    __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.w3 + ((size_t)wave_u * nk2) * 1024), 0, nk2 * 4096, 0x00020000);
+    const float slope0 = P.slope, slope1 = P.slope2, slope2 = P.slope3;
+    auto bias_at = [&](const float *b) {
+        int c = wave * 32 + li;
+        asm volatile("" : "+v"(c));
+        return gload1(b + c);
+    };
+    auto tap_of = [&](int ts) { return ts == 0 ? 0 : ts == 2 ? res_tap : 3 - res_tap; };   // the residual tap comes last
+    // rows of a tile -> byte offsets of their E row (tap 0) and of their window's V row
+    auto fill_rowtab = [&](int row0, int buf) {
+        if (tid < MI * 32) {
+            const int orow = row0 + tid < M ? row0 + tid : M - 1;
+            const int win = orow / rpw, j = orow - win * rpw;
+            const unsigned wb = (unsigned)win * (unsigned)P.enc_ws;
+            rowtab[buf * 128 + tid] = (int)(wb * 4u + (unsigned)(9 * j) * (unsigned)ld4);
+            rowtab[buf * 128 + 64 + tid] = (int)((wb + (unsigned)P.enc_cur) * 4u);
+        }
+    };
+    f32x16 acc0[MI], vt[MI], acc1[MI];
+    auto issue_e = [&](int buf, int tap) {
+        const int so = __builtin_amdgcn_readfirstlane(tap * 3 * ld4);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                acc0[mi][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frs, (unsigned)rowtab[buf * 128 + lr] + ecol, so, 0));
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);       // (four row offsets at a time: hoisting all the table reads spills)
+            }
+    };
+    auto issue_v = [&](int buf) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                vt[mi][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frs, (unsigned)rowtab[buf * 128 + 64 + lr] + vcol, 0, 0));
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+    f32x4 rb[4], rbn[4], rbn2[4];                            // streaming weight fragments (three sets rotating: 555 k against 544 k poses/s with two)
+    fill_rowtab(__builtin_amdgcn_readfirstlane(tile_list[0].y), 0);
+    __syncthreads();
+    issue_e(0, 0);
+    issue_v(0);
+#pragma unroll 1
+    for (int ti = 0; ti < ntiles; ++ti) {
+        const int row0 = __builtin_amdgcn_readfirstlane(tile_list[ti * tstride].y);
+        const int next_row0 = ti + 1 < ntiles ? __builtin_amdgcn_readfirstlane(tile_list[(ti + 1) * tstride].y) : -1;
+        const int cur = ti & 1;
+#ifdef R3D_TIMING
+        long long *dbg = dbg_base && ti < 8 ? dbg_base + ti * 8 : nullptr;
+#else
+        long long *dbg = nullptr;
+        (void)dbg;
+        (void)dbg_base;
+#endif
+        R3D_TSTAMP(0);
+        if (next_row0 >= 0) fill_rowtab(next_row0, cur ^ 1);   // (visible behind this tile's first barrier; read at its last tap)
+        const float b1v = bias_at(P.bias2);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[mi][r] = b1v;
+#pragma unroll 1
+        for (int ts = 0; ts < 3; ++ts) {
+            const int tap = tap_of(ts);
+            // ---- this tap's expand_conv activations (E + V arrived during the previous matrix phase) -> H
+            load_frag(w1rsrc, tap * tiles_per_tap, rb);
+            load_frag(w1rsrc, __builtin_amdgcn_readfirstlane(tap * tiles_per_tap + (tiles_per_tap > 1 ? 1 : 0)), rbn);
+            float *Ht = ts == 2 ? HR : H;                     // (the residual tap comes last)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                float *wr = Ht + (mi * 32 + 4 * lh) * PAIR_LD + wave * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = lrelu(acc0[mi][r] + vt[mi][r], slope0);
+            }
+            __syncthreads();
+            // ---- the next tap's values (the next tile's first tap behind the last one), in front of this tap's matrix work
+            if (ts < 2) issue_e(cur, tap_of(ts + 1));
+            else if (next_row0 >= 0) { issue_e(cur ^ 1, 0); issue_v(cur ^ 1); }
+            // ---- this tap's third of the 3-tap convolution: K = C, barrier-free, weights two K tiles ahead
+            {
+                const float *h_frag = Ht + li * PAIR_LD + lh * 16;
+                const int kbase = tap * tiles_per_tap, lastk = tiles_per_tap - 1;
+                auto k_tile1 = [&](int kin, f32x4 (&w_use)[4], f32x4 (&w_load)[4]) {
+                    load_frag(w1rsrc, kbase + (kin + 2 < lastk ? kin + 2 : lastk), w_load);
+                    const float *sp = h_frag + kin * BK;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 av[MI];
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) av[mi] = *reinterpret_cast<const f32x4 *>(sp + mi * 32 * PAIR_LD + q * 4);
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi)
+                                acc1[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][kk], w_use[q][kk], acc1[mi], 0, 0, 0);
+                    }
+                };
+                int kin = 0;
+                for (; kin + 2 < tiles_per_tap; kin += 3) {
+                    k_tile1(kin, rb, rbn2);
+                    k_tile1(kin + 1, rbn, rb);
+                    k_tile1(kin + 2, rbn2, rbn);
+                }
+                if (kin < tiles_per_tap) {
+                    k_tile1(kin, rb, rbn2);
+                    if (kin + 1 < tiles_per_tap) k_tile1(kin + 1, rbn, rb);
+                }
+            }
+            if (ts < 2) __syncthreads();                      // every wavefront is done reading this tap's H (the last tap's is HR)
+        }
+        R3D_TSTAMP(1);
+        // ---- level activations -> H; the 1x1 convolution on them
+        load_frag(w2rsrc, 0, rb);
+        load_frag(w2rsrc, nk2 > 1 ? 1 : 0, rbn);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            float *wr = H + (mi * 32 + 4 * lh) * PAIR_LD + wave * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = lrelu(acc1[mi][r], slope1);
+        }
+        __syncthreads();
+        R3D_TSTAMP(2);
+        const float b2v = bias_at(P.bias3);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[mi][r] = b2v;
+        {
+            const float *h_frag = H + li * PAIR_LD + lh * 16;
+            const int last2 = nk2 - 1;
+            auto k_tile2 = [&](int kt, f32x4 (&w_use)[4], f32x4 (&w_load)[4]) {
+                load_frag(w2rsrc, kt + 2 < last2 ? kt + 2 : last2, w_load);
+                const float *sp = h_frag + kt * BK;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 av[MI];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) av[mi] = *reinterpret_cast<const f32x4 *>(sp + mi * 32 * PAIR_LD + q * 4);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+                            acc1[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][kk], w_use[q][kk], acc1[mi], 0, 0, 0);
+                }
+            };
+            int kt = 0;
+            for (; kt + 2 < nk2; kt += 3) {
+                k_tile2(kt, rb, rbn2);
+                k_tile2(kt + 1, rbn, rb);
+                k_tile2(kt + 2, rbn2, rbn);
+            }
+            if (kt < nk2) {
+                k_tile2(kt, rb, rbn2);
+                if (kt + 1 < nk2) k_tile2(kt + 1, rbn, rb);
+            }
+        }
+        R3D_TSTAMP(3);
+        // ---- epilogue: + the residual tap's activations (registers), rows transposed through H, 1 KiB stores
+        __syncthreads();                                     // every wavefront is done reading H
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            float *wr = H + (mi * 32 + 4 * lh) * PAIR_LD + wave * 32 + li;
+            const float *rr = HR + (mi * 32 + 4 * lh) * PAIR_LD + wave * 32 + li;        // (this lane's own values of the residual tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = lrelu(acc1[mi][r], slope2) + rr[((r & 3) + 8 * (r >> 2)) * PAIR_LD];
+        }
+        __syncthreads();
+        {
+            const int rd_row = tid >> 6, rd_c4 = (tid & 63) * 4;
+            const int N = P.N, ldc = P.ldc;
+            const __amdgpu_buffer_rsrc_t crs = act_rsrc(P.c + (size_t)row0 * ldc);
+#pragma unroll
+            for (int j = 0; j < 4 * MI; ++j) {
+                const int lr = rd_row + 8 * j, row = row0 + lr;
+                if (row >= M) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(H + lr * PAIR_LD + rd_c4);
+                if (rd_c4 + 4 <= N) {
+                    act_store4(crs, (lr * ldc + rd_c4) * 4, v);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (rd_c4 + c < N) act_store1(crs, (lr * ldc + rd_c4 + c) * 4, v[c]);
+                }
+            }
+        }
+        if (cnt) tile_drain();
+        __syncthreads();                                     // H is free for the next tile's activations
+        if (cnt) {
+            const int4 te = tile_list[ti * tstride + 1];     // {dependencies (none), first ready counter, granules, -}
+            tile_signal(cnt, __builtin_amdgcn_readfirstlane(te.y), __builtin_amdgcn_readfirstlane(te.z), MI);
+        }
+        R3D_TSTAMP(4);
+    }
 }
 
 
@@ -2387,7 +2630,7 @@ __device__ __forceinline__ void gemv_run(FwdArgsPtr fargs, const int4 *tl, const
 // three specialisations - r3d_forward_f32 (neither: the fp32 throughput tiles only), r3d_forward_b3, r3d_forward_lat - picked
 // on the host by what the schedule's tile lists hold, so that the headline kernel pays neither registers nor scratch for
 // code it never runs and a trace names the mode.
-template <bool ENC, bool UV, bool DEP = false, bool B3 = true, bool NARROW = true>
+template <bool ENC, bool UV, bool DEP = false, bool B3 = true, bool NARROW = true, bool CLIP = !DEP>
 __device__ __forceinline__ void gemm_persistent(float *smem) {
     LaunchArgsPtr args = (LaunchArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     FwdArgsPtr fargs = (FwdArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();      // (DEP: the same segment holds a FwdArgs)
@@ -2422,10 +2665,10 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
     }
     // The clock this launch ran at: workgroup 0 stamps its shader-cycle counter and the 100 MHz wall clock at both ends and
     // leaves the two differences behind the abort flag (words ncnt + 2, ncnt + 3 of its counter bank: r3d_last_clock).
-    long long clk_c0 = 0, clk_w0 = 0;
+    // (the start stamps wait in those two words, not in registers: four values live across the persistent loop spilled)
     if (DEP && blockIdx.x == 0 && threadIdx.x == 0) {
-        clk_c0 = __builtin_readcyclecounter();
-        clk_w0 = wall_clock64();
+        fargs->cnt[fargs->ncnt + 2] = (unsigned)__builtin_readcyclecounter();
+        fargs->cnt[fargs->ncnt + 3] = (unsigned)wall_clock64();
     }
     long long *dbg = nullptr;
 #ifdef R3D_TIMING
@@ -2491,7 +2734,12 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                 long long *run_dbg = nullptr;
 #endif
                 const int4 *tl = tiles + t * TS;
-                if (B3 && P.wb3 != nullptr) {   // fp32 on the bf16 matrix cores
+                if (CLIP && P.lut == nullptr) {   // a clip call: expand_conv's pre-activations come from the per-frame buffer
+                  if constexpr (CLIP) {
+                    if (mi >= 2) first_level_shared<2>(P, tl, TS, n, smem, cnt, run_dbg);
+                    else first_level_shared<1>(P, tl, TS, n, smem, cnt, run_dbg);
+                  }
+                } else if (B3 && P.wb3 != nullptr) {   // fp32 on the bf16 matrix cores
                   if constexpr (B3) {
                     if (P.K <= 64) {
                         if (mi >= 2) first_level_taps_b3<2, false, UV>(P, tl, TS, n, new_prob, smem, cnt, run_dbg);
@@ -2616,8 +2864,10 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
         }
     }
     if (DEP && blockIdx.x == 0 && threadIdx.x == 0) {
-        fargs->cnt[fargs->ncnt + 2] = (unsigned)(__builtin_readcyclecounter() - clk_c0);
-        fargs->cnt[fargs->ncnt + 3] = (unsigned)(wall_clock64() - clk_w0);
+        volatile unsigned *ck = fargs->cnt + fargs->ncnt + 2;
+        const unsigned c0 = ck[0], w0 = ck[1];
+        ck[0] = (unsigned)__builtin_readcyclecounter() - c0;      // (differences of the low words: a forward is far below 2^32 cycles)
+        ck[1] = (unsigned)wall_clock64() - w0;
     }
 #ifdef R3D_TIMING
     if (dbg_arg && threadIdx.x == 0) {
@@ -2643,18 +2893,20 @@ extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_uv_f32(const
 // The whole forward in one launch: every level's tiles, ordered by ready counters (wait_deps above).  One workgroup per
 // CU, all of them resident (grid <= CU count: a waiting workgroup can only wait for tiles of resident workgroups or of
 // its own past).
-#define R3D_FORWARD_KERNEL(name, UV_, B3_, NARROW_)                                                     \
+#define R3D_FORWARD_KERNEL(name, UV_, B3_, NARROW_, CLIP_)                                              \
     extern "C" __global__ __launch_bounds__(GEMM_THREADS) void name(const FwdArgs args_) {             \
         extern __shared__ __attribute__((aligned(16))) float smem[];                                    \
         (void)args_;                                                                                    \
-        gemm_persistent<false, UV_, true, B3_, NARROW_>(smem);                                          \
+        gemm_persistent<false, UV_, true, B3_, NARROW_, CLIP_>(smem);                                   \
     }
-R3D_FORWARD_KERNEL(r3d_forward_f32, false, false, false)        // the fp32 throughput tiles only (the headline kernel)
-R3D_FORWARD_KERNEL(r3d_forward_uv_f32, true, false, false)
-R3D_FORWARD_KERNEL(r3d_forward_b3, false, true, false)          // + the bf16x3 tiles (r3d_config.bf16x3, calls of >= 96 windows)
-R3D_FORWARD_KERNEL(r3d_forward_uv_b3, true, true, false)
-R3D_FORWARD_KERNEL(r3d_forward_lat, false, false, true)         // + GEMV / latency tiles (calls of <= 32 windows)
-R3D_FORWARD_KERNEL(r3d_forward_uv_lat, true, false, true)
+R3D_FORWARD_KERNEL(r3d_forward_f32, false, false, false, false)        // the fp32 throughput tiles only (the headline kernel)
+R3D_FORWARD_KERNEL(r3d_forward_uv_f32, true, false, false, false)
+R3D_FORWARD_KERNEL(r3d_forward_b3, false, true, false, false)          // + the bf16x3 tiles (r3d_config.bf16x3, calls of >= 96 windows)
+R3D_FORWARD_KERNEL(r3d_forward_uv_b3, true, true, false, false)
+R3D_FORWARD_KERNEL(r3d_forward_lat, false, false, true, false)         // + GEMV / latency tiles (calls of <= 32 windows)
+R3D_FORWARD_KERNEL(r3d_forward_uv_lat, true, false, true, false)
+R3D_FORWARD_KERNEL(r3d_forward_clip_f32, false, false, false, true)    // clip calls: first levels on the per-frame buffer (first_level_shared)
+R3D_FORWARD_KERNEL(r3d_forward_clip_uv_f32, true, false, false, true)  // (UV input: GlobalInfo's current frames are still gathered)
 
 // Ahead of r3d_forward_f32 on the same stream: zero the call's ready counters and abort flag, and turn the schedule's
 // relative problem table (pointer fields = byte offsets, one base tag per field) into this call's absolute one - the
@@ -2732,6 +2984,7 @@ static FwdKernel forward_kernel(int kind, bool uv) {
     switch (kind) {
         case FWD_KERNEL_B3: return uv ? r3d_forward_uv_b3 : r3d_forward_b3;
         case FWD_KERNEL_LAT: return uv ? r3d_forward_uv_lat : r3d_forward_lat;
+        case FWD_KERNEL_CLIP: return uv ? r3d_forward_clip_uv_f32 : r3d_forward_clip_f32;
         default: return uv ? r3d_forward_uv_f32 : r3d_forward_f32;
     }
 }
@@ -2739,6 +2992,7 @@ const char *forward_kernel_name(int kind, bool uv) {
     switch (kind) {
         case FWD_KERNEL_B3: return uv ? "r3d_forward_uv_b3" : "r3d_forward_b3";
         case FWD_KERNEL_LAT: return uv ? "r3d_forward_uv_lat" : "r3d_forward_lat";
+        case FWD_KERNEL_CLIP: return uv ? "r3d_forward_clip_uv_f32" : "r3d_forward_clip_f32";
         default: return uv ? "r3d_forward_uv_f32" : "r3d_forward_f32";
     }
 }

@@ -276,6 +276,31 @@ Model *model_create(const r3d_config &cfg) {
         br.lut_uv_off = m->iarena.size();
         m->iarena.insert(m->iarena.end(), l1uv.begin(), l1uv.end());
         m->iarena.insert(m->iarena.end(), lk.begin(), lk.end());
+        // the per-frame form (Layer::shared_of): the same columns, the current-frame ones gathered at the row's own frame
+        if (m->cfg.num_levels >= 2 && m->cfg.channels <= N_ALIGN && !m->cfg.dense && br.k0pad <= 256) {
+            std::vector<int> lk0(br.k0pad / 4, 0);
+            br.lut_frame_off = m->iarena.size();
+            m->iarena.insert(m->iarena.end(), l1.begin(), l1.end());
+            m->iarena.insert(m->iarena.end(), lk0.begin(), lk0.end());
+            br.lut_frame_uv_off = m->iarena.size();
+            m->iarena.insert(m->iarena.end(), l1uv.begin(), l1uv.end());
+            m->iarena.insert(m->iarena.end(), lk0.begin(), lk0.end());
+            Layer S;
+            S.weight_key = S.bias_key = S.bn_prefix = "";
+            S.taps = 1;
+            S.cin = S.cin_ref = br.k0pad;
+            S.N = 2 * m->cfg.channels;
+            S.K = S.Kpad = br.k0pad;
+            S.Npad = round_up(S.N, N_ALIGN);
+            S.slope = 1.0f;
+            S.frag = true;
+            S.w_off = S.b_off = 0;
+            S.shared_of = m->layer_index[br.prefix + ".expand_conv"];
+            S.shared_split = GX + GR;
+            br.frame_layer = (int)m->layers.size();
+            m->layer_index[br.prefix + ".expand_conv@frame"] = br.frame_layer;
+            m->layers.push_back(S);
+        }
     }
     // GlobalInfo.fc_1 reads in_current = x[:, RF // F] flattened (rie.py:290-292), zero padded to CUR_LD
     {
@@ -377,6 +402,21 @@ int model_finalize(Model *m) {
     Folder f{m};
     std::vector<double> s, t;
     for (auto &L : m->layers) {
+        if (L.shared_of >= 0) {
+            // [E | V] from the folded, column-mapped source layer (processed earlier: it precedes this one in the list)
+            const Layer &S = m->layers[L.shared_of];
+            const float *src = m->arena.data() + S.w_off, *sb = m->arena.data() + S.b_off;
+            float *dst = m->arena.data() + L.w_off, *bd = m->arena.data() + L.b_off;
+            const int nk = L.Kpad / BK, C = S.N;
+            for (int o = 0; o < C; ++o)
+                for (int k = 0; k < L.Kpad; ++k) {
+                    const float v = src[frag_index(o, k, nk)];
+                    dst[frag_index(o, k, nk)] = k < L.shared_split ? v : 0.0f;
+                    dst[frag_index(C + o, k, nk)] = k < L.shared_split ? 0.0f : v;
+                }
+            for (int o = 0; o < C; ++o) { bd[o] = sb[o]; bd[C + o] = 0.0f; }
+            continue;
+        }
         f.scale_shift(L, s, t);
         const float *w = f.get(L.weight_key);
         float *dst = m->arena.data() + L.w_off;

@@ -420,6 +420,35 @@ static Plan *build_plan(const Model *a, const Model *b, int kind) {
         levelise(false, false, pl->stages_asap, true);
         if (pl->stages_asap == pl->stages) pl->stages_asap.clear();
     }
+    // the per-frame buffer of clip calls (Plan::frame_buf): LAST, so that its RF - 1 rows beyond B lie in the tail
+    {
+        bool all = true;
+        int col = 0;
+        std::vector<Plan::FrameProb> fps;
+        for (auto &q : pl->probs) {
+            if (q.layer3 < 0) continue;
+            const Model *mm = pl->m[q.model];
+            const Model::Branch *br = nullptr;
+            for (const auto &b : mm->branches)
+                if ((int)b.lut_off == q.enc_lut) br = &b;
+            if (!br || br->frame_layer < 0) { all = false; break; }
+            q.frame_col = col;
+            fps.push_back({q.model, br->frame_layer, col, (int)br->lut_frame_off, mm->cfg.in_features == 3 ? (int)br->lut_frame_uv_off : -1});
+            col += (mm->layers[br->frame_layer].N + 15) / 16 * 16;
+        }
+        if (all && !fps.empty() && fps.size() <= (size_t)MAX_PROB) {
+            Builder B{*pl, 0, *pl->m[0]};
+            pl->frame_ld = col;
+            pl->frame_buf = B.buffer("frames", col);
+            pl->frame_probs = fps;
+            int RF = 1;
+            for (const Model *mm : pl->m)
+                if (mm) RF = std::max(RF, mm->RF);
+            pl->tail_floats = std::max<int64_t>(pl->tail_floats, (int64_t)(RF + 2) * col);
+        } else {
+            for (auto &q : pl->probs) q.frame_col = -1;
+        }
+    }
     // workspace offsets
     int64_t off = 0;
     for (auto &bf : pl->buffers) {

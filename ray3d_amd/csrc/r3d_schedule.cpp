@@ -30,10 +30,12 @@ Schedule::~Schedule() {
     if (fwd.d_wgoff) (void)hipFree(fwd.d_wgoff);
     if (fwd.d_ctrl) (void)hipFree(fwd.d_ctrl);
     if (fwd.d_act) (void)hipFree(fwd.d_act);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
         if (fwd.d_rel[i]) (void)hipFree(fwd.d_rel[i]);
         if (fwd.d_tags[i]) (void)hipFree(fwd.d_tags[i]);
     }
+    if (d_frame_tiles) (void)hipFree(d_frame_tiles);
+    if (d_frame_wgoff) (void)hipFree(d_frame_wgoff);
 }
 
 bool forward_single_launch() {
@@ -736,6 +738,29 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
         delete s;
         return nullptr;
     }
+    // ---- the per-frame first layers of a clip call (Plan::frame_probs): one launch of gathered GEMMs over B + RF - 3 rows
+    if (pl->frame_buf >= 0) {
+        const int rows = (int)(B + pl->m[0]->RF - 3);
+        std::vector<SchedProb> fp;
+        for (const auto &f : pl->frame_probs) {
+            const Layer &L = pl->m[f.model]->layers[f.layer];
+            SchedProb sp{rows, L.N, L.Kpad / BK, 1, std::max(1, std::min(3, (64 * 1024) / ((L.Kpad + 4) * 4 * 32)))};
+            sp.nk2 = 2;
+            fp.push_back(sp);
+        }
+        std::vector<int4> ft;
+        std::vector<int> fo;
+        schedule_stage(fp, nwg, GEMM_SCHED_MAX_UNITS, ft, fo, s->frame_stage, false);
+        if ((e = hipMalloc((void **)&s->d_frame_tiles, std::max<size_t>(ft.size(), 1) * sizeof(int4))) != hipSuccess ||
+            (e = hipMalloc((void **)&s->d_frame_wgoff, std::max<size_t>(fo.size(), 1) * sizeof(int))) != hipSuccess ||
+            (e = hipMemcpy(s->d_frame_tiles, ft.data(), ft.size() * sizeof(int4), hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(s->d_frame_wgoff, fo.data(), fo.size() * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) {
+            hip_fail(e, "schedule upload (per-frame launch)");
+            delete s;
+            return nullptr;
+        }
+        s->frame_stage.tiles_off = s->frame_stage.wgoff_off = 0;
+    }
     // ---- the single-launch form: tile lists with dependencies + the relative problem tables (rays / UV input)
     if (forward_single_launch()) {
         std::vector<int> ft, fo;
@@ -746,21 +771,28 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
                       (e = hipMalloc((void **)&fw.d_wgoff, fo.size() * sizeof(int))) == hipSuccess &&
                       (e = hipMemcpy(fw.d_tiles, ft.data(), ft.size() * sizeof(int), hipMemcpyHostToDevice)) == hipSuccess &&
                       (e = hipMemcpy(fw.d_wgoff, fo.data(), fo.size() * sizeof(int), hipMemcpyHostToDevice)) == hipSuccess;
-            for (int uv = 0; ok && uv < 2; ++uv) {
-                if (uv && a->cfg.in_features != 3) break;
+            for (int v = 0; ok && v < 4; ++v) {           // v = UV input + 2 * first levels on the per-frame buffer
+                const int uv = v & 1, shared = v >> 1;
+                if (uv && a->cfg.in_features != 3) continue;
+                if (shared && pl->frame_buf < 0) break;
                 std::vector<GemmProb> rel(fw.nprob);
                 std::vector<unsigned char> tags((size_t)fw.nprob * BIND_NPTR);
                 Bases none;
                 CallShape cs;
                 cs.uv = uv != 0;
+                cs.shared = shared != 0;
+                if (shared) {                              // (a clip call: window stride one frame - r3d_api.cpp, run)
+                    cs.window_stride = 1;
+                    cs.frames = B + a->RF - 1;
+                }
                 bool filled = true;
                 for (int i = 0; i < fw.nprob && filled; ++i)
                     filled = fill_prob(pl, pl->probs[i], B, a, none, cs, rel[i], tags.data() + (size_t)i * BIND_NPTR) == R3D_OK;
-                if (!filled) { if (uv) break; ok = false; break; }
-                ok = (e = hipMalloc((void **)&fw.d_rel[uv], rel.size() * sizeof(GemmProb))) == hipSuccess &&
-                     (e = hipMalloc((void **)&fw.d_tags[uv], tags.size())) == hipSuccess &&
-                     (e = hipMemcpy(fw.d_rel[uv], rel.data(), rel.size() * sizeof(GemmProb), hipMemcpyHostToDevice)) == hipSuccess &&
-                     (e = hipMemcpy(fw.d_tags[uv], tags.data(), tags.size(), hipMemcpyHostToDevice)) == hipSuccess;
+                if (!filled) { if (v) continue; ok = false; break; }
+                ok = (e = hipMalloc((void **)&fw.d_rel[v], rel.size() * sizeof(GemmProb))) == hipSuccess &&
+                     (e = hipMalloc((void **)&fw.d_tags[v], tags.size())) == hipSuccess &&
+                     (e = hipMemcpy(fw.d_rel[v], rel.data(), rel.size() * sizeof(GemmProb), hipMemcpyHostToDevice)) == hipSuccess &&
+                     (e = hipMemcpy(fw.d_tags[v], tags.data(), tags.size(), hipMemcpyHostToDevice)) == hipSuccess;
             }
             fw.h_tiles = ft;
             fw.h_wgoff = fo;
@@ -783,7 +815,7 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
                     if (fw.d_tiles) (void)hipFree(fw.d_tiles);
                     if (fw.d_wgoff) (void)hipFree(fw.d_wgoff);
                     if (fw.d_ctrl) (void)hipFree(fw.d_ctrl);
-                    for (int i = 0; i < 2; ++i) {
+                    for (int i = 0; i < 4; ++i) {
                         if (fw.d_rel[i]) (void)hipFree(fw.d_rel[i]);
                         if (fw.d_tags[i]) (void)hipFree(fw.d_tags[i]);
                     }

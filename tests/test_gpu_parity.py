@@ -173,10 +173,16 @@ def test_calls_of_five_to_32_windows_run_the_latency_tiles(over, monkeypatch):
         assert not np.array_equal(outs[0], outs[1])
 
 
-def test_forward_clip_equals_materialised_windows():
-    """In-kernel sliding windows (window_stride = 1) == eval_data_prepare's copies (trainer.py:47-58)."""
+@pytest.mark.parametrize("per_frame", [True, False], ids=["per-frame-first-layers", "gathered"])
+def test_forward_clip_equals_materialised_windows(per_frame, monkeypatch):
+    """In-kernel sliding windows (window_stride = 1) == eval_data_prepare's copies (trainer.py:47-58).  A clip call
+    evaluates expand_conv once per input FRAME (first_level_shared: E[first frame] + V[current frame] instead of one
+    gathered product per window row - another summation order, same values to fp32 rounding); with that switched off
+    (R3D_NO_SHARED_L0, hooks build) the two calls are the same arithmetic in the same order: bit-identical."""
     import ray3d_amd
     from ray3d_amd import synth
+    if not per_frame:
+        dev_switch(monkeypatch, "R3D_NO_SHARED_L0", "1")
     mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
     pos, trj, (cp, _), _ = build_modules(mc)
     lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
@@ -190,7 +196,11 @@ def test_forward_clip_equals_materialised_windows():
         a = lifter.forward_clip(torch.from_numpy(clip).cuda(), torch.from_numpy(prow).cuda()).cpu().numpy()
         b = lifter(torch.from_numpy(windows).cuda(), torch.from_numpy(np.tile(prow, (n, 1))).cuda()).cpu().numpy()
         assert a.shape == (n, 1, 17, 3)
-        assert np.array_equal(a, b)        # same arithmetic, same order: bit-identical
+        if per_frame:
+            check_parity(a, b, "clip call (per-frame first layers) vs the same windows materialised", tol=1e-5 * max(1.0, float(np.abs(b).max())))
+            assert not np.array_equal(a, b)    # (it did take the other path)
+        else:
+            assert np.array_equal(a, b)        # same arithmetic, same order: bit-identical
         # chunked: 64 windows per forward, the last chunk rounded up to a multiple of 32 over repeated last frames
         lifter.CLIP_CHUNK, lifter.CLIP_ROUND = 64, 32
         c = lifter.forward_clip(torch.from_numpy(clip).cuda(), torch.from_numpy(prow).cuda())
