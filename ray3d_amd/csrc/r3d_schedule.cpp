@@ -444,11 +444,8 @@ void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units,
     const size_t t0 = tiles.size();
     int grid = 0;
     wgoff.push_back(0);
-    // (experiment, R3D_XCD_ALIGN=1 in the hooks build: empty bins keep their place, so that bin b of a launch of n = CUs bins
-    //  is workgroup-of-XCD b / (n / 8) whatever the launch holds - a layer of 32 tiles then sits on ONE XCD, level after level)
-    const bool keep_empty = hook_on("R3D_XCD_ALIGN") && !enc;
     for (const auto &bin : best->a.bins) {
-        if (bin.empty() && !keep_empty) continue;
+        if (bin.empty()) continue;
         for (const Run &r : bin) {
             // emit the run as evenly sized tiles of <= cap units
             const int nt = (r.n + r.cap - 1) / r.cap;
