@@ -17,5 +17,5 @@ find $O -name "*.csv" | head -30
 # the summaries that get committed: per-kernel stats of the traced run, the bench line of that run, the PMC table
 cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 grep '^{' $O/trace.log > $O/bench_line.json
-python $R/profiles/summarize_pmc.py $O > $O/pmc_table.txt
+python $R/profiles/summarize_pmc.py $O > $O/pmc_table.txt   # (+ $O/pmc_summary.json)
 du -sh $O

@@ -441,6 +441,74 @@ def test_h36m_shape_eval_rf243_against_the_oracle_chain():
 
 
 
+def test_clip_calls_run_the_per_frame_first_layers():
+    """A call whose windows slide over a clip one frame at a time (trainer.py:47-58) evaluates expand_conv once per input
+    frame: a launch of gathered GEMMs ahead of the forward, then r3d_forward_clip_f32 (first_level_shared).  Checked here:
+    which kernels run (rays and pixel input; per-window cameras and independent windows keep the gathered path), the
+    oracle on every window, the level-by-level form, and a captured call replayed on new clip contents."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    from oracle import torch_port
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3,3")
+    pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    lifter.CLIP_ROUND = 0
+    rf, n = 81, 200
+    cams, ocams, _, _ = _dhp_cameras()
+    cam = cams[2]
+    rng = np.random.default_rng(11)
+    uv = (rng.uniform(200, 1800, (1, 17, 2)) + np.cumsum(rng.normal(0, 3.0, (n + rf - 1, 17, 2)), axis=0)).astype(np.float32)
+    rays = cam.rays_from_uv(uv.astype(np.float64)).astype(np.float32)
+    prow = cam.param().astype(np.float32)
+    windows = np.stack([rays[i:i + rf] for i in range(n)])
+    sds = [{k: torch.from_numpy(np.asarray(v)) for k, v in s_.items()} for s_ in (sp, st)]
+    with torch.no_grad():
+        ref = (torch_port.forward(cp, sds[0], torch.from_numpy(windows), torch.from_numpy(np.tile(prow, (n, 1)))) +
+               torch_port.forward(ct, sds[1], torch.from_numpy(windows), torch.from_numpy(np.tile(prow, (n, 1))))).numpy()
+    names = lambda recs: [r["kernel"] for r in recs]
+    clip_d, uv_d = torch.from_numpy(rays).cuda(), torch.from_numpy(uv).cuda()
+    p_d, row_d = torch.from_numpy(prow).cuda(), torch.from_numpy(cam.cam_row()).cuda()
+    staged_env = os.environ.get("R3D_STAGED") == "1"
+    with torch.no_grad():
+        a = lifter.forward_clip(clip_d, p_d)
+        check_parity(a, ref, "rays clip")
+        recs = names(lifter.profile_call(lambda: lifter.forward_clip(clip_d, p_d), "cuda:0"))
+        if not staged_env:
+            assert "r3d_forward_clip_f32" in recs and "r3d_forward_f32" not in recs and recs.count("r3d_gemm_f32") == 1, recs
+        b = lifter.forward_uv(uv_d, row_d, p_d)                   # pixel clip, ONE camera: per-frame first layers too
+        check_parity(b, ref, "pixel clip, one camera")
+        recs = names(lifter.profile_call(lambda: lifter.forward_uv(uv_d, row_d, p_d), "cuda:0"))
+        if not staged_env:
+            assert "r3d_forward_clip_uv_f32" in recs and recs.count("r3d_gemm_uv_f32") == 1, recs
+        rows = row_d.view(1, 8).expand(n, 8).contiguous()        # a camera row PER WINDOW: frames have no single camera - gathered path
+        c = lifter.forward_uv(uv_d, rows, p_d)
+        check_parity(c, ref, "pixel clip, a camera row per window")
+        recs = names(lifter.profile_call(lambda: lifter.forward_uv(uv_d, rows, p_d), "cuda:0"))
+        if not staged_env:
+            assert "r3d_forward_uv_f32" in recs and "r3d_forward_clip_uv_f32" not in recs, recs
+        w = lifter(torch.from_numpy(windows).cuda(), p_d.view(1, 2).expand(n, 2).contiguous())   # independent windows: nothing to share
+        check_parity(w, ref, "materialised windows")
+        # a captured clip call (per-frame launch + forward in the graph), replayed on another clip behind the same pointer
+        lifter.prepare([n])
+        out = torch.empty((n, 1, 17, 3), device="cuda")
+        g, s_ = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        buf = clip_d.clone()
+        with torch.cuda.stream(s_):
+            with torch.cuda.graph(g, stream=s_):
+                lifter._run(ray3d_amd._capi.R3D_INPUT_RAYS, buf, 1, n, p_d, 0, out=out)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, a)
+        buf.copy_(torch.flip(clip_d, dims=[0]))
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, lifter.forward_clip(torch.flip(clip_d, dims=[0]).contiguous(), p_d))
+        # the level-by-level form (R3D_OPT_STAGED) reads the same per-frame buffer
+        lifter.set_staged(True)
+        check_parity(lifter.forward_clip(clip_d, p_d), ref, "rays clip, level by level")
+        assert torch.equal(lifter.forward_clip(clip_d, p_d), a)
+
+
 def test_rf243_flip_tta_and_uv_clip_mode_against_the_oracle_chain():
     """RF 243 with what the h36m-shape test leaves out: (a) flip test-time augmentation (lib/train_val/trainer.py:299-302,
     338-353: mirrored input, mirrored output, mean) through evaluate_clips, against the oracle chain restated here with
