@@ -193,9 +193,11 @@ def roofline(lifter, x, p, step_ms, reps=5, fn=None, batch=None, key=None):
     key = key or ("b%d" % batch)
     prec = lifter.precision(dev)
     peak = PEAK_FP32_MFMA_TFLOPS if prec == "f32" else PEAK_BF16X3_TFLOPS
-    for _ in range(3):
+    # the clock of a BUSY chip: after a synchronisation the clocks need tens of forwards to come back (a reading behind three
+    # forwards says 2.1 GHz where the steady state runs at 2.4), and the event-bracketed launches below run at yet another one
+    for _ in range(40):
         fn()
-    clk = lifter.last_clock_ghz(dev)                   # (before the bracketed launches: those run at another clock)
+    clk = lifter.last_clock_ghz(dev)
     lifter.profile_call(fn, dev)
     pair_ms = []
     for _ in range(reps):

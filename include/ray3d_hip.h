@@ -194,10 +194,9 @@ int r3d_profile_enable(r3d_model *m, int on);
 int r3d_profile_read(r3d_model *m, r3d_launch_record *records, int capacity);
 
 /* The shader clock the handle's last single-launch forward ran at, in GHz (for a pair: ask the pos handle): the kernel's
- * first workgroup stamps its cycle counter and the 100 MHz wall clock at both ends.  Synchronises `hip_stream`.  What the
- * chip sustains under the fp32 matrix work on real operands is below the 2.4 GHz the datasheet peak is quoted at
- * (measured: DESIGN.md), so a roofline needs it next to the rate (north_star: counters against the gfx950 peak - there is
- * no reference counterpart).  *ghz = 0 when the last forward ran level by level (R3D_OPT_STAGED, plans the single launch
+ * first workgroup stamps its cycle counter and the 100 MHz wall clock at both ends.  Synchronises `hip_stream`.  The
+ * first forwards after an idle period run below the clock a busy chip settles at, so a roofline wants it
+ * next to the rate (north_star: counters against the gfx950 peak - there is no reference counterpart).  *ghz = 0 when the last forward ran level by level (R3D_OPT_STAGED, plans the single launch
  * cannot hold) or none ran yet. */
 int r3d_last_clock(r3d_model *m, void *hip_stream, double *ghz);
 

@@ -397,7 +397,9 @@ class Ray3DLifter(nn.Module):
                 sizes.append(r)
             else:
                 up = -(-r // self.CLIP_ROUND) * self.CLIP_ROUND
-                for small in (32, 64):
+                # (short rests: the sizes whose schedules hold the GEMV / latency tiles of calls of a few windows - a
+                #  one-window rest lifted as 32 would do 2-30 times the work)
+                for small in (1, 2, 4, 8, 16, 32, 64):
                     if r <= small < up:
                         up = small
                         break

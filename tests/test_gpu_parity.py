@@ -441,6 +441,30 @@ def test_h36m_shape_eval_rf243_against_the_oracle_chain():
 
 
 
+def test_last_clock_reports_the_shader_clock_of_a_single_launch_forward():
+    """r3d_last_clock: workgroup 0 of the persistent kernel stamps its cycle counter and the 100 MHz wall clock at both ends;
+    the ratio is the shader clock of that forward (bench.py's roofline.clk_ghz).  0 for a level-by-level forward."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
+    pos, trj, (cp, _), _ = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    x = torch.from_numpy(synth.synth_rays(256, cp, seed=1)).cuda()
+    p = torch.from_numpy(synth.synth_param(256, seed=2)).cuda()
+    assert lifter.last_clock_ghz("cuda:0") == 0.0                  # nothing ran yet
+    with torch.no_grad():
+        for _ in range(30):
+            out = lifter(x, p)
+        ghz = lifter.last_clock_ghz("cuda:0")
+        if os.environ.get("R3D_STAGED") == "1":
+            assert ghz == 0.0
+            return
+        assert 0.5 < ghz < 2.6, ghz                               # (MI355X: 2.4 GHz maximum)
+        lifter.set_staged(True)
+        assert torch.equal(lifter(x, p), out)
+        assert lifter.last_clock_ghz("cuda:0") == 0.0
+
+
 def test_clip_calls_run_the_per_frame_first_layers():
     """A call whose windows slide over a clip one frame at a time (trainer.py:47-58) evaluates expand_conv once per input
     frame: a launch of gathered GEMMs ahead of the forward, then r3d_forward_clip_f32 (first_level_shared).  Checked here:
@@ -507,6 +531,34 @@ def test_clip_calls_run_the_per_frame_first_layers():
         lifter.set_staged(True)
         check_parity(lifter.forward_clip(clip_d, p_d), ref, "rays clip, level by level")
         assert torch.equal(lifter.forward_clip(clip_d, p_d), a)
+
+
+@pytest.mark.parametrize("over", [dict(ARCHITECTURE="3,3"), dict(ARCHITECTURE="3,3", NUM_KPTS=14, STAGE=2),
+                                  dict(ARCHITECTURE="3,3,3", NUM_KPTS=15), dict(ARCHITECTURE="3,3,3", CHANNELS=128, LATENT_FEATURES_DIM=160),
+                                  dict(ARCHITECTURE="3,3,3,3", DISABLE_OPTIMIZATIONS=True, CAUSAL=True),
+                                  dict(ARCHITECTURE="3,3,3", INPUT_DIM=2, CAMERA_EMBDDING=False)],
+                         ids=["rf9", "j14-rf9-s2", "j15-rf27", "c128", "rf81-causal-dilated", "f2-noemb"])
+def test_clip_calls_of_many_lengths_equal_their_materialised_windows(over):
+    """forward_clip over clips of 1 ... ~700 windows (every tail size of clip_batch_sizes, chunks of 256: the plans of
+    small, medium and large calls; per-frame first layers where the plan has them) against the same windows materialised
+    and lifted as independent windows - the two differ in summation order at most."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    mc = ray3d_amd.default_model_config(**over)
+    pos, trj, (cp, _), _ = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    lifter.CLIP_CHUNK = 256
+    rf, J, F = cp.receptive_field, cp.num_joints, cp.in_features
+    rng = np.random.default_rng(123)
+    prow = torch.from_numpy(np.array([1.4, 0.15], np.float32)).cuda()
+    for n in (1, 2, 3, 5, 11, 17, 40, 64, 97, 130, 257, 300, 511, 700):
+        clip = (rng.normal(0, 0.4, (1, J, F)) + np.cumsum(rng.normal(0, 0.03, (n + rf - 1, J, F)), axis=0)).astype(np.float32)
+        windows = np.stack([clip[i:i + rf] for i in range(n)])
+        with torch.no_grad():
+            a = lifter.forward_clip(torch.from_numpy(clip).cuda(), prow)
+            b = lifter(torch.from_numpy(windows).cuda(), prow.view(1, 2).expand(n, 2).contiguous() if cp.camera_embedding else None)
+        assert a.shape == (n, 1, J, 3)
+        check_parity(a, b.cpu().numpy(), "%d windows" % n, tol=2e-5 * max(1.0, float(b.abs().max())))
 
 
 def test_rf243_flip_tta_and_uv_clip_mode_against_the_oracle_chain():

@@ -768,20 +768,22 @@ def test_camera_augmentation_grid_matches_the_reference_script():
 
 
 def test_clip_batch_sizes_share_a_handful_of_schedules():
-    """Ray3DLifter.clip_batch_sizes: 4096-window chunks, the rest rounded up to a multiple of 128 - to 32 or 64 when it
-    is that short - so that clips of any length use at most 34 batch sizes; CLIP_ROUND = 0 lifts exact sizes."""
+    """Ray3DLifter.clip_batch_sizes: 4096-window chunks, the rest rounded up to a multiple of 128 - to 1, 2, 4 ... 64 when it
+    is that short (the GEMV / latency schedules of calls of a few windows) - so that clips of any length use at most 39
+    batch sizes; CLIP_ROUND = 0 lifts exact sizes."""
     mc = default_model_config(ARCHITECTURE="3,3")
     fac = ray3d_amd.Model(mc, {}, is_train=False)
     lifter = ray3d_amd.Ray3DLifter(fac.get_pos_model(), fac.get_trj_model())
-    assert lifter.clip_batch_sizes(1) == [32] and lifter.clip_batch_sizes(33) == [64] and lifter.clip_batch_sizes(65) == [128]
+    assert lifter.clip_batch_sizes(1) == [1] and lifter.clip_batch_sizes(3) == [4] and lifter.clip_batch_sizes(17) == [32]
+    assert lifter.clip_batch_sizes(33) == [64] and lifter.clip_batch_sizes(65) == [128]
     assert lifter.clip_batch_sizes(128) == [128] and lifter.clip_batch_sizes(129) == [256]
-    assert lifter.clip_batch_sizes(4096) == [4096] and lifter.clip_batch_sizes(4097) == [4096, 32]
+    assert lifter.clip_batch_sizes(4096) == [4096] and lifter.clip_batch_sizes(4097) == [4096, 1]
     assert lifter.clip_batch_sizes(5000) == [4096, 1024] and lifter.clip_batch_sizes(9000) == [4096, 4096, 896]
     seen = set()
     for n in range(1, 13000, 7):
         sizes = lifter.clip_batch_sizes(n)
         assert sum(sizes) >= n and sum(sizes) - n < 128
         seen.update(sizes)
-    assert len(seen) <= 34
+    assert len(seen) <= 39
     lifter.CLIP_ROUND = 0
     assert lifter.clip_batch_sizes(5000) == [4096, 904]

@@ -97,7 +97,16 @@ int main(int argc, char **argv) {
     for (int i = 0; i < 3; ++i) CK(launch());
     CK(hipDeviceSynchronize());
     float best = 1e9, sum = 0;
-    for (int i = 0; i < reps; ++i) {
+    if (getenv("PROBE_NOSYNC")) {   // back to back, no host synchronisation between the launches: the clock of a busy chip
+        for (int i = 0; i < 200; ++i) CK(launch());
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < reps; ++i) CK(launch());
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("back to back: %.1f us per launch\n", ms * 1e3 / reps);
+    }
+    for (int i = 0; i < (getenv("PROBE_NOSYNC") ? 0 : reps); ++i) {
         CK(hipEventRecord(e0, 0));
         CK(launch());
         CK(hipEventRecord(e1, 0));

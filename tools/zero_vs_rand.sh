@@ -1,4 +1,7 @@
-cd $GRAFT_REPO_ROOT
-# the shader clock of an M = B launch (cycle counter against the 100 MHz wall clock per workgroup: "eff GHz"): random / zero
-# operands; every problem streaming the same 4 MB of weights (L2-resident) instead of its own
-for z in "" "PROBE_ZERO=1" "PROBE_SHARE_W=1" "PROBE_SHARE_W=1 PROBE_SHARE_A=1"; do for K in 1024 4096; do echo "== [$z] K=$K"; env $z ./tools/gemm_probe_timing.bin 7 256 1024 $K 30 | grep -E "best|wall span| [0-9]+: 1 " | head -5; done; done
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+# An M = B launch (7 x 256 x 1024 x K) - cycles and shader clock per workgroup ("eff GHz": cycle counter against the 100 MHz wall
+# clock) - launched with a host synchronisation after every launch and back to back (PROBE_NOSYNC), on random and on all-zero
+# operands.
+for sync in "" "PROBE_NOSYNC=1"; do for z in "" "PROBE_ZERO=1"; do for K in 1024 4096; do
+  echo "== [$sync $z] K=$K"; env $sync $z ./tools/gemm_probe_timing.bin 7 256 1024 $K 200 | grep -E "best|back to back|wall span| [0-9]+: 1 " | head -5
+done; done; done
