@@ -680,6 +680,31 @@ def main():
                                           % (world, args.clips, evaluate.PARTIAL_COLS)},
                 "mpjpe_mm": {"action_average": avg[0], "p_mpjpe": avg[1], "n_mpjpe": avg[2], "mpjve": avg[3], "mrpe": avg[4],
                              "checksum": float(allrows[allrows[:, 0].argsort()][:, 3].sum().item())}})
+            # the whole pass as a rate: every window is 251.7 MFLOP of the reference's arithmetic, whatever the
+            # clip path shares between windows - and the roofline of its dominant kernel on ONE full chunk of the first clip
+            flops_per_window = 251.7e6
+            line["algorithmic_tflops"] = round(frames * args.steps / elapsed * flops_per_window / 1e12, 2)
+            line["frac_of_fp32_mfma_peak"] = round(line["algorithmic_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
+            if world == 1 and mine and lifter.precision(dev) == "f32":
+                def _clip_roofline():
+                    nb = lifter.CLIP_CHUNK
+                    c, padded, prow, _ = max(mine, key=lambda t: t[1].shape[0])
+                    reps = -(-(nb + 242) // padded.shape[0])
+                    clipb = torch.cat([padded] * reps, dim=0)[: nb + 242].contiguous()
+                    run = lambda: lifter.forward_clip(clipb, prow)
+                    with torch.no_grad():
+                        run()
+                        settle_clocks(run, dev, group=5, max_groups=20)
+                        el_c, dev_c, _ = timed_steps(run, 20, 3, barrier, dev)
+                        rl = roofline(lifter, clipb, prow, dev_c / 20 * 1e3, fn=run, batch=nb, key="eval_b%d" % nb)
+                    rl.update({"windows": nb, "ms_per_call": round(el_c / 20 * 1e3, 4),
+                               "note": "one clip call of %d windows (window stride one frame): the per-frame launch + r3d_forward_clip_f32 + "
+                                       "decoder; algorithmic FLOPs count expand_conv per window, the kernel evaluates it per frame" % nb})
+                    return rl
+                try:
+                    line["roofline"] = _clip_roofline()
+                except Exception as e:                      # noqa: BLE001 - reported, not swallowed
+                    line["roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
             print(json.dumps(line))
     if dist is not None:
         dist.barrier()
