@@ -787,3 +787,45 @@ def test_clip_batch_sizes_share_a_handful_of_schedules():
     assert len(seen) <= 39
     lifter.CLIP_ROUND = 0
     assert lifter.clip_batch_sizes(5000) == [4096, 904]
+
+
+# ------------------------------------------------------------------ profile tooling
+
+def test_pmc_summary_picks_the_timed_kernel_by_name(tmp_path):
+    """profiles/summarize_pmc.py: one row per kernel NAME (the last dispatch of that name in each pass), the timed kernel taken
+    from the run's bench line - a pixel-keypoint run also launches the rays mode's kernel, which must not stand in for it -
+    with the gfx950 unit corrections (SQ quad-cycle counters x4, FETCH_SIZE x2, KiB); profiles/make_pmc_json.py keys the
+    result by workload for bench.py."""
+    import csv
+    import json
+    import subprocess
+    import sys
+    root = tmp_path / "r99_cfg4_rf9"
+    passes = {1: ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"],
+              2: ["GRBM_GUI_ACTIVE", "SQ_LDS_IDX_ACTIVE"], 3: ["FETCH_SIZE"], 4: ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]}
+    # dispatches: uv kernel (id 1, 3) and rays kernel (id 2, 4: the LAST one - what round 3's summary took); 1000 us each
+    val = {"SQ_VALU_MFMA_BUSY_CYCLES": {"r3d_forward_uv_f32": 1.2e9, "r3d_forward_f32": 0.6e9}, "GRBM_GUI_ACTIVE": 8 * 2.4e6,
+           "FETCH_SIZE": {"r3d_forward_uv_f32": 400000.0, "r3d_forward_f32": 100000.0}, "WRITE_SIZE": 200000.0,
+           "TCC_HIT_sum": 3.0, "TCC_MISS_sum": 1.0}
+    for i, ctrs in passes.items():
+        d = root / ("pmc%d" % i) / "host"
+        d.mkdir(parents=True)
+        with open(d / "1_counter_collection.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Dispatch_Id", "Kernel_Name", "Grid_Size", "Start_Timestamp", "End_Timestamp", "Counter_Name", "Counter_Value"])
+            for did, name in ((1, "r3d_forward_uv_f32"), (2, "r3d_forward_f32"), (3, "r3d_forward_uv_f32.kd"), (4, "r3d_forward_f32(FwdArgs)")):
+                for c in ctrs:
+                    v = val.get(c, 1.0)
+                    v = v[name.split("(")[0].split(".")[0]] if isinstance(v, dict) else v
+                    w.writerow([did, name, 131072, 1000000 * did, 1000000 * did + 1000000, c, v])
+    (root / "bench_line.json").write_text(json.dumps({"dtype": "f32", "config": {"batch_per_gpu": 1024, "receptive_field": 9, "joints": 17,
+                                                      "workload": "cfg4"}, "roofline": {"kernel": "r3d_forward_uv_f32"}}))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "summarize_pmc.py"), str(root)], capture_output=True, text=True, check=True).stdout
+    assert "timed kernel r3d_forward_uv_f32" in out and "RF 9" in out
+    sm = json.load(open(root / "pmc_summary.json"))
+    assert sm["timed_kernel"] == "r3d_forward_uv_f32" and set(sm["kernels"]) == {"r3d_forward_uv_f32", "r3d_forward_f32"}
+    uv, rays = sm["kernels"]["r3d_forward_uv_f32"], sm["kernels"]["r3d_forward_f32"]
+    assert uv["fetch_bytes"] == 800000000 and rays["fetch_bytes"] == 200000000 and uv["write_bytes"] == 200000000   # x2, KiB -> bytes
+    assert abs(uv["clk_ghz_pmc_pass"] - 2.4) < 1e-9
+    assert abs(uv["mfma_busy_frac"] - 1.2e9 / (1024 * 1000e3 * 2.4)) < 1e-4 and abs(uv["executed_flops"] - 1.2e9 * 64) < 1.0
+    assert uv["l2_hit_pct"] == 75.0
