@@ -183,6 +183,8 @@ def test_forward_clip_equals_materialised_windows(per_frame, monkeypatch):
     from ray3d_amd import synth
     if not per_frame:
         dev_switch(monkeypatch, "R3D_NO_SHARED_L0", "1")
+    elif os.environ.get("R3D_BF16X3") == "1":
+        pytest.skip("bf16x3 handles keep the gathered first level (the per-frame form exists for the fp32 tiles)")
     mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
     pos, trj, (cp, _), _ = build_modules(mc)
     lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
@@ -473,6 +475,8 @@ def test_clip_calls_run_the_per_frame_first_layers():
     import ray3d_amd
     from ray3d_amd import synth
     from oracle import torch_port
+    if os.environ.get("R3D_BF16X3") == "1":
+        pytest.skip("bf16x3 handles keep the gathered first level (the per-frame form exists for the fp32 tiles)")
     mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3,3")
     pos, trj, (cp, sp), (ct, st) = build_modules(mc)
     lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
