@@ -419,6 +419,27 @@ def make_clip(i, n, cams, seed=0):
     return evaluate.Clip(cam, rays, cam.world2normalized(world).astype(np.float32), "A%d" % (i % 15), i)
 
 
+def eval_partition(n_clips, world, seed=0, length_div=1):
+    """Everything about the clip-sharded evaluation that is a pure function of (n_clips, world, seed) - so that every
+    rank derives it without communicating: clip lengths and cameras, the whole-clip shards (longest first), the action ids.
+    `length_div` shortens the clips (CPU tests of this very path: tests/test_host.py, world size 8 over gloo)."""
+    from ray3d_amd import evaluate
+    lengths, cams = synthetic_eval_set(n_clips, seed)
+    lengths = [max(n // length_div, 2) for n in lengths]
+    actions = sorted(set("A%d" % (i % 15) for i in range(n_clips)))
+    return {"lengths": lengths, "cams": cams, "shards": evaluate.shard_clips(lengths, world),
+            "aid": {a: i for i, a in enumerate(actions)}}
+
+
+def eval_summary(allrows):
+    """The gathered per-clip rows -> what the line reports: the action-wise averages (trainer.py:473-477) and a checksum of
+    the MPJPE column in clip order.  Neither depends on the number of ranks."""
+    from ray3d_amd import evaluate
+    avg = evaluate.action_average(evaluate.reduce_partials(allrows))
+    return {"action_average": avg[0], "p_mpjpe": avg[1], "n_mpjpe": avg[2], "mpjve": avg[3], "mrpe": avg[4],
+            "checksum": float(allrows[allrows[:, 0].argsort()][:, 3].sum().item())}
+
+
 def self_launch(args):
     """--gpus N without a launcher: start N ranks through torch.distributed.run, forward their output."""
     n = torch.cuda.device_count()
@@ -623,10 +644,8 @@ def main():
             print(json.dumps(line))
     else:
         # ---- clip-sharded evaluation (configs[2]): whole clips per rank, resident in HBM, one all_gather per pass
-        lengths, cams = synthetic_eval_set(args.clips)
-        shards = evaluate.shard_clips(lengths, world)
-        actions = sorted(set("A%d" % (i % 15) for i in range(args.clips)))
-        aid = {a: i for i, a in enumerate(actions)}
+        part = eval_partition(args.clips, world)
+        lengths, cams, shards, aid = part["lengths"], part["cams"], part["shards"], part["aid"]
         mine = []
         for idx in shards[rank]:
             c = make_clip(idx, lengths[idx], cams)
@@ -634,15 +653,14 @@ def main():
             mine.append((c, padded, torch.from_numpy(c.camera.param()).to(dev), torch.from_numpy(c.gt_norm).to(dev)))
         sizes = sorted(set(b for c, _, _, _ in mine for b in lifter.clip_batch_sizes(c.rays.shape[0])))
         lifter.prepare(sizes, dev)
-        result = {}
+        # the rank's per-clip rows: header columns (clip, action, frames) uploaded ONCE, error columns written on the device
+        local_rows = evaluate.partial_rows([(c.clip_id, aid[c.action], c.rays.shape[0]) for c, _, _, _ in mine], dev)
+        counts = [len(s) for s in shards]
 
         def one_pass():
-            rows = [evaluate.clip_partials_hip(lifter.forward_clip(padded, prow), c, aid[c.action], gt_dev=gt)
-                    for c, padded, prow, gt in mine]
-            local_rows = torch.stack(rows) if rows else torch.zeros((0, evaluate.PARTIAL_COLS), dtype=torch.float64, device=dev)
-            allrows = evaluate.gather_partials(local_rows, [len(s) for s in shards]) if dist is not None else local_rows
-            result["rows"] = allrows
-            return allrows
+            for k, (c, padded, prow, gt) in enumerate(mine):
+                evaluate.clip_partials_hip(lifter.forward_clip(padded, prow), c, aid[c.action], gt_dev=gt, out=local_rows[k])
+            return evaluate.gather_partials(local_rows, counts) if dist is not None else local_rows
 
         with torch.no_grad():
             one_pass()                          # first touch: workspace allocation
@@ -650,16 +668,14 @@ def main():
             # this rank's own pass (its clips, no gather, device time): what the shard costs without waiting for the others
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(dev))
-            for c, padded, prow, gt in mine:
-                evaluate.clip_partials_hip(lifter.forward_clip(padded, prow), c, aid[c.action], gt_dev=gt)
+            for k, (c, padded, prow, gt) in enumerate(mine):
+                evaluate.clip_partials_hip(lifter.forward_clip(padded, prow), c, aid[c.action], gt_dev=gt, out=local_rows[k])
             e1.record(torch.cuda.current_stream(dev))
             e1.synchronize()
             own_pass_ms = e0.elapsed_time(e1)
         elapsed = max_over_ranks(elapsed_own)
         per_rank_pass_ms = all_ranks(own_pass_ms)
         shard_frames = [sum(lengths[i] for i in sh) for sh in shards]
-        per = evaluate.reduce_partials(allrows)
-        avg = evaluate.action_average(per)
         frames = sum(lengths)
         if rank == 0:
             assert allrows.shape[0] == args.clips and sorted(int(v) for v in allrows[:, 0].tolist()) == list(range(args.clips))
@@ -678,8 +694,7 @@ def main():
                            "pass_ms_imbalance": round(max(per_rank_pass_ms) / (sum(per_rank_pass_ms) / world), 4),
                            "parallelism": "clips sharded over %d rank(s); collective = all_gather of %d x %d float64"
                                           % (world, args.clips, evaluate.PARTIAL_COLS)},
-                "mpjpe_mm": {"action_average": avg[0], "p_mpjpe": avg[1], "n_mpjpe": avg[2], "mpjve": avg[3], "mrpe": avg[4],
-                             "checksum": float(allrows[allrows[:, 0].argsort()][:, 3].sum().item())}})
+                "mpjpe_mm": eval_summary(allrows)})
             # the whole pass as a rate: every window is 251.7 MFLOP of the reference's arithmetic, whatever the
             # clip path shares between windows - and the roofline of its dominant kernel on ONE full chunk of the first clip
             flops_per_window = 251.7e6

@@ -144,7 +144,9 @@ size_t r3d_workspace_bytes(const r3d_model *pos, const r3d_model *trj, int64_t B
  * pair and frees the least recently used one beyond that - EXCEPT sizes named in r3d_prepare, which stay resident
  * until r3d_release (or until either model is destroyed): a hipGraph that captured a forward holds pointers into its
  * size's schedule and never calls the library again, so prepare every size you capture and release it only after the
- * graph is destroyed.  Never call r3d_prepare / a first forward of a new size while a stream is capturing. */
+ * graph is destroyed.  Never call r3d_prepare / a first forward of a new size while a stream is capturing.
+ * A captured forward also holds the handle's status word (pinned host memory, freed by r3d_destroy): destroy every
+ * graph that captured a forward of a handle BEFORE the handle - a replay after r3d_destroy writes to freed memory. */
 int r3d_prepare(r3d_model *pos, r3d_model *trj, int64_t B);
 int r3d_release(r3d_model *pos, r3d_model *trj, int64_t B);   /* un-pins the size; R3D_ERR_ARG if it was never prepared */
 

@@ -58,10 +58,24 @@ _libs = {}
 _hooks = os.environ.get("R3D_USE_HOOKS_LIB", "0") not in ("", "0")   # (tools/: A/B runs of bench.py on the hooks build)
 
 
+_live = {}      # library path -> number of live Handles it created
+
+
 def use_hooks(on: bool) -> None:
     """Tests / tools: make load() return libray3d_hip_hooks.so (True) or the product library (False, the default).  Handles
-    belong to the library that created them: switch before building modules, and do not carry them across a switch."""
+    belong to the library that created them: switch before building modules, and do not carry them across a switch.
+    The two libraries are two copies of the same code with their OWN process-wide state - in particular the ordering of
+    single-launch forwards of different streams (each needs every CU): forwards issued through both copies are not ordered
+    against each other.  So when handles of the library being left are still alive, the switch first waits for the device -
+    nothing of theirs is in flight when the other copy launches.  Do not run forwards of both copies concurrently."""
     global _hooks
+    if bool(on) != _hooks and _live.get(HOOKS_LIB_PATH if _hooks else LIB_PATH, 0) > 0:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except ImportError:
+            pass
     _hooks = bool(on)
 
 
@@ -128,6 +142,8 @@ class Handle:
                    1 if cfg.dense_convs else 0, 1 if getattr(cfg, "bf16x3", False) else 0)
         self.ptr = C.c_void_p()
         check(lib.r3d_create(C.byref(c), C.byref(self.ptr)), "r3d_create")
+        self._lib_path = HOOKS_LIB_PATH if lib is _libs.get(HOOKS_LIB_PATH) else LIB_PATH
+        _live[self._lib_path] = _live.get(self._lib_path, 0) + 1
 
     def keys(self) -> List[str]:
         lib = self._lib
@@ -184,6 +200,7 @@ class Handle:
         if getattr(self, "ptr", None) and self.ptr.value and getattr(self, "_lib", None) is not None:
             self._lib.r3d_destroy(self.ptr)
             self.ptr = C.c_void_p()
+            _live[self._lib_path] = _live.get(self._lib_path, 1) - 1
 
     def __del__(self):
         try:

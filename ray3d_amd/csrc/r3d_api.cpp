@@ -310,8 +310,11 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
     // clip, fp32 tiles.
     bool b3_call = false;
     for (const Model *mm : pl->m) b3_call = b3_call || (mm && mm->use_b3 && B >= b3_min_batch());
+    // (the per-frame buffer is addressed with 32-bit byte offsets in first_level_shared - row tables, descriptor bound: a
+    //  clip whose buffer would reach 4 GiB, ~349 k windows for a pos + trj pair, keeps the gathered path, which has 64-bit tile bases)
     const bool shared = pl->frame_buf >= 0 && sched->d_frame_tiles != nullptr && in->window_stride == 1 && !b3_call &&
-                        (frames - 2) * 4 <= B * (int64_t)(a->RF / 3) && !(uv && in->cam_stride != 0) && !hook_on("R3D_NO_SHARED_L0");
+                        (frames - 2) * 4 <= B * (int64_t)(a->RF / 3) && !(uv && in->cam_stride != 0) && !hook_on("R3D_NO_SHARED_L0") &&
+                        (unsigned long long)frames * (unsigned long long)pl->frame_ld * 4ull < 0xffffffffull;
     shape.shared = shared;
     const int variant = (uv ? 1 : 0) + (shared ? 2 : 0);
     const bool single = forward_single_launch() && !a->opt_staged && !(b && b->opt_staged) && sched->fwd.grid > 0 && sched->fwd.d_rel[variant] != nullptr &&

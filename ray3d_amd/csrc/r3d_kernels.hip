@@ -2997,7 +2997,8 @@ const char *forward_kernel_name(int kind, bool uv) {
     }
 }
 
-hipError_t launch_forward(const FwdArgs &args, int nwg, int kind, bool uv, hipStream_t stream) {
+// every specialisation may use the whole LDS allocation (set once per device, before the first launch AND before the occupancy query)
+static hipError_t forward_set_lds_attr() {
     static bool attr_done_dev[64] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -3009,15 +3010,21 @@ hipError_t launch_forward(const FwdArgs &args, int nwg, int kind, bool uv, hipSt
             }
         attr_done_dev[dev] = true;
     }
+    return hipSuccess;
+}
+
+hipError_t launch_forward(const FwdArgs &args, int nwg, int kind, bool uv, hipStream_t stream) {
+    if (hipError_t e = forward_set_lds_attr(); e != hipSuccess) return e;
     forward_kernel(kind, uv)<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
     return hipGetLastError();
 }
 
 // Workgroups of the single-launch forward that can be resident at once on the current device (it needs ALL of its grid
-// resident: a waiting workgroup spins for tiles of workgroups that must be running).
+// resident: a waiting workgroup spins for tiles of workgroups that must be running).  0: unknown.
 int forward_resident_capacity(int kind, bool uv) {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(forward_kernel(kind, uv)), GEMM_THREADS, GEMM_LDS_BYTES) != hipSuccess) {
+    if (forward_set_lds_attr() != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(forward_kernel(kind, uv)), GEMM_THREADS, GEMM_LDS_BYTES) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }

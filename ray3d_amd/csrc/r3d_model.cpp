@@ -504,8 +504,9 @@ int model_finalize(Model *m) {
         plans_drop(m);
     }
     m->device = dev;
-    if (!m->status_host) {             // the word the decoder kernel raises when a dependency wait gave up (r3d_status)
-        if ((e = hipHostMalloc((void **)&m->status_host, 64, hipHostMallocDefault)) != hipSuccess) return hip_fail(e, "hipHostMalloc(status)");
+    if (!m->status_host) {             // the word the decoder kernel raises when a dependency wait gave up (r3d_status); portable + mapped:
+                                       // the handle may be re-finalised on another device and the word stays valid there
+        if ((e = hipHostMalloc((void **)&m->status_host, 64, hipHostMallocPortable | hipHostMallocMapped)) != hipSuccess) return hip_fail(e, "hipHostMalloc(status)");
         *m->status_host = 0u;
     }
     if (!m->d_arena) {

@@ -497,6 +497,9 @@ void plans_drop(const Model *m) {
     std::lock_guard<std::mutex> lock(g_plans_mutex);
     for (auto it = g_plans.begin(); it != g_plans.end();) {
         if (it->first.first.first == m->id || it->first.first.second == m->id) {
+            // (r3d_last_clock must not read the control region of a schedule that is freed here)
+            for (const Model *mm : it->second->m)
+                if (mm) const_cast<Model *>(mm)->last_clk_dev = nullptr;
             delete it->second;
             it = g_plans.erase(it);
         } else {

@@ -809,7 +809,18 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
             // holds of that kernel; a CU mask (which the occupancy query does not see) or a lists-mix no specialisation
             // carries sends the size to the launch-by-launch form instead.
             if (ok) {
-                const int cap = forward_resident_capacity(fw.kernel, false);
+                // (every specialisation that may run these lists: the selected kind, its pixel-input form, and the clip
+                //  kernels when the plan has a per-frame buffer - their register / LDS figures are their own)
+                int cap = forward_resident_capacity(fw.kernel, false);
+                auto also = [&](int kind, bool uvk) {
+                    const int c = forward_resident_capacity(kind, uvk);
+                    if (c > 0) cap = cap > 0 ? std::min(cap, c) : c;
+                };
+                if (fw.uses_gather && pl->m[0]->cfg.in_features == 3) also(fw.kernel, true);
+                if (pl->frame_buf >= 0 && fw.kernel == FWD_KERNEL_F32) {
+                    also(FWD_KERNEL_CLIP, false);
+                    if (pl->m[0]->cfg.in_features == 3) also(FWD_KERNEL_CLIP, true);
+                }
                 const bool masked = getenv("HSA_CU_MASK") != nullptr || getenv("ROC_GLOBAL_CU_MASK") != nullptr;
                 if ((narrow && b3_tiles) || (cap > 0 && fw.grid > cap) || masked) {
                     if (fw.d_tiles) (void)hipFree(fw.d_tiles);

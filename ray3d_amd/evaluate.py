@@ -78,11 +78,23 @@ def predict_clip(lift_clip: Callable, clip: Clip, rf: int, device, flip: bool = 
     return pred
 
 
+def partial_rows(headers: Sequence[tuple], device) -> torch.Tensor:
+    """The (k, PARTIAL_COLS) float64 matrix of a rank's per-clip rows with the host-known columns - clip id, action id,
+    frame count - filled in: ONE host-to-device copy per evaluation instead of one per clip (the error columns are written
+    on the device by :func:`clip_partials_hip`)."""
+    rows = torch.zeros((len(headers), PARTIAL_COLS), dtype=torch.float64)
+    if headers:
+        rows[:, :3] = torch.tensor([[float(v) for v in h] for h in headers], dtype=torch.float64)
+    return rows.to(device)
+
+
 def clip_partials_hip(pred_norm: torch.Tensor, clip: Clip, action_id: int = 0,
-                      gt_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      gt_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """clip_partials on the GPU through r3d_clip_metrics: world transform, the five error sums and the per-frame
     Procrustes fits in one float64 kernel on the current stream - no D2H copy of the predictions.
-    `gt_dev`: the clip's ground truth already on the device (callers that keep a data set resident in HBM)."""
+    `gt_dev`: the clip's ground truth already on the device (callers that keep a data set resident in HBM).
+    `out`: a row of :func:`partial_rows` (header columns already on the device): only the five sums are written, by a
+    device copy - no host tensor, no host synchronisation per clip, whatever the number of ranks."""
     from . import _capi
     dev = pred_norm.device
     n = pred_norm.shape[0]
@@ -96,9 +108,14 @@ def clip_partials_hip(pred_norm: torch.Tensor, clip: Clip, action_id: int = 0,
     _capi.clip_metrics(pred.data_ptr(), gt.data_ptr(), n, pred.shape[1], np.asarray(clip.camera.Rn2w, dtype=np.float64),
                        np.asarray(clip.camera.Tn2w, dtype=np.float64).reshape(3), sums.data_ptr(),
                        torch.cuda.current_stream(dev).cuda_stream)
+    if out is not None:
+        assert out.shape == (PARTIAL_COLS,) and out.dtype == torch.float64 and out.device == dev
+        out[3:8] = sums[:5]           # R3D_METRIC_* order == columns 3..7 (mpjpe, p-mpjpe, n-mpjpe, velocity, root)
+        return out
     row = torch.empty(PARTIAL_COLS, dtype=torch.float64, device=dev)
-    row[:3] = torch.tensor([clip.clip_id, action_id, n], dtype=torch.float64)
-    row[3:8] = sums[:5]               # R3D_METRIC_* order == columns 3..7 (mpjpe, p-mpjpe, n-mpjpe, velocity, root)
+    for c, v in enumerate((clip.clip_id, action_id, n)):
+        row[c].fill_(float(v))        # (scalars travel as kernel arguments: no pageable host tensor, no blocking copy)
+    row[3:8] = sums[:5]
     return row
 
 
@@ -204,12 +221,16 @@ def evaluate_clips(lift_clip: Callable, clips: Sequence[Clip], rf: int, device, 
     actions = sorted(set(c.action for c in clips))
     aid = {a: i for i, a in enumerate(actions)}
     shards = shard_clips([c.rays.shape[0] for c in clips], world_size)
-    rows = []
-    for idx in shards[rank]:
+    on_gpu = torch.device(device).type == "cuda"
+    local = partial_rows([(idx, aid[clips[idx].action], clips[idx].rays.shape[0]) for idx in shards[rank]], device)
+    for k, idx in enumerate(shards[rank]):
         c = clips[idx]
         pred = predict_clip(lift_clip, c, rf, device, flip, kps_left, kps_right, causal, joints_left, joints_right)
-        rows.append(clip_partials(pred, Clip(c.camera, c.rays, c.gt_norm, c.action, idx), aid[c.action]))
-    local = torch.stack(rows) if rows else torch.zeros((0, PARTIAL_COLS), dtype=torch.float64, device=device)
+        cc = Clip(c.camera, c.rays, c.gt_norm, c.action, idx)
+        if on_gpu and pred.is_cuda:
+            clip_partials_hip(pred, cc, aid[c.action], out=local[k])
+        else:
+            local[k] = clip_partials(pred, cc, aid[c.action])
     if world_size > 1:
         allrows = gather_partials(local, [len(s) for s in shards], group)
     else:

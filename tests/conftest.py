@@ -69,17 +69,25 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     if not PARITY:
         return
     tr = terminalreporter
-    tr.section("parity: measured max abs error per configuration (bound: the literal 1e-4 abs)")
+    tr.section("parity: measured max abs error per configuration (bound: the literal 1e-4 abs unless the row says otherwise)")
     worst = {}
     for label, err, tol, ref_max in PARITY:
         w = worst.get(label)
         if w is None or err > w[0]:
             worst[label] = (err, tol, ref_max)
-    for label, (err, tol, ref_max) in worst.items():
+    LITERAL = 1e-4
+    relaxed = {k: v for k, v in worst.items() if v[1] > LITERAL * (1 + 1e-9)}
+    strict = {k: v for k, v in worst.items() if k not in relaxed}
+    for label, (err, tol, ref_max) in strict.items():
         tr.write_line("parity %-88s err %.2e  bound %.2e%s" % (label, err, tol, "" if ref_max is None else "  |ref|max %.2f" % ref_max))
-    lit = [e for (e, t, r) in worst.values() if r is not None and r <= 10.0]
-    tr.write_line("parity summary: %d configurations at the literal 1e-4 bound, worst err %.2e; %d with |ref| <= 10 m, worst %.2e"
-                  % (len(worst), max(e for e, _, _ in worst.values()), len(lit), max(lit) if lit else 0.0))
+    for label, (err, tol, ref_max) in relaxed.items():
+        tr.write_line("parity RELAXED-BOUND %-74s err %.2e  bound %.2e%s" % (label, err, tol, "" if ref_max is None else "  |ref|max %.2f" % ref_max))
+    lit = [e for (e, t, r) in strict.values() if r is not None and r <= 10.0]
+    tr.write_line("parity summary: %d configurations at the literal 1e-4 bound (or tighter), worst err %.2e; %d of them with |ref| <= 10 m, worst %.2e"
+                  % (len(strict), max([e for e, _, _ in strict.values()] or [0.0]), len(lit), max(lit) if lit else 0.0))
+    if relaxed:
+        tr.write_line("parity summary: %d configuration(s) under a labelled RELAXED bound (opt-in bf16x3 on the over-scaled 108 m fixture), worst err %.2e against %.2e"
+                      % (len(relaxed), max(e for e, _, _ in relaxed.values()), max(t for _, t, _ in relaxed.values())))
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
         import json

@@ -486,6 +486,39 @@ def gen_undistort():
         distorted = distortPoint(ideal.copy(), K, dist.reshape(1, 5).astype(np.float64))
         blob.update({"cam%d/K" % i: K, "cam%d/dist" % i: dist.astype(np.float64), "cam%d/ideal" % i: ideal.T.copy(),
                      "cam%d/distorted" % i: distorted.T.copy()})
+        # -- the ALGORITHM pin (OpenCV itself cannot be run here): the reference's forward model on a DENSE grid, and what
+        # cv2.undistortPoints(pts, K, dist, P=K) of opencv-python 4.4.0.42 (requirements.txt:40; call site
+        # lib/camera/camera.py:420) is documented to compute for it - cvUndistortPointsInternal with the default
+        # TermCriteria(MAX_ITER, 5, 0.01): exactly five iterations of x <- (x0 - tangential(x)) / radial(x) on normalised
+        # coordinates, re-projected with P = K - restated here independently of the product and of oracle/, in float64.
+        # `dense_und5` is that result point by point, `res5_*` the residual those five iterations leave against the true
+        # inverse (the grid the reference's distortPoint started from), `res200_max` the same after 200 iterations: the
+        # iteration converges to the grid, five iterations stop where the table says.
+        dx_, dy_ = np.meshgrid(np.linspace(0.0, float(intr["res_w"]), 65), np.linspace(0.0, float(intr["res_h"]), 65))
+        dense = np.stack([dx_.ravel(), dy_.ravel()], axis=0)
+        dense_d = distortPoint(dense.copy(), K, dist.reshape(1, 5).astype(np.float64))
+
+        def cv_undistort(pts, iters):
+            k1, k2, p1, p2, k3 = (float(v) for v in dist.astype(np.float64))
+            x0 = (pts[0] - K[0, 2]) / K[0, 0]
+            y0 = (pts[1] - K[1, 2]) / K[1, 1]
+            x, y = x0.copy(), y0.copy()
+            for _ in range(iters):
+                r2 = x * x + y * y
+                icdist = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2)
+                deltaX = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
+                deltaY = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
+                x = (x0 - deltaX) * icdist
+                y = (y0 - deltaY) * icdist
+            return np.stack([x * K[0, 0] + K[0, 2], y * K[1, 1] + K[1, 2]], axis=0)
+        und5, und200 = cv_undistort(dense_d, 5), cv_undistort(dense_d, 200)
+        w_, h_ = float(intr["res_w"]), float(intr["res_h"])
+        inner = (np.abs(dense[0] - 0.5 * w_) <= 0.4 * w_) & (np.abs(dense[1] - 0.5 * h_) <= 0.4 * h_)
+        r5 = np.abs(und5 - dense).max(axis=0)
+        blob.update({"cam%d/dense_ideal" % i: dense.T.copy(), "cam%d/dense_distorted" % i: dense_d.T.copy(),
+                     "cam%d/dense_und5" % i: und5.T.copy(), "cam%d/dense_inner" % i: inner,
+                     "cam%d/res5_inner_max" % i: np.float64(r5[inner].max()), "cam%d/res5_all_max" % i: np.float64(r5.max()),
+                     "cam%d/res200_max" % i: np.float64(np.abs(und200 - dense).max())})
     blob["n"] = np.int64(len(h36m_cameras_intrinsic_params))
     np.savez_compressed(os.path.join(HERE, "undistort.npz"), **blob)
     print("undistort: %d coefficient sets, %d points each" % (int(blob["n"]), ideal.shape[1]))

@@ -545,11 +545,17 @@ def test_clip_calls_run_the_per_frame_first_layers():
 def test_clip_calls_of_many_lengths_equal_their_materialised_windows(over):
     """forward_clip over clips of 1 ... ~700 windows (every tail size of clip_batch_sizes, chunks of 256: the plans of
     small, medium and large calls; per-frame first layers where the plan has them) against the same windows materialised
-    and lifted as independent windows - the two differ in summation order at most."""
+    and lifted as independent windows - the two differ in summation order at most.  At 130 windows (a plan with the
+    per-frame first layers where the variant has them) the clip call is also held to the ORACLE - the torch port of the
+    reference graph on the materialised windows - so that the per-frame [E | V] fold of every variant's tables (J = 14 / 15
+    groups, 128 channels, causal-dilated, two input features) is checked against the reference arithmetic, not only against
+    this library's own window path."""
     import ray3d_amd
     from ray3d_amd import synth
+    from oracle import torch_port
     mc = ray3d_amd.default_model_config(**over)
-    pos, trj, (cp, _), _ = build_modules(mc)
+    pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+    sds = [{k: torch.from_numpy(np.asarray(v)) for k, v in s_.items()} for s_ in (sp, st)]
     lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
     lifter.CLIP_CHUNK = 256
     rf, J, F = cp.receptive_field, cp.num_joints, cp.in_features
@@ -563,6 +569,12 @@ def test_clip_calls_of_many_lengths_equal_their_materialised_windows(over):
             b = lifter(torch.from_numpy(windows).cuda(), prow.view(1, 2).expand(n, 2).contiguous() if cp.camera_embedding else None)
         assert a.shape == (n, 1, J, 3)
         check_parity(a, b.cpu().numpy(), "%d windows" % n, tol=2e-5 * max(1.0, float(b.abs().max())))
+        if n == 130:
+            with torch.no_grad():
+                pw = torch.from_numpy(np.tile(prow.cpu().numpy(), (n, 1)))
+                ref = (torch_port.forward(cp, sds[0], torch.from_numpy(windows), pw) +
+                       torch_port.forward(ct, sds[1], torch.from_numpy(windows), pw)).numpy()
+            check_parity(a, ref, "130 windows, clip call against the oracle")
 
 
 def test_rf243_flip_tta_and_uv_clip_mode_against_the_oracle_chain():
@@ -665,8 +677,8 @@ LITERAL_SCALE = 0.25     # decoder scale at which the RF-243 outputs stay below 
 @pytest.mark.parametrize("out_scale", [pytest.param(1.0, id="scale1"), pytest.param(LITERAL_SCALE, id="literal-1e-4")])
 def test_full_size_batch_properties(out_scale):
     """B = 256, RF 243 (BASELINE configs[1]): permutation equivariance, split invariance, determinism,
-    and oracle agreement on every window - with the synthetic decoders at scale 1 (outputs of up to ~23 m: bound 1e-4
-    relative to 10 m) and at a scale that keeps every output below 10 m (the literal 1e-4 abs bound of north_star)."""
+    and oracle agreement on every window at the literal 1e-4 abs bound of north_star - with the synthetic decoders at scale 1
+    (outputs of up to ~23 m) and at a scale that keeps every output below 10 m."""
     import ray3d_amd
     from ray3d_amd import synth
     from oracle import oracle

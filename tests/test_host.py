@@ -263,6 +263,39 @@ def test_undistortion_inverts_the_references_distortion_model():
     print("undistort(distortPoint_ref(p)) - p: worst inner-grid error %.2e px" % worst)
 
 
+# What five iterations leave on the dense grid, per H36M coefficient set (pixels; tests/golden/make_golden.py gen_undistort,
+# INTEGRATION.md section 5): the residual a maintainer with OpenCV should also see from
+# cv2.undistortPoints(distortPoint(grid), K, dist, P=K) against the grid.
+UNDISTORT_RES5_PX = {0: (4.3e-6, 5.6e-6), 1: (3.9e-6, 5.0e-6), 2: (4.1e-6, 5.2e-6), 3: (5.7e-6, 8.4e-6)}   # (inner 80 %, whole image)
+
+
+def test_undistortion_is_opencvs_five_iteration_inverse_on_a_dense_grid():
+    """The ALGORITHM pin of the one boundary that stays unpinned against cv2 itself (opencv-python 4.4.0.42 is not in the
+    image and cannot be installed): the reference's distortPoint on a dense 65 x 65 grid over the whole image for the four
+    H36M coefficient sets, and - restated a third time, in the fixture generator, independently of product and oracle - what
+    cv2.undistortPoints(pts, K, dist, P=K) is documented to compute: exactly five fixed-point iterations
+    (cvUndistortPointsInternal, default TermCriteria(MAX_ITER, 5, 0.01)).  Product and oracle must reproduce that result
+    point by point, the residual against the true inverse must be the documented one per camera (micro-pixels: five
+    iterations are converged for H36M's lenses), and the iteration itself must converge to the grid (200 iterations)."""
+    from oracle import oracle
+    z = np.load(os.path.join(GOLDEN, "undistort.npz"))
+    for i in range(int(z["n"])):
+        K, dist = z["cam%d/K" % i], z["cam%d/dist" % i]
+        ideal, distorted, und5, inner = (z["cam%d/dense_%s" % (i, k)] for k in ("ideal", "distorted", "und5", "inner"))
+        assert ideal.shape == (65 * 65, 2) and inner.sum() > 2000
+        cam = ray3d_amd.Camera(K, np.eye(3), np.zeros(3) + [0, 0, 4.0], dist_coeff=dist, undistort=True)
+        assert np.abs(cam.distort_points(ideal) - distorted).max() < 1e-9          # the product's forward model IS distortPoint
+        for und in (cam.undistort_points(distorted), oracle.undistort_points(K, dist, distorted)):
+            assert np.abs(und - und5).max() < 1e-9, i                               # the same five iterations, point by point
+            res = np.abs(und - ideal).max(axis=1)
+            want_inner, want_all = UNDISTORT_RES5_PX[i]
+            assert res[inner].max() <= want_inner and res.max() <= want_all, (i, res[inner].max(), res.max())
+            assert abs(res[inner].max() - float(z["cam%d/res5_inner_max" % i])) < 1e-9
+            assert abs(res.max() - float(z["cam%d/res5_all_max" % i])) < 1e-9
+        assert float(z["cam%d/res200_max" % i]) < 1e-9                              # ... of an iteration that converges to the grid
+        assert np.abs(distorted - ideal).max() > 20.0                               # (a distortion of tens of pixels at the corners)
+
+
 def test_metrics_match_reference():
     z = np.load(os.path.join(GOLDEN, "losses.npz"))
     a, b = torch.from_numpy(z["pred"]), torch.from_numpy(z["target"])
@@ -366,6 +399,75 @@ def test_two_rank_gather_matches_single_process():
         for a in named1:
             assert np.allclose(named[a], named1[a], rtol=0, atol=1e-9)
         assert sorted(rows[:, 0].tolist()) == [0.0, 1.0, 2.0]
+
+
+def _standin_pred(clip):
+    """A cheap deterministic stand-in for the lifted poses of a clip (the arithmetic under test is the sharding, the
+    per-rank rows and the gather, not the forward): ground truth plus a smooth function of the rays."""
+    n = clip.rays.shape[0]
+    return torch.from_numpy((clip.gt_norm + 0.01 * np.sin(7.0 * clip.rays[..., :3])).astype(np.float32)).reshape(n, 1, -1, 3)
+
+
+def _bench_eval_rows(world, rank, n_clips, length_div, gather):
+    """bench.py --mode eval's pass with the stand-in above: the same partition (bench.eval_partition), the same
+    once-per-evaluation header upload (evaluate.partial_rows), the same gather, the same summary."""
+    import bench
+    part = bench.eval_partition(n_clips, world, length_div=length_div)
+    mine = [bench.make_clip(idx, part["lengths"][idx], part["cams"]) for idx in part["shards"][rank]]
+    local = evaluate.partial_rows([(c.clip_id, part["aid"][c.action], c.rays.shape[0]) for c in mine], "cpu")
+    for k, c in enumerate(mine):
+        local[k, 3:8] = evaluate.clip_partials(_standin_pred(c), c, part["aid"][c.action])[3:8]
+    return gather(local, [len(s) for s in part["shards"]]), part
+
+
+def _gloo_eval_worker(rank, world, port, q, n_clips, length_div):
+    import torch.distributed as dist
+    import bench
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        rows, _ = _bench_eval_rows(world, rank, n_clips, length_div, evaluate.gather_partials)
+        q.put((rank, bench.eval_summary(rows), sorted(int(v) for v in rows[:, 0].tolist())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_eval_sharding_and_gather_at_world_size_8_matches_world_size_1():
+    """bench.py --mode eval --gpus 8 on CPU over gloo: the 240-clip set (shortened clips) sharded longest-first over EIGHT
+    ranks, every rank's rows built as the bench builds them, one all_gather - the gathered MPJPE, the other four action
+    averages and the checksum equal the single-process values exactly, on every rank; every clip appears once."""
+    import torch.multiprocessing as mp
+    import bench
+    n_clips, div = 240, 40
+    rows1, part1 = _bench_eval_rows(1, 0, n_clips, div, lambda local, counts: local)
+    want = bench.eval_summary(rows1)
+    assert sorted(len(s) for s in bench.eval_partition(n_clips, 8)["shards"]) == [30] * 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_eval_worker, args=(r, 8, port, q, n_clips, div)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(8)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r for r, _, _ in res) == list(range(8))
+    for rank, got, ids in res:
+        assert ids == list(range(n_clips)), rank
+        for k in want:
+            # the per-clip sums are computed by the same code on the same data whatever the rank; only the row ORDER of the
+            # gathered matrix differs, and the summary sorts / groups before it adds
+            assert abs(got[k] - want[k]) <= 1e-9 * max(1.0, abs(want[k])), (rank, k, got[k], want[k])
+
+
+def test_partial_rows_header_is_uploaded_once_and_kept():
+    hdr = [(5, 2, 100), (7, 0, 33)]
+    rows = evaluate.partial_rows(hdr, "cpu")
+    assert rows.shape == (2, evaluate.PARTIAL_COLS) and rows.dtype == torch.float64
+    assert rows[:, :3].tolist() == [[5.0, 2.0, 100.0], [7.0, 0.0, 33.0]] and float(rows[:, 3:].abs().sum()) == 0.0
+    assert evaluate.partial_rows([], "cpu").shape == (0, evaluate.PARTIAL_COLS)
 
 
 # ----------------------------------------------------------------- static tile schedule (host code, no GPU)
