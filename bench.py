@@ -241,6 +241,11 @@ def roofline(lifter, x, p, step_ms, reps=5, fn=None, batch=None, key=None):
            # of the launch, and the FLOPs those busy cycles executed over this run's launch time
            "mfma_busy_frac": pmc["mfma_busy_frac"] if pmc else None,
            "executed_tflops": round(pmc["executed_flops"] / launch_s / 1e12, 2) if pmc else None,
+           # ... and that rate against the same peak: what the matrix cores really did, beside `frac`, which credits the
+           # reference's arithmetic (a clip call evaluates expand_conv per frame and is credited per window; the folded first
+           # layers execute fewer FLOPs than the reference's cat(x, diff, diff_t) form)
+           "executed_frac": round(pmc["executed_flops"] / launch_s / 1e12 / peak, 4) if pmc else None,
+           "pmc_source": "committed profile (profiles/pmc.json: rocprofv3 --pmc passes of this workload on an earlier run), not this run" if pmc else None,
            "pmc": {"table": "profiles/pmc.json[%s][%s]" % (key, name), "clk_ghz_pmc_pass": pmc["clk_ghz_pmc_pass"],
                    "l2_hit_pct": pmc["l2_hit_pct"], "fetch_bytes": pmc["fetch_bytes"], "write_bytes": pmc["write_bytes"]} if pmc else None,
            "launches_per_step": d["launches"] // reps,

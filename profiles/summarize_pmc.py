@@ -59,7 +59,7 @@ def main():
     p1, p2, p3, p4 = (last_by_name(load('%s/pmc%d' % (root, i))) for i in (1, 2, 3, 4))
     print('# one forward: %s windows, RF %s, %s joints (%s); timed kernel %s; cycles in millions (SQ_* quad-cycle counters x4); '
           'FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B); clk = GRBM_GUI_ACTIVE / 8 XCDs / duration; busy = MFMA-busy '
-          'cycles / (1024 SIMDs x duration x clk)' % (cfg.get('batch_per_gpu', '?'), cfg.get('receptive_field', '?'), cfg.get('joints', '?'),
+          'cycles / (1024 SIMDs x duration x clk)' % (cfg.get('batch_per_gpu', rl.get('windows', '?')), cfg.get('receptive_field', '?'), cfg.get('joints', '?'),
                                                        str(cfg.get('workload', ''))[:40], main_kernel))
     print('%-22s %9s %8s %8s %8s %8s %8s %8s %5s | %7s %6s | %8s %8s %5s' % (
         'kernel', 'grid', 'dur_us', 'waveMcy', 'mfmaMcy', 'waitAny', 'waitInst', 'active', 'busy', 'ldsIdxM', 'clkGHz', 'fetchMB',
@@ -89,7 +89,7 @@ def main():
               'of the SIMD-cycles; executed %.2f GFLOP' % (main_kernel, m['fetch_bytes'] / 1e6, m['write_bytes'] / 1e6, m['traffic_bytes'],
                                                            m['mfma_busy_cycles'] / 1e6, m['dur_us_pmc_pass'], m['clk_ghz_pmc_pass'],
                                                            m['mfma_busy_frac'], m['executed_flops'] / 1e9))
-    json.dump({"timed_kernel": main_kernel, "dtype": dtype, "batch_per_gpu": cfg.get('batch_per_gpu'),
+    json.dump({"timed_kernel": main_kernel, "dtype": dtype, "batch_per_gpu": cfg.get('batch_per_gpu', rl.get('windows')),
                "receptive_field": cfg.get('receptive_field'), "kernels": summary}, open(root + '/pmc_summary.json', 'w'), indent=1)
 
 

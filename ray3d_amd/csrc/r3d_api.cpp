@@ -778,10 +778,11 @@ int r3d_debug_schedule_check(int nprob, const int *M, const int *N, const int *n
     for (int i = 0; i < nprob; ++i) cover[i].assign((size_t)((M[i] + 31) / 32) * ((N[i] + COL_GRANULE - 1) / COL_GRANULE), 0);
     for (const int4 &t : tiles) {
         const int pi = t.x & 0xff, mi = t.x >> 8, ks = t.w;
-        if (pi >= nprob || mi < 1 || (ks != 1 && ks != 2 && ks != 4 && ks != 8 && ks != 16)) return -4;
+        if (pi >= nprob || mi < 1 || (ks != 1 && ks != 2 && ks != 4 && ks != 8 && ks != 16 && !(ks >= NB_CODE + 4 && ks <= NB_CODE + 7))) return -4;
         if (ks < 8 && ks > max_ks[pi]) return -5;
         if ((ks == 1 && mi > (max_units[pi] > 0 ? std::min(max_units[pi], GEMM_SCHED_MAX_UNITS) : GEMM_SCHED_MAX_UNITS)) || (ks == 2 && mi > 2) || (ks >= 4 && mi != 1)) return -6;
-        if (t.y % 32 || t.y < 0 || t.y >= M[pi] || t.z % tile_width(ks) || t.z < 0 || t.z >= N[pi]) return -7;
+        if (t.y % 32 || t.y < 0 || t.y >= M[pi] || t.z % (tile_is_nb(ks) ? 32 : tile_width(ks)) || t.z < 0 || t.z >= N[pi]) return -7;
+        if (tile_is_nb(ks) && t.z + tile_width(ks) > N[pi]) return -7;        // (narrow tiles cover whole blocks of existing columns)
         if (ks > 1 && ks < 8 && (nk[pi] + ks - 1) / ks < 2) return -8;
         const int gcols = (N[pi] + COL_GRANULE - 1) / COL_GRANULE;
         for (int u = t.y / 32; u < t.y / 32 + mi; ++u) {

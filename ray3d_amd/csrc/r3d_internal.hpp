@@ -437,10 +437,14 @@ struct SchedProb {
     int row0 = 0;    // first row this launch computes (a multiple of 32): rows [row0, M)
     bool gemv = false;   // M <= GEMV_ROWS rows of a plain layer: 32-column GEMV tiles (tile code ks == 8), r3d_kernels.hip gemv_tile
     bool lat = false;    // ... of up to 32 rows: 32-column latency tiles on the matrix cores (tile code 16), lat_tile
+    bool nb_ok = false;  // a plain fp32 layer of whole 32-column blocks whose single-unit tiles may be 5 - 7 blocks wide (gemm_tile_nb)
 };
 constexpr int GEMV_ROWS = 4;          // == GEMV_MAX_M of the kernels (at eight rows the MFMA split-K tiles are the faster ones: 0.207 against 0.222 ms)
 constexpr int COL_GRANULE = 32;       // ready counters and cover checks count columns in granules of this many
-inline int tile_width(int ks) { return ks >= 8 ? 32 : 256 / ks; }     // columns of a tile by its split code (8: a GEMV tile, 16: a latency tile)
+constexpr int NB_CODE = 64;           // tile code NB_CODE + nb: one 32-row unit x nb column blocks of 32, nb = 5 .. 7 (r3d_kernels.hip, gemm_tile_nb)
+constexpr bool tile_is_nb(int ks) { return ks > NB_CODE; }
+constexpr bool tile_is_narrow(int ks) { return ks >= 8 && ks < NB_CODE; }    // GEMV (8) / latency (16) tiles
+constexpr int tile_width(int ks) { return ks > NB_CODE ? (ks - NB_CODE) * 32 : ks >= 8 ? 32 : 256 / ks; }   // columns of a tile by its code
 void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units, std::vector<int4> &tiles,
                     std::vector<int> &wgoff, StageSchedule &out, bool enc = false);
 // index of weight element (output channel o, GEMM column k) in the fragment-ordered packing

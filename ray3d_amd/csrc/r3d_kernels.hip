@@ -522,6 +522,232 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
     R3D_TSTAMP(4);
 }
 
+// ------------------------------------------------------------------------------------ single-unit tiles of NB x 32 columns
+//
+// gemm_tile_nb<NB>: C = res + lrelu(A W^T + b) for ONE 32-row unit and NB in {5, 6, 7} 32-column blocks - the tile of the
+// M = B levels of calls whose levels are one tile deep (256 windows: a FuseBlock / Integration level is 160 - 224 whole
+// 32 x 256 tiles for 256 CUs, a level cannot be shorter than its longest tile, and a quarter of the chip idles).  Cutting
+// a row of 32 column blocks into five tiles of 7 / 6 instead of four of 8 puts every CU to work IF the narrower tile is
+// proportionally shorter, which the 32 x 256 tile's wavefront = column block mapping cannot give (six blocks on four
+// SIMDs take as long as eight).  Here wavefronts 0-3 (one per SIMD) own column blocks 0-3 whole, and the 4 (NB - 4)
+// quarter-blocks that remain - column block b, k = 4 q .. 4 q + 3 of each 16-deep half of a K tile: one q of the fragment
+// packing, 4 of a block's 16 MFMAs per K tile - are dealt NB - 4 apiece to wavefronts 4-7, the SIMD partners: every
+// SIMD issues 16 + 4 (NB - 4) MFMAs per K tile instead of 32.  The partial sums of a split block are added through LDS
+// before the epilogue (as the split-K tiles do).  Operand paths as in gemm_tile<1, 1>: A through the three-stage ring,
+// weights fragment-ordered straight into VGPRs two K tiles ahead (a split block's wavefront requests its own q only).
+template <int NB>
+__device__ __forceinline__ void gemm_tile_nb(ProbRef P, const int row0, const int col0, float *smem, long long *dbg) {
+    static_assert(NB >= 4 && NB <= 7, "NB = 8 is gemm_tile<1, 1>");   // (NB = 4: the narrow end of an uneven row - wavefronts 4-7 only stage)
+    constexpr int SF = STAGE_FLOATS;
+    constexpr int NX = NB - 4;               // quarter-blocks per extra wavefront
+    constexpr int AD = 5;
+    R3D_TSTAMP(0);
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool main_w = wave_u < 4;
+    const int M = P.M, K = P.K;
+    const int nk = K / BK;
+    const int srow = tid >> 3, a_kq = (tid & 7) * 4;
+    // ---- this wavefront's share, as slots (column block of the tile, q): wavefront w < 4 the four q of block w; wavefront
+    // 4 + j the quarter-blocks g = j NX .. j NX + NX - 1 of the list (block 4, q 0..3), (block 5, q 0..3), ...  One
+    // accumulator per slot for the extra wavefronts (a share may straddle two blocks); slot counts are compile-time per
+    // role, so each role's K loop is straight-line code (a branch per slot would pin every LDS read behind it).
+    const int xg0 = (wave_u - 4) * NX;
+    int s_blk[4], s_q[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int sc = s < NX ? s : 0;
+        s_blk[s] = main_w ? wave_u : (NX > 0 ? 4 + (xg0 + sc) / 4 : wave_u - 4);
+        s_q[s] = main_w ? s : (NX > 0 ? (xg0 + sc) & 3 : 0);
+    }
+    // ---- A staging (one segment list, as gemm_tile)
+    const bool multi = P.kend[0] < K;
+    int seg_ld = P.lda[0], seg_k0 = 0, seg_end = P.kend[0], seg_i = 0;
+    int a_voff;
+    __amdgpu_buffer_rsrc_t arsrc;
+    auto open_seg = [&]() {
+        const float *base = P.a[seg_i] + (size_t)row0 * seg_ld;
+        const long long b = ((long long)(M - 1 - row0) * seg_ld + (seg_end < K ? seg_end : K) - seg_k0) * 4;
+        arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, b < 0x7fffffffLL ? (int)b : 0x7fffffff, 0x00020000);
+        const int gr = row0 + (srow & 31);                               // (staged rows 32 .. 63 re-read the tile's rows)
+        a_voff = (((gr < M ? gr : M - 1) - row0) * seg_ld + a_kq) * 4;
+    };
+    open_seg();
+    auto prep_seg = [&](int kt) {
+        if (!multi) return;
+        while (kt * BK >= seg_end) {
+            ++seg_i;
+            seg_k0 = seg_end;
+            seg_ld = P.lda[seg_i];
+            seg_end = P.kend[seg_i];
+            open_seg();
+        }
+    };
+    f32x4 ra, ra2, ra3;
+    auto issue_a = [&](int kt, f32x4 &R) {
+        R = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff, (kt * BK - seg_k0) * 4, ACT_AUX));
+    };
+    const int st_off = srow * LDS_LD + a_kq;
+    auto commit_a = [&](int stage, const f32x4 &R) {
+        float *sp = stage == 0 ? smem + st_off : stage == 1 ? smem + SF + st_off : smem + 2 * SF + st_off;
+        *reinterpret_cast<f32x4 *>(sp) = R;
+    };
+    // ---- W fragments: one descriptor over the tile's NB column blocks; slot s of K tile kt at scalar offset
+    // (s_blk * nk + kt) * 4096 + s_q * 1024 bytes
+    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.w + (size_t)(col0 >> 5) * nk * 1024), 0, NB * nk * 4096, 0x00020000);
+    const int w_voff = lane * 16;
+    int w_soff[4], a_off[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        w_soff[s] = __builtin_amdgcn_readfirstlane((s_blk[s] * nk) * 4096 + s_q[s] * 1024);
+        a_off[s] = li * LDS_LD + lh * 16 + s_q[s] * 4;                   // lane (i, h) reads A[row i][k = 16 h + 4 q ..] of a stage
+    }
+    const int last = nk - 1;
+    // One role's whole K loop: NS slots per K tile, slot s into acc[s % NACC] (main: one accumulator, extra: one per slot)
+    auto k_loop = [&](auto ns_tag, auto nacc_tag, f32x16 *acc) {
+        constexpr int NS = decltype(ns_tag)::value, NACC = decltype(nacc_tag)::value;
+        constexpr int NSL = NS > 0 ? NS : 1;                             // (a wavefront without a share still stages A)
+        f32x4 rb[NSL], rbn[NSL], rbn2[NSL];
+        auto load_w = [&](int kt, f32x4 (&dst)[NSL]) {
+            if (NS == 0) return;
+#pragma unroll
+            for (int s = 0; s < NSL; ++s)
+                dst[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff, w_soff[s] + kt * 4096, 0));
+        };
+        load_w(0, rb);
+        load_w(1 < last ? 1 : last, rbn);
+        {
+            f32x4 r0, r1;
+            issue_a(0, r0);
+            prep_seg(1 < last ? 1 : last);
+            issue_a(1 < last ? 1 : last, r1);
+            prep_seg(2 < last ? 2 : last);
+            issue_a(2 < last ? 2 : last, ra);
+            prep_seg(3 < last ? 3 : last);
+            issue_a(3 < last ? 3 : last, ra2);
+            prep_seg(4 < last ? 4 : last);
+            issue_a(4 < last ? 4 : last, ra3);
+            prep_seg(5 < last ? 5 : last);
+            commit_a(0, r0);
+            commit_a(1, r1);
+        }
+        __syncthreads();
+        f32x4 av0 = *reinterpret_cast<const f32x4 *>(smem + a_off[0]);
+        R3D_TSTAMP(1);
+        int st_cur = 0;
+        auto k_tile = [&](int kt, f32x4 (&w_use)[NSL], f32x4 (&w_load)[NSL], f32x4 &stg) {
+            const int st_next = st_cur == 2 ? 0 : st_cur + 1, st_next2 = st_next == 2 ? 0 : st_next + 1;
+            const float *sp = smem + st_cur * SF;
+            commit_a(st_next2, stg);
+            load_w(kt + 2 < last ? kt + 2 : last, w_load);
+            issue_a(kt + AD < last ? kt + AD : last, stg);
+            prep_seg(kt + AD + 1 < last ? kt + AD + 1 : last);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const f32x4 av = s == 0 ? av0 : *reinterpret_cast<const f32x4 *>(sp + a_off[s]);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    acc[s % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], w_use[s][kk], acc[s % NACC], 0, 0, 0);
+            }
+            if (NS > 0) av0 = *reinterpret_cast<const f32x4 *>(smem + st_next * SF + a_off[0]);
+            __syncthreads();
+            st_cur = st_next;
+        };
+        int kt = 0;
+        for (; kt + 2 < nk; kt += 3) {
+            k_tile(kt, rb, rbn2, ra);
+            k_tile(kt + 1, rbn, rb, ra2);
+            k_tile(kt + 2, rbn2, rbn, ra3);
+        }
+        if (kt < nk) {
+            k_tile(kt, rb, rbn2, ra);
+            if (kt + 1 < nk) k_tile(kt + 1, rbn, rb, ra2);
+        }
+    };
+    // ---- the two roles (the same number of barriers on both sides)
+    constexpr int PART = 16 * 64;                                        // floats of one accumulator in LDS
+    f32x16 fin;                                                          // this wavefront's finished 32 x 32 block (writers)
+    if (main_w) {
+        f32x16 acc[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
+        k_loop(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{}, acc);
+        fin = acc[0];
+        R3D_TSTAMP(2);
+        if (NX > 0) __syncthreads();                                     // (the extra wavefronts publish their partial sums)
+    } else {
+        constexpr int NA_ = NX > 0 ? NX : 1;
+        f32x16 acc[NA_];
+#pragma unroll
+        for (int a = 0; a < NA_; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+        k_loop(std::integral_constant<int, NX>{}, std::integral_constant<int, NA_>{}, acc);
+        // the split blocks' partial sums -> LDS (the ring is idle: the K loop ended on a barrier), quarter-block g at g * PART;
+        // then wavefront 4 + e adds up block 4 + e: quarter-blocks 4 e .. 4 e + 3
+        if (NX > 0) {
+            float *red = smem + lane;
+#pragma unroll
+            for (int a = 0; a < NX; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(xg0 + a) * PART + r * 64] = acc[a][r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) fin[r] = 0.0f;
+            if (wave_u < NB) {
+                const float *src = red + (wave_u - 4) * 4 * PART;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) fin[r] += src[g * PART + r * 64];
+            }
+        }
+    }
+    R3D_TSTAMP(3);
+    // ---- epilogue: the NB slabs of 32 columns transposed through LDS, 16-byte accesses along the rows (store_tile)
+    {
+        constexpr int COLS = NB * 32, TPR = COLS / 4;                    // threads per output row
+        const int N = P.N;
+        const float slope = P.slope;
+        const float *res = P.res;
+        const int ldc = P.ldc, ldr = P.ldr;
+        const __amdgpu_buffer_rsrc_t crs = act_rsrc(P.c + (size_t)row0 * ldc + col0);
+        const __amdgpu_buffer_rsrc_t rrs = act_rsrc(res ? res + (size_t)row0 * ldr + col0 : P.c);
+        const bool writer = wave_u < NB;
+        const float bias = writer ? gload1(P.bias + col0 + wave * 32 + li) : 0.0f;
+        __syncthreads();                                                 // the partial sums have been read
+        if (writer) {
+            float *wr = smem + (4 * lh) * EPI_LD + wave * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wr[((r & 3) + 8 * (r >> 2)) * EPI_LD] = lrelu(fin[r] + bias, slope);
+        }
+        __syncthreads();
+        const bool vec = col0 + COLS <= N;
+#pragma unroll
+        for (int it = 0; it < (32 * TPR + GEMM_THREADS - 1) / GEMM_THREADS; ++it) {
+            const int c = tid + it * GEMM_THREADS;
+            if (c >= 32 * TPR) break;
+            const int lr = c / TPR, c4 = (c % TPR) * 4;
+            if (row0 + lr >= M) continue;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(smem + lr * EPI_LD + c4);
+            if (vec) {
+                if (res) v += act_load4(rrs, (lr * ldr + c4) * 4);
+                act_store4(crs, (lr * ldc + c4) * 4, v);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col0 + c4 + e < N) act_store1(crs, (lr * ldc + c4 + e) * 4, v[e] + (res ? act_load1(rrs, (lr * ldr + c4 + e) * 4) : 0.0f));
+            }
+        }
+        __syncthreads();
+    }
+    R3D_TSTAMP(4);
+}
+
 // ------------------------------------------------------------------------------------ fp32 on the bf16 matrix cores
 //
 // gemm_tile_b3: C = res + lrelu(A W^T + b) like gemm_tile, evaluated by v_mfma_f32_32x32x16_bf16 (16x the FLOP
@@ -555,6 +781,14 @@ __device__ __forceinline__ void b3_split8(const f32x4 &a, const f32x4 &b, bf16x8
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     u32x4 p0, p1, p2;
+#ifdef R3D_EXP_NOSPLIT_W     // (tools/b3_split_bound.sh: what the weights' split costs - the three planes are the leading term; results are wrong)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p0[i] = p1[i] = p2[i] = b3_pack(x[2 * i], x[2 * i + 1]);
+    pl[0] = __builtin_bit_cast(bf16x8, p0);
+    pl[1] = __builtin_bit_cast(bf16x8, p1);
+    pl[2] = __builtin_bit_cast(bf16x8, p2);
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const unsigned h = b3_pack(x[2 * i], x[2 * i + 1]);
@@ -568,6 +802,9 @@ __device__ __forceinline__ void b3_split8(const f32x4 &a, const f32x4 &b, bf16x8
     pl[1] = __builtin_bit_cast(bf16x8, p1);
     pl[2] = __builtin_bit_cast(bf16x8, p2);
 }
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void b3_split4(const f32x4 &x, u32x2 (&pl)[3]);
 
 template <int MI>
 __device__ __forceinline__ void gemm_tile_b3(ProbRef P, const int row0, const int col0, float *smem, long long *dbg) {
@@ -624,14 +861,12 @@ __device__ __forceinline__ void gemm_tile_b3(ProbRef P, const int row0, const in
         for (int i = 0; i < NA; ++i) {
             if (srow + 64 * i >= VR) continue;
             const f32x4 x = R.a[i];
-            const unsigned h0 = b3_pack(x[0], x[1]), h1 = b3_pack(x[2], x[3]);
-            const float r0 = x[0] - b3_lo(h0), r1 = x[1] - b3_hi(h0), r2 = x[2] - b3_lo(h1), r3 = x[3] - b3_hi(h1);
-            const unsigned m0 = b3_pack(r0, r1), m1 = b3_pack(r2, r3);
-            const unsigned l0 = b3_pack(r0 - b3_lo(m0), r1 - b3_hi(m0)), l1 = b3_pack(r2 - b3_lo(m1), r3 - b3_hi(m1));
+            u32x2 pl[3];
+            b3_split4(x, pl);
             float *d = s + i * 64 * B3_LD;
-            *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(m0, m1);
-            *reinterpret_cast<uint2 *>(d + 2 * PLANE) = make_uint2(l0, l1);
+            *reinterpret_cast<u32x2 *>(d) = pl[0];
+            *reinterpret_cast<u32x2 *>(d + PLANE) = pl[1];
+            *reinterpret_cast<u32x2 *>(d + 2 * PLANE) = pl[2];
         }
     };
     // ---- W fragments: fp32, [(n/32)][K tile][k16 half][4-float group][lane][4]
@@ -726,13 +961,16 @@ __device__ __forceinline__ void gemm_tile_b3(ProbRef P, const int row0, const in
 // as its B operand): a lane then owns one row and, per register quad q, the four consecutive channels
 // ch0 + 8 q .. + 3 (ch0 = 32 * wavefront + 4 * (lane / 32)), so activations go to LDS as packed bf16 planes and
 // output rows as float4 - no 2- or 4-byte scatter.
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 struct WFragB3 { f32x4 f[2][2]; };                           // one K tile of a wavefront's 32 channels, fp32: [k16 half][4-float group]
 constexpr int B3T_H_PITCH = 264;                             // bf16 per row of an activation plane: 528 B (conflict-free b128 reads)
 
 // four fp32 values -> their three bf16 terms, packed (exact: every remainder is representable in fp32)
 __device__ __forceinline__ void b3_split4(const f32x4 &x, u32x2 (&pl)[3]) {
     const unsigned h0 = b3_pack(x[0], x[1]), h1 = b3_pack(x[2], x[3]);
+#ifdef R3D_EXP_NOSPLIT_A     // (tools/b3_split_bound.sh: what the activations' split costs; results are wrong)
+    pl[0] = pl[1] = pl[2] = u32x2{h0, h1};
+    return;
+#endif
     const float r0 = x[0] - b3_lo(h0), r1 = x[1] - b3_hi(h0), r2 = x[2] - b3_lo(h1), r3 = x[3] - b3_hi(h1);
     const unsigned m0 = b3_pack(r0, r1), m1 = b3_pack(r2, r3);
     pl[0] = u32x2{h0, h1};
@@ -2702,11 +2940,11 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
             if (dbg_arg && threadIdx.x == 0) dbg_arg[16384 + (long long)t * 4 + 0] = wall_clock64();      // tile fetched
 #endif
             // (GEMV / latency tiles wait themselves, behind their weight requests)
-            if (ndep > 0 && (!NARROW || ks < 8)) wait_deps(tiles + t * TS, ndep, cnt, abort_flag, fargs->spin_ticks);
+            if (ndep > 0 && (!NARROW || !tile_is_narrow(ks))) wait_deps(tiles + t * TS, ndep, cnt, abort_flag, fargs->spin_ticks);
 #ifdef R3D_TIMING
             if (dbg_arg && threadIdx.x == 0) dbg_arg[16384 + (long long)t * 4 + 1] = wall_clock64();      // producers ready
 #endif
-            tdep = TileDeps{tiles + t * TS, NARROW && ks >= 8 ? ndep : 0, cnt, abort_flag, NARROW && fargs->poll != 0, nullptr, fargs->spin_ticks};
+            tdep = TileDeps{tiles + t * TS, NARROW && tile_is_narrow(ks) ? ndep : 0, cnt, abort_flag, NARROW && fargs->poll != 0, nullptr, fargs->spin_ticks};
 #ifdef R3D_TIMING
             if (dbg_arg) tdep.tstamp = dbg_arg + 16384 + (long long)t * 4;
 #endif
@@ -2813,6 +3051,13 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
                 lat_tile(P, col0, smem, tdep);
                 break;
             }
+            }
+            if (ks > NB_CODE) {          // a single-unit tile of 4 .. 7 column blocks
+                if (ks == NB_CODE + 4) gemm_tile_nb<4>(P, row0, col0, smem, dbg);
+                else if (ks == NB_CODE + 5) gemm_tile_nb<5>(P, row0, col0, smem, dbg);
+                else if (ks == NB_CODE + 6) gemm_tile_nb<6>(P, row0, col0, smem, dbg);
+                else gemm_tile_nb<7>(P, row0, col0, smem, dbg);
+                break;
             }
             if (ks > 1) {
                 if (ks == 4) gemm_tile<1, 4>(P, row0, col0, smem, dbg);

@@ -112,7 +112,7 @@ bool schedule_build_fwd(const Plan *pl, int64_t B, int nwg, const std::vector<st
     for (size_t si = 0; si < stages.size(); ++si)
         for (int t = 0; t < stages[si].ntiles; ++t) {
             const int4 &tl = tiles[stages[si].tiles_off + t];
-            if (tl.w >= 8) narrow[levels[si][tl.x & 0xff] & ~STAGE_SPILL_IN] = 1;
+            if (tile_is_narrow(tl.w)) narrow[levels[si][tl.x & 0xff] & ~STAGE_SPILL_IN] = 1;
         }
     for (int i = 0; i < np; ++i)
         for (int dp : pl->probs[i].deps)
@@ -228,6 +228,13 @@ double unit_cycles(int iters, int ks) {
     const CostModel &c = cost_model();
     if (ks > 1) return iters * c.ks_iter + c.ks_fixed;
     return iters * c.iter + c.fixed + (iters < 4 ? (4 - iters) * 1400.0 : 0.0);
+}
+
+// a single-unit tile of nb column blocks (gemm_tile_nb): every SIMD issues 16 + 4 (nb - 4) MFMAs of 64 cycles per K tile; staging and
+// barrier per K tile as in the whole tile (iter - 2048), prologue / epilogue plus the reduction of the split blocks
+double nb_cycles(int nk, int nb) {
+    const CostModel &c = cost_model();
+    return nk * (64.0 * (16 + 4 * (nb - 4)) + (c.iter - 2048.0) + 60.0) + c.fixed + 1500.0;
 }
 
 // a GEMV tile (r3d_kernels.hip): one memory round trip for the weights of its 32 columns, the operand copy, two barriers,
@@ -432,12 +439,86 @@ void pack(const std::vector<SchedProb> &probs, int nbins_max, int max_units, Pac
 
 }  // namespace
 
+// One-tile-deep launches (the M = B levels of a 256-window call: 160 - 224 whole 32 x 256 tiles for 256 CUs): the launch is
+// as long as one tile whatever the packing, and a quarter of the chip idles.  gemm_tile_nb's tiles of 5 - 7 column blocks are
+// proportionally shorter, so the eligible problems' rows of N / 32 blocks are cut into more, narrower tiles - one per
+// workgroup - and the rest of the launch (pyramid riders, short layers) is packed classically into the workgroups left.
+// Returns false when that is not shorter than the classic packing by the cost model.
+static bool pack_nb(const std::vector<SchedProb> &probs, int nwg, int max_units, const Packed &classic, Packed &out) {
+    std::vector<int> elig, rest_idx;
+    std::vector<SchedProb> rest;
+    for (int i = 0; i < (int)probs.size(); ++i) {
+        const SchedProb &p = probs[i];
+        if (p.nb_ok && p.row0 == 0 && p.M > 0 && p.N % 32 == 0) elig.push_back(i);
+        else { rest_idx.push_back(i); rest.push_back(p); }
+    }
+    if (elig.empty()) return false;
+    // only where the classic packing is one whole tile per workgroup for these problems: its budget is a single unit's time
+    double unit_max = 0;
+    long long whole_tiles = 0;
+    for (int i : elig) {
+        unit_max = std::max(unit_max, unit_cycles(probs[i].nk, 1));
+        whole_tiles += (long long)((probs[i].M + 31) / 32) * ((probs[i].N + 255) / 256);
+    }
+    if (whole_tiles > nwg || classic.T > 1.05 * unit_max) return false;
+    double best_T = classic.T * 0.97;                  // (modelled gains of a few percent do not materialise)
+    int best_nb = 0;
+    Packed best_rest;
+    for (int nbmax = 5; nbmax <= 7; ++nbmax) {
+        long long ntiles = 0;
+        double T_nb = 0;
+        for (int i : elig) {
+            const int nblk = probs[i].N / 32, per_row = (nblk + nbmax - 1) / nbmax, widest = (nblk + per_row - 1) / per_row;
+            if (widest < 5 || nblk / per_row < 4) { ntiles = nwg + 1; break; }   // (the kernel's tile kinds: 4 .. 7 blocks, 8 = the whole tile)
+            ntiles += (long long)((probs[i].M + 31) / 32) * per_row;
+            T_nb = std::max(T_nb, nb_cycles(probs[i].nk, widest));
+        }
+        if (ntiles > nwg) continue;
+        double T = T_nb;
+        Packed pr;
+        if (!rest.empty()) {
+            if (nwg - ntiles < 1) continue;
+            pack(rest, (int)(nwg - ntiles), max_units, pr);
+            T = std::max(T, pr.T);
+        }
+        if (T < best_T) { best_T = T; best_nb = nbmax; best_rest = pr; }
+    }
+    if (!best_nb) return false;
+    out = Packed();
+    out.T = best_T;
+    out.ks = best_rest.ks ? best_rest.ks : 1;
+    out.total = 0;
+    // the narrow tiles first: (problem, column tile, unit) - consecutive workgroups share a column tile's weights
+    for (int i : elig) {
+        const int nblk = probs[i].N / 32, per_row = (nblk + best_nb - 1) / best_nb, units = (probs[i].M + 31) / 32;
+        int b0 = 0;
+        for (int t = 0; t < per_row; ++t) {
+            const int w = (nblk - b0 + (per_row - t) - 1) / (per_row - t);      // evenly sized, wider ones first
+            for (int u = 0; u < units; ++u) {
+                out.a.bins.push_back({Run{i, b0 * 32, w == 8 ? 1 : NB_CODE + w, u, 1, 1}});
+                out.total += w == 8 ? unit_cycles(probs[i].nk, 1) : nb_cycles(probs[i].nk, w);
+            }
+            b0 += w;
+        }
+    }
+    for (const auto &bin : best_rest.a.bins) {
+        if (bin.empty()) continue;
+        std::vector<Run> b2 = bin;
+        for (Run &r : b2) r.prob = rest_idx[r.prob];
+        out.a.bins.push_back(b2);
+    }
+    out.total += best_rest.total;
+    out.a.worst = best_T;
+    return true;
+}
+
 void schedule_stage(const std::vector<SchedProb> &probs, int nwg, int max_units, std::vector<int4> &tiles,
                     std::vector<int> &wgoff, StageSchedule &out, bool enc) {
-    Packed big;
+    Packed big, narrow;
     const Packed *best = &big;
     out.kind = enc ? STAGE_ENC : STAGE_BIG;
     pack(probs, nwg, max_units, big);
+    if (!enc && pack_nb(probs, nwg, max_units, big, narrow)) best = &narrow;
     out.ks = 1;
     out.tiles_off = tiles.size();
     out.wgoff_off = wgoff.size();
@@ -504,6 +585,9 @@ static SchedProb sched_prob_of(const Plan *pl, const ProbSpec &q, int64_t B) {
         // ... and of up to 32 rows (one unit): latency tiles on the matrix cores (not beside the bf16x3 tiles: B >= 96 there)
         sp.lat = !sp.gemv && M <= 32 && narrow_ok && !hook_on("R3D_NO_LAT");
         const bool b3 = B >= b3_min_batch();               // (r3d_api.cpp passes the bf16x3 operands under the same condition)
+        // single-unit tiles of 5 - 7 column blocks (gemm_tile_nb) for the wide plain fp32 layers: the FCBlocks' 1024-wide Linears
+        sp.nb_ok = q.enc_lut < 0 && q.layer2 < 0 && !sp.gemv && !sp.lat && !(b3 && L.bf3) && L.N % 32 == 0 && L.N >= 512 &&
+                   L.Kpad / BK >= 8 && !hook_on("R3D_NO_NB");
         if (b3 && L.bf3 && q.layer2 < 0 && q.enc_lut < 0) {   // bf16-matrix-core tiles: whole tiles of <= 128 rows, ~1.5x the iteration rate
             sp.max_ks = 1;
             sp.max_units = 4;
@@ -582,7 +666,7 @@ static void build_stage(const Plan *pl, const std::vector<int> &st, int64_t B, i
     // launch's packing is a function of its problems' shapes, so it is computed once per distinct launch of a build.
     std::vector<int> key{enc ? 1 : 0, nwg};
     for (const SchedProb &sp : probs)
-        key.insert(key.end(), {sp.M, sp.N, sp.nk, sp.max_ks, sp.max_units, sp.nk2, sp.row0, sp.gemv ? 1 : sp.lat ? 2 : 0});
+        key.insert(key.end(), {sp.M, sp.N, sp.nk, sp.max_ks, sp.max_units, sp.nk2, sp.row0, (sp.gemv ? 1 : sp.lat ? 2 : 0) + (sp.nb_ok ? 4 : 0)});
     auto hit = g_stage_memo.find(key);
     if (hit == g_stage_memo.end()) {
         StageMemo m;
@@ -801,7 +885,7 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
                 ok = (e = hipMalloc((void **)&fw.d_ctrl, 2 * fw.bank_bytes + 2 * (size_t)fw.nprob * sizeof(GemmProb))) == hipSuccess;
             }
             bool narrow = false;       // GEMV / latency tiles in the lists: activation banks of the library's own (poll mode)
-            for (size_t t = 0; t * FWD_TILE_INT4 * 4 < ft.size(); ++t) narrow |= ft[t * FWD_TILE_INT4 * 4 + 3] >= 8;
+            for (size_t t = 0; t * FWD_TILE_INT4 * 4 < ft.size(); ++t) narrow |= tile_is_narrow(ft[t * FWD_TILE_INT4 * 4 + 3]);
             // which specialisation of the persistent kernel runs these lists (r3d_kernels.hip, R3D_FORWARD_KERNEL)
             const bool b3_tiles = B >= b3_min_batch() && ((pl->m[0] && pl->m[0]->use_b3) || (pl->m[1] && pl->m[1]->use_b3));
             fw.kernel = narrow ? FWD_KERNEL_LAT : b3_tiles ? FWD_KERNEL_B3 : FWD_KERNEL_F32;

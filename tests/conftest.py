@@ -86,7 +86,8 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     tr.write_line("parity summary: %d configurations at the literal 1e-4 bound (or tighter), worst err %.2e; %d of them with |ref| <= 10 m, worst %.2e"
                   % (len(strict), max([e for e, _, _ in strict.values()] or [0.0]), len(lit), max(lit) if lit else 0.0))
     if relaxed:
-        tr.write_line("parity summary: %d configuration(s) under a labelled RELAXED bound (opt-in bf16x3 on the over-scaled 108 m fixture), worst err %.2e against %.2e"
+        tr.write_line("parity summary: %d configuration(s) under a labelled RELAXED bound (rows above: HIP-against-HIP comparisons whose bound scales with "
+                      "|ref|, and the opt-in bf16x3 mode on the over-scaled 108 m fixture), worst err %.2e, widest bound %.2e"
                       % (len(relaxed), max(e for e, _, _ in relaxed.values()), max(t for _, t, _ in relaxed.values())))
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
