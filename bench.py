@@ -301,6 +301,53 @@ def bf16x3_line(dev, states, x, p, out_f32, args, barrier, cfg):
     return res
 
 
+def half_chip_variant(dev, x, p, out_ref, steps, warmup):
+    """EXPERIMENT, secondary object only (never `value` / `ms_per_step`): two persistent forwards side by side, each on a
+    CU-masked stream of 128 CUs (ray3d_amd.masked_stream: both halves span all eight XCDs) with its own pair of handles
+    (R3D_OPT_CU_LIMIT = 128: 128 workgroups per forward, no cross-stream ordering).  A round = one 256-window forward on
+    EACH stream; the two do not depend on each other, so this is the throughput of back-to-back independent batches, not
+    the latency of one.  At 256 windows the M = B levels of one forward leave 30 - 60 CUs idle (192 - 224 tiles for 256
+    CUs); on 128 CUs the same levels run as two full rounds."""
+    import ray3d_amd
+    streams = [ray3d_amd.masked_stream(range(0, 128), dev), ray3d_amd.masked_stream(range(128, 256), dev)]
+    lifters = []
+    for _ in streams:
+        l, _s = build(dev)
+        l.set_cu_limit(128)
+        lifters.append(l)
+    B = x.shape[0]
+    xs, ps = [x.clone() for _ in streams], [p.clone() for _ in streams]
+    outs = [None, None]
+
+    def round_():
+        for i, (l, st) in enumerate(zip(lifters, streams)):
+            with torch.cuda.stream(st):
+                outs[i] = l(xs[i], ps[i])
+
+    with torch.no_grad():
+        for l, st in zip(lifters, streams):
+            with torch.cuda.stream(st):
+                l.prepare([B], dev)
+        round_()
+        torch.cuda.synchronize()
+        for l in lifters:
+            l.check_status(dev)
+        err = max(float((o - out_ref).abs().max().item()) for o in outs)
+        for _ in range(max(warmup, 30)):
+            round_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            round_()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    del lifters
+    return {"value": round(2 * B * steps / el, 1), "unit": "poses/s", "ms_per_round": round(el / steps * 1e3, 4),
+            "rounds": steps, "windows_per_round": 2 * B, "max_abs_diff_vs_whole_chip_path_m": err,
+            "note": "EXPERIMENT: two independent %d-window forwards per round, one per CU-masked stream of 128 CUs (two pairs of "
+                    "handles, R3D_OPT_CU_LIMIT); throughput of back-to-back independent batches - not the headline's step" % B}
+
+
 def parity_gate(lifter, dev, batch):
     """no timing counts before parity.  The reference's own outputs for the weights this bench
     builds (seeds 1 / 2, decoder scale 1: tests/golden/model_j17_rf243_s3.npz, written by the reference's PyTorch-CPU
@@ -475,6 +522,8 @@ def main():
     ap.add_argument("--no-b1024", action="store_true", help="windows mode: skip the roofline point at 1024 windows")
     ap.add_argument("--no-bf16x3", action="store_true", help="windows mode: skip the secondary bf16x3 (fp32-equivalent) measurement")
     ap.add_argument("--two-stream", action="store_true", help="also time Ray3DLifter.forward_overlapped (two half batches on two streams)")
+    ap.add_argument("--half-chip-streams", action="store_true",
+                    help="also time two independent forwards side by side on two CU-masked streams of 128 CUs (secondary object `two_stream_variant`)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 50 if args.mode == "windows" else 3
@@ -641,9 +690,11 @@ def main():
             if world == 1 and args.two_stream:
                 with torch.no_grad():
                     el2, _, _ = timed_steps(lambda: lifter.forward_overlapped(x, p), args.steps, args.warmup, barrier, dev)
-                line["two_stream_variant"] = {"value": round(args.batch * args.steps / el2, 1), "unit": "poses/s",
+                line["two_half_batches_variant"] = {"value": round(args.batch * args.steps / el2, 1), "unit": "poses/s",
                                               "ms_per_step": round(el2 / args.steps * 1e3, 4),
                                               "note": "same work as `value`, issued as 2 half batches on 2 streams"}
+            if world == 1 and args.half_chip_streams and lifter.precision(dev) == "f32":
+                guarded("two_stream_variant", lambda: half_chip_variant(dev, x, p, out, args.steps, args.warmup))
             if world == 1 and not args.no_cpu_baseline:
                 guarded("cpu_baseline", lambda: cpu_baseline(states, x_np, p_np))
             print(json.dumps(line))

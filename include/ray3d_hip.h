@@ -176,6 +176,12 @@ int r3d_status(r3d_model *m, void *hip_stream);
                                    * co-residency assumption; a few percent slower) instead of one persistent launch    */
 #define R3D_OPT_SPIN_TIMEOUT_MS 2 /* how long a tile of the single-launch forward waits for its producers before the
                                    * forward gives up (default 1000)                                                    */
+#define R3D_OPT_CU_LIMIT 3        /* value = n > 0: this handle's forwards are launched on a CU-masked stream that can use n CUs
+                                   * (hipExtStreamCreateWithCUMask): the single-launch forward uses at most n workgroups, and
+                                   * it is NOT ordered against single-launch forwards of other streams - the caller guarantees
+                                   * that streams used concurrently have DISJOINT masks of at least n CUs each (two half-chip
+                                   * forwards side by side: DESIGN.md 5.2).  0 (default): the whole device.  Drops the
+                                   * handle's cached tile schedules; for a pair set it on both handles.                      */
 int r3d_set_option(r3d_model *m, int32_t option, int64_t value);
 
 /* ---- instrumentation (bench.py / tests) ---- */

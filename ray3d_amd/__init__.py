@@ -12,7 +12,7 @@ All arithmetic of the networks runs in libray3d_hip.so (hand-written gfx950 kern
 ABI of include/ray3d_hip.h).  No CPU fallback exists.
 """
 from .spec import LiftConfig, config_from_dicts, default_model_config   # noqa: F401
-from .modules import (Model, RIEModel, RIETrajectoryModel, Ray3DLifter, load_checkpoint, load_weight)   # noqa: F401
+from .modules import (Model, RIEModel, RIETrajectoryModel, Ray3DLifter, load_checkpoint, load_weight, masked_stream)   # noqa: F401
 from .camera import Camera, augment_camera, camera_grid, synthetic_camera   # noqa: F401
 from . import dataset, evaluate, metrics, synth   # noqa: F401
 

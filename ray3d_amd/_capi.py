@@ -18,7 +18,7 @@ HOOKS_LIB_PATH = os.path.join(_HERE, "libray3d_hip_hooks.so")
 R3D_KIND_POS, R3D_KIND_TRJ = 0, 1
 R3D_INPUT_RAYS, R3D_INPUT_UV = 0, 1
 R3D_ERR_ABORTED = -7
-R3D_OPT_STAGED, R3D_OPT_SPIN_TIMEOUT_MS = 1, 2
+R3D_OPT_STAGED, R3D_OPT_SPIN_TIMEOUT_MS, R3D_OPT_CU_LIMIT = 1, 2, 3
 
 # every symbol include/ray3d_hip.h declares (tests check the library exports exactly these)
 EXPORTS = (

@@ -300,7 +300,9 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
     shape.cam_stride = in->cam_stride;
     shape.frames = frames;
 
-    Schedule *sched = schedule_get(pl, B, device_cu_count());
+    // (R3D_OPT_CU_LIMIT: a CU-masked stream - fewer workgroups, and no ordering against other streams' forwards below)
+    const int cu_limit = std::max(a->cu_limit, b ? b->cu_limit : 0);
+    Schedule *sched = schedule_get(pl, B, cu_limit > 0 ? std::min(cu_limit, device_cu_count()) : device_cu_count());
     if (!sched) return R3D_ERR_HIP;
     const unsigned *abort_flag = nullptr;
     // Clip calls (window stride one frame, lib/train_val/trainer.py:47-58): consecutive windows share all but one of their
@@ -399,7 +401,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         for (int k = 0; bound && k < BIND_NBASE; ++k) bound = bd.base[k] == ba.base[k];
         const int bank = bound ? bd.bank ^ 1 : 0;
         unsigned *cnt = reinterpret_cast<unsigned *>(ctrl + (own ? bank : 0) * bank_bytes);
-        if ((e = order_single_launch(stream, true)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
+        if (cu_limit == 0 && (e = order_single_launch(stream, true)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
         if (!bound) {
             ba.cnt = reinterpret_cast<unsigned *>(ctrl);
             ba.ncnt = own ? (int)(2 * bank_bytes / sizeof(unsigned)) - 4 : fw.ncnt;      // (the kernel zeroes ncnt + 4 words: both banks)
@@ -455,7 +457,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
 #endif
         if ((e = launch_forward(fa, fw.grid, fwd_kernel, uv_launch, stream)) != hipSuccess) return hip_fail(e, "launch r3d_forward_f32");
         a->last_clk_dev = cap == hipStreamCaptureStatusNone ? cnt + fw.ncnt + 2 : nullptr;   // (a captured call runs later, maybe never)
-        if ((e = order_single_launch(stream, false)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        if (cu_limit == 0 && (e = order_single_launch(stream, false)) != hipSuccess) return hip_fail(e, "hipEventRecord");
         if (own) {                     // the next call on these buffers needs no bind
             bd.valid = true;
             bd.bank = bank;
@@ -703,7 +705,8 @@ int r3d_prepare(r3d_model *pos, r3d_model *trj, int64_t B) {
     for (Model *m : {a, b})
         if (m && (!m->finalized || m->dirty)) { set_error("r3d_prepare called before r3d_finalize (or weights changed since)"); return R3D_ERR_STATE; }
     if (b && !same_input_shape(a, b)) { set_error("pos and trj models disagree on J / F / levels / extrinsic_dim"); return R3D_ERR_ARG; }
-    return schedule_get(plan_get(a, b, plan_kind(B)), B, device_cu_count(), /*pin=*/true) ? R3D_OK : R3D_ERR_HIP;
+    const int cu_limit = std::max(a->cu_limit, b ? b->cu_limit : 0);
+    return schedule_get(plan_get(a, b, plan_kind(B)), B, cu_limit > 0 ? std::min(cu_limit, device_cu_count()) : device_cu_count(), /*pin=*/true) ? R3D_OK : R3D_ERR_HIP;
 }
 
 int r3d_release(r3d_model *pos, r3d_model *trj, int64_t B) {
@@ -762,7 +765,11 @@ int r3d_profile_read(r3d_model *m, r3d_launch_record *records, int capacity) {
 int r3d_debug_schedule_check(int nprob, const int *M, const int *N, const int *nk, const int *max_ks, const int *max_units,
                              int nwg, int enc, int *out_grid, int *out_tiles, double *out_imbalance) {
     std::vector<SchedProb> probs;
-    for (int i = 0; i < nprob; ++i) probs.push_back({M[i], N[i], nk[i], max_ks[i], max_units[i]});
+    for (int i = 0; i < nprob; ++i) {
+        probs.push_back({M[i], N[i], nk[i], max_ks[i], max_units[i]});
+        // (as sched_prob_of marks the plan's wide plain layers: their single-unit tiles may be 4 .. 7 column blocks wide)
+        probs.back().nb_ok = !enc && N[i] % 32 == 0 && N[i] >= 512 && nk[i] >= 8 && max_units[i] == 0 && !hook_on("R3D_NO_NB");
+    }
     std::vector<int4> tiles;
     std::vector<int> wgoff;
     StageSchedule ss{};
@@ -1003,6 +1010,15 @@ int r3d_set_option(r3d_model *m, int32_t option, int64_t value) {
         case R3D_OPT_SPIN_TIMEOUT_MS:
             if (value < 1 || value > 600000) { r3d::set_error("r3d_set_option: spin timeout must be 1 .. 600000 ms (got %lld)", (long long)value); return R3D_ERR_ARG; }
             mm->spin_timeout_ms = (int)value;
+            return R3D_OK;
+        case R3D_OPT_CU_LIMIT:
+            if (value < 0 || value > 4096) { r3d::set_error("r3d_set_option: CU limit must be 0 .. 4096 (got %lld)", (long long)value); return R3D_ERR_ARG; }
+            if (mm->cu_limit != (int)value) {
+                // the cached schedules were packed for another workgroup count; their launches may still be in flight
+                if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+                r3d::plans_drop(mm);
+                mm->cu_limit = (int)value;
+            }
             return R3D_OK;
         default: r3d::set_error("r3d_set_option: unknown option %d", option); return R3D_ERR_ARG;
     }

@@ -250,6 +250,7 @@ struct Model {
     // r3d_set_option
     bool opt_staged = false;          // this handle's forwards run one launch per level (no co-residency assumption)
     int spin_timeout_ms = 1000;       // bound of a dependency wait of the single-launch forward
+    int cu_limit = 0;                 // R3D_OPT_CU_LIMIT: CUs of the (masked) stream this handle's forwards run on; 0 = the whole device
     const unsigned *last_clk_dev = nullptr;   // the clock stamp of the last single-launch forward (two words of its counter bank: r3d_last_clock)
     unsigned *status_host = nullptr;  // pinned host word the decoder kernel raises when a wait gave up (r3d_status reads and clears it)
     // profiling

@@ -85,7 +85,9 @@ __device__ __forceinline__ void act_store1(__amdgpu_buffer_rsrc_t r, int byte_of
 // barrier is the one that ends the tile anyway.
 __device__ __forceinline__ void tile_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void tile_signal(const gu32 cnt, const int sig_base, const int sig_add, const int units) {
-    if ((int)threadIdx.x < units) __hip_atomic_fetch_add(cnt + sig_base + threadIdx.x, (unsigned)sig_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));      // (opaque: `cnt + 4 t` would be hoisted out of the persistent loop and stay live - and spill - across every tile)
+    if (t < units) __hip_atomic_fetch_add(cnt + sig_base + t, (unsigned)sig_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // LeakyReLU for slopes in (0, 1] (0.2, 0.01; 1 = linear layer): max(v, slope v) - a multiply and a max instead of
 // multiply, compare, select

@@ -278,6 +278,8 @@ bool assign(const std::vector<Seg> &segs, int nbins, double T, int ksplit, Assig
     const double top_c1 = segs.empty() ? 0.0 : segs.front().c1;
     for (const Seg &s : segs)
         if (s.c1 == top_c1) top_units += s.units;
+    // (two per workgroup where one would do - 64-row first-level tiles of the trajectory model instead of 32-row ones - was
+    //  measured: 0.586 against 0.5786 ms at 256 windows, 1.928 against 1.930 at 1024; round 5)
     const int top_cap = (int)std::max<long long>(1, (top_units + nbins - 1) / nbins);
     for (const Seg &s : segs) {          // sorted by c1, descending
         if (s.gemv) {

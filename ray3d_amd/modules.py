@@ -92,6 +92,7 @@ class LiftModule(nn.Module):
         self._synced = False
         self._staged = False
         self._spin_timeout_ms: Optional[int] = None
+        self._cu_limit = 0
         self._ws = _Workspace()
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
 
@@ -141,6 +142,13 @@ class LiftModule(nn.Module):
         if self._handle is not None:
             self._handle.set_option(_capi.R3D_OPT_SPIN_TIMEOUT_MS, self._spin_timeout_ms)
 
+    def set_cu_limit(self, n: int):
+        """r3d_set_option(R3D_OPT_CU_LIMIT): this module's forwards run on a CU-masked stream of `n` CUs (0: the whole
+        device) - see :func:`ray3d_amd.masked_stream` and Ray3DLifter.set_cu_limit."""
+        self._cu_limit = int(n)
+        if self._handle is not None:
+            self._handle.set_option(_capi.R3D_OPT_CU_LIMIT, self._cu_limit)
+
     def check_status(self, device=None) -> None:
         """Synchronises the current stream of `device` and raises when a forward of this module since the last check
         gave up waiting for its own tiles (r3d_status: its outputs are NaN).  The reference's seam reports errors as
@@ -160,6 +168,8 @@ class LiftModule(nn.Module):
                 self._handle.set_option(_capi.R3D_OPT_STAGED, 1)
             if self._spin_timeout_ms is not None:
                 self._handle.set_option(_capi.R3D_OPT_SPIN_TIMEOUT_MS, self._spin_timeout_ms)
+            if self._cu_limit:
+                self._handle.set_option(_capi.R3D_OPT_CU_LIMIT, self._cu_limit)
         if not self._synced or getattr(self, "_device", None) != device:
             sd = self.state_dict()
             for key in self._handle.keys():
@@ -291,6 +301,14 @@ class Ray3DLifter(nn.Module):
     def set_spin_timeout_ms(self, ms: int):
         self.pos.set_spin_timeout_ms(ms)
         self.trj.set_spin_timeout_ms(ms)
+
+    def set_cu_limit(self, n: int):
+        """The pair's forwards run on a CU-masked stream that can use `n` CUs (R3D_OPT_CU_LIMIT; 0: the whole device): the
+        single persistent launch then uses at most `n` workgroups and is not ordered against forwards of other streams.
+        For two lifters side by side on disjoint halves of the chip (ray3d_amd.masked_stream) - an experiment reported
+        by bench.py --half-chip-streams, not the default path."""
+        self.pos.set_cu_limit(n)
+        self.trj.set_cu_limit(n)
 
     def check_status(self, device=None) -> None:
         """Synchronise and raise if a forward of the pair gave up waiting for its own tiles (the pair's flag lives in the
@@ -548,3 +566,35 @@ def load_checkpoint(path: str, pos_model, trj_model=None) -> dict:
             raise KeyError("%s has no 'model_trj' entry but a trajectory model was given" % path)
         load_weight(trj_model, ckpt["model_trj"])
     return {k: v for k, v in ckpt.items() if k not in ("model_pos", "model_trj", "optimizer")}
+
+
+def masked_stream(cu_bits, device=None):
+    """A HIP stream restricted to the CUs whose bits are set in `cu_bits` (an iterable of CU indices), as a
+    torch.cuda.ExternalStream: hipExtStreamCreateWithCUMask through ctypes on the HIP runtime torch has loaded.  Bit i of the
+    mask is CU i // 8 of XCD i % 8 on MI355X's 8 x 32 CUs (the driver deals consecutive bits to consecutive XCDs), so
+    `range(0, 128)` and `range(128, 256)` are two disjoint halves that both span all eight XCDs (and their L2s).
+    The stream lives until the process ends (torch does not own it)."""
+    import ctypes
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    bits = sorted(set(int(b) for b in cu_bits))
+    if not bits or bits[0] < 0:
+        raise ValueError("masked_stream needs at least one CU index >= 0")
+    words = (bits[-1] // 32) + 1
+    mask = (ctypes.c_uint32 * words)()
+    for b in bits:
+        mask[b // 32] |= 1 << (b % 32)
+    hip = None
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+        try:
+            hip = ctypes.CDLL(name)
+            break
+        except OSError:
+            continue
+    if hip is None:
+        raise _capi.Ray3DHipError("the HIP runtime (libamdhip64.so) could not be loaded")
+    stream = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(stream), ctypes.c_uint32(words), mask)
+    if rc != 0 or not stream.value:
+        raise _capi.Ray3DHipError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
+    return torch.cuda.ExternalStream(stream.value, device=dev)

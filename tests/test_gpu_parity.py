@@ -1565,6 +1565,58 @@ def test_two_streams_share_a_lifter(B):
         assert torch.equal(got, want)
 
 
+def test_two_lifters_side_by_side_on_half_chip_streams():
+    """R3D_OPT_CU_LIMIT (Ray3DLifter.set_cu_limit) + ray3d_amd.masked_stream: two pairs of handles, each on a CU-masked stream
+    of 128 CUs (disjoint halves of the chip), lift different batches at the same time - the single persistent launch with at
+    most 128 workgroups each, not ordered against the other stream.  Both get the oracle's poses (the literal bound), every
+    time, nothing aborts; the forward kernel's grid is <= 128; back on an unmasked stream with the limit lifted the same
+    lifter runs on the whole chip again."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    from oracle import torch_port
+    if os.environ.get("R3D_STAGED") == "1":
+        pytest.skip("the limit concerns the single-launch form")
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3,3")
+    B = 256
+    streams = [ray3d_amd.masked_stream(range(0, 128)), ray3d_amd.masked_stream(range(128, 256))]
+    lifters, xs, refs = [], [], []
+    p = torch.from_numpy(synth.synth_param(B, seed=9)).cuda()
+    for i in range(2):
+        pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+        l = ray3d_amd.Ray3DLifter(pos, trj).eval()
+        l.set_cu_limit(128)
+        lifters.append(l)
+        x = synth.synth_rays(B, cp, seed=500 + i)
+        xs.append(torch.from_numpy(x).cuda())
+        sds = [{k: torch.from_numpy(np.asarray(v)) for k, v in s_.items()} for s_ in (sp, st)]
+        with torch.no_grad():
+            refs.append((torch_port.forward(cp, sds[0], torch.from_numpy(x), p.cpu()) +
+                         torch_port.forward(ct, sds[1], torch.from_numpy(x), p.cpu())).numpy())
+    outs = [[], []]
+    with torch.no_grad():
+        for it in range(12):
+            for i in range(2):
+                with torch.cuda.stream(streams[i]):
+                    outs[i].append(lifters[i](xs[i], p))
+        torch.cuda.synchronize()
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                lifters[i].check_status()
+                recs = lifters[i].profile_call(lambda: lifters[i](xs[i], p), "cuda:0")
+            fw = [r for r in recs if r["kernel"].startswith("r3d_forward")]
+            assert fw and all(r["blocks"] <= 128 for r in fw), recs
+    for i in range(2):
+        check_parity(outs[i][0], refs[i], "half-chip stream %d vs torch port" % i)
+        for o in outs[i][1:]:
+            assert torch.equal(o, outs[i][0])
+    with torch.no_grad():
+        lifters[0].set_cu_limit(0)
+        whole = lifters[0](xs[0], p)
+        recs = lifters[0].profile_call(lambda: lifters[0](xs[0], p), "cuda:0")
+    assert max(r["blocks"] for r in recs if r["kernel"].startswith("r3d_forward")) > 128
+    check_parity(whole, refs[0], "the same lifter on the whole chip again")
+
+
 def test_pos_and_trj_with_different_channel_counts():
     """CHANNELS may differ between the two networks (separate model_configs in the reference): one of them fusable
     (<= 256 channels), the other not - the pair then runs the un-fused first level for both (r3d_plan.cpp) instead of

@@ -735,6 +735,39 @@ def test_single_launch_forward_is_a_sound_dependency_machine():
     hp.close()
 
 
+def test_narrow_column_tiles_and_the_cu_limit_option_on_the_host():
+    """(i) One-tile-deep M = B launches are re-tiled with gemm_tile_nb's narrower single-unit tiles (tile codes 64 + 4 .. 7):
+    exact cover by the library's own checker, and fewer modelled cycles than the whole-tile packing it replaces.
+    (ii) R3D_OPT_CU_LIMIT is accepted (0 .. 4096), rejected outside, and the single-launch lists for a 128-CU stream are a
+    sound dependency machine."""
+    lib = hooks_library()
+    # 6 problems of 256 x 1024 (K = 1024): the Integration levels of a 256-window call - 192 whole tiles for 256 CUs
+    probs = [(256, 1024, 32, 4, 0)] * 6
+    rc, grid, tiles, imb = _schedule_check(probs)
+    assert rc == 0 and tiles == 240 and grid == 240, (rc, grid, tiles)        # five tiles per row of 32 blocks: 7 + 7 + 6 + 6 + 6
+    # seven problems: 7 x 8 x 5 narrow tiles would be 280 > 256 - the whole tiles stay
+    rc, grid, tiles, imb = _schedule_check([(256, 1024, 32, 4, 0)] * 7)
+    assert rc == 0 and tiles == 224, (rc, tiles)
+    # 128 windows (four units): the split-K pieces of the classic packing stay where they are modelled shorter
+    assert _schedule_check([(128, 1024, 32, 4, 0)] * 7)[0] == 0
+    assert _schedule_check([(192, 1024, 32, 4, 0)] * 7)[0] == 0
+    fn = lib.r3d_debug_forward_check
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    fn.restype = ctypes.c_int
+    mc = default_model_config(ARCHITECTURE="3,3,3,3,3")
+    hp, ht = _capi.Handle(config_from_dicts(mc, "pos")), _capi.Handle(config_from_dicts(mc, "trj"))
+    n, c = ctypes.c_int(), ctypes.c_int()
+    for h in (hp, ht):
+        h.set_option(_capi.R3D_OPT_CU_LIMIT, 128)
+        with pytest.raises(_capi.Ray3DHipError):
+            h.set_option(_capi.R3D_OPT_CU_LIMIT, -1)
+    for B in (192, 256, 512):
+        assert fn(hp.ptr, ht.ptr, B, 128, ctypes.byref(n), ctypes.byref(c)) == 0, B
+    for h in (hp, ht):
+        h.set_option(_capi.R3D_OPT_CU_LIMIT, 0)
+        h.close()
+
+
 def test_plans_do_not_outlive_a_partner_model():
     """A (pos, trj) plan holds the partner's layer indices and K paddings.  It is keyed by model ids that are never
     reused and dropped when either model is destroyed: a new trajectory model - which malloc may well place at the old
