@@ -533,8 +533,10 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         if ((n_enc != 0) != (ss.kind == STAGE_ENC)) { set_error("internal: schedule and plan disagree on the launch kind"); return R3D_ERR_STATE; }
         bool uv_launch = false;                             // UV mode: only the launches that gather from the input
         for (int i = 0; i < la.nprob; ++i) uv_launch = uv_launch || la.p[i].cam != nullptr;
+        bool b3_launch = false;                             // (launch_gemm_stage picks the kernel by the same test)
+        for (int i = 0; i < la.nprob; ++i) b3_launch = b3_launch || la.p[i].wb3 != nullptr;
         const char *kname = ss.kind == STAGE_ENC ? (uv_launch ? "r3d_gemm_enc_uv_f32" : "r3d_gemm_enc_f32")
-                                                 : (uv_launch ? "r3d_gemm_uv_f32" : "r3d_gemm_f32");
+                          : b3_launch ? (uv_launch ? "r3d_gemm_uv_b3" : "r3d_gemm_b3") : (uv_launch ? "r3d_gemm_uv_f32" : "r3d_gemm_f32");
         if ((e = rec.begin(kname, stage_no, ss.nwg, ss.flops, ss.bytes)) != hipSuccess) return hip_fail(e, "hipEventRecord");
 #ifdef R3D_TIMING
         // development build only (tools/build_probe.sh): phase stamps of the first tiles of launch $R3D_TIMING_STAGE

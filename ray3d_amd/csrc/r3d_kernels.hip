@@ -3128,13 +3128,24 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
 extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_f32(const LaunchArgs args_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     (void)args_;
-    gemm_persistent<false, false>(smem);
+    gemm_persistent<false, false, false, false>(smem);      // (the fp32 tiles only: the bf16x3 tile kinds live in r3d_gemm_b3)
+}
+// ... and for launches of handles in bf16x3 mode (some problem carries GemmProb::wb3)
+extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_b3(const LaunchArgs args_) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    (void)args_;
+    gemm_persistent<false, false, false, true>(smem);
+}
+extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_uv_b3(const LaunchArgs args_) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    (void)args_;
+    gemm_persistent<false, true, false, true>(smem);
 }
 // the same for launches whose gathered operands are pixel keypoints (UV input mode: rays encoded while staging)
 extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_uv_f32(const LaunchArgs args_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     (void)args_;
-    gemm_persistent<false, true>(smem);
+    gemm_persistent<false, true, false, false>(smem);
 }
 
 // The whole forward in one launch: every level's tiles, ordered by ready counters (wait_deps above).  One workgroup per
@@ -3201,18 +3212,21 @@ extern "C" __global__ __launch_bounds__(GEMM_THREADS, 4) void r3d_gemm_enc_uv_f3
 }
 
 hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, int kind, bool uv, hipStream_t stream) {
+    bool b3 = false;                 // some problem runs on the bf16 matrix cores: the kernel that carries those tile kinds
+    for (int i = 0; i < args.nprob; ++i) b3 = b3 || args.p[i].wb3 != nullptr;
     // more dynamic LDS than the 64 KiB default cap: raised once per device (a process may drive several)
     static bool attr_done_dev[64] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     bool &attr_done = attr_done_dev[dev];
     if (!attr_done) {
-        const void *big[2] = {reinterpret_cast<const void *>(r3d_gemm_f32), reinterpret_cast<const void *>(r3d_gemm_uv_f32)};
+        const void *big[4] = {reinterpret_cast<const void *>(r3d_gemm_f32), reinterpret_cast<const void *>(r3d_gemm_uv_f32),
+                              reinterpret_cast<const void *>(r3d_gemm_b3), reinterpret_cast<const void *>(r3d_gemm_uv_b3)};
         const void *enc[2] = {reinterpret_cast<const void *>(r3d_gemm_enc_f32), reinterpret_cast<const void *>(r3d_gemm_enc_uv_f32)};
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 4; ++i) {
             hipError_t e = hipFuncSetAttribute(big[i], hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
             if (e != hipSuccess) return e;
-            if ((e = hipFuncSetAttribute(enc[i], hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS_BYTES)) != hipSuccess) return e;
+            if (i < 2 && (e = hipFuncSetAttribute(enc[i], hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS_BYTES)) != hipSuccess) return e;
         }
         attr_done = true;
     }
@@ -3220,8 +3234,13 @@ hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, int kind, bool uv,
         if (uv) r3d_gemm_enc_uv_f32<<<dim3(nwg), dim3(GEMM_THREADS), ENC_LDS_BYTES, stream>>>(args);
         else r3d_gemm_enc_f32<<<dim3(nwg), dim3(GEMM_THREADS), ENC_LDS_BYTES, stream>>>(args);
     } else {
-        if (uv) r3d_gemm_uv_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
-        else r3d_gemm_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
+        if (b3) {
+            if (uv) r3d_gemm_uv_b3<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
+            else r3d_gemm_b3<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
+        } else {
+            if (uv) r3d_gemm_uv_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
+            else r3d_gemm_f32<<<dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream>>>(args);
+        }
     }
     return hipGetLastError();
 }

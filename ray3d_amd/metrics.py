@@ -3,6 +3,11 @@
 Counterparts of lib/loss/loss.py: mpjpe (:12-18), n_mpjpe (:72-82), p_mpjpe (:30-69, NumPy SVD in
 the reference, batched torch.linalg.svd here so it can stay on the GPU), mean_velocity_error
 (:95-104).  All take (..., J, 3) tensors and return a 0-d tensor.
+
+HOST-SIDE ONLY: the product path computes these on the device in float64 (r3d_clip_metrics, csrc/r3d_metrics.hip), which
+is what `evaluate.clip_partials` calls for every CUDA tensor.  This module serves CPU tensors - the host-logic tests that
+drive the evaluation loop with a stand-in lifter (tests/test_host.py) and callers without a GPU tensor in hand; it is
+never a fallback for the HIP kernels.
 """
 from __future__ import annotations
 
