@@ -1565,6 +1565,44 @@ def test_two_streams_share_a_lifter(B):
         assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("arch,B", [("3,3,3", 130), ("3,3,3", 192), ("3,3,3", 200), ("3,3,3", 250), ("3,3", 300), ("3,3,3,3", 224)])
+def test_narrow_column_tiles_against_the_oracle(arch, B, monkeypatch):
+    """Calls whose M = B levels are one tile deep run them as single-unit tiles of 4 .. 7 column blocks (gemm_tile_nb: whole blocks
+    on wavefronts 0-3, quarter blocks on 4-7, partial sums through LDS): every width, ragged last units (130 = 4 units + 2 rows,
+    250 = 7 units + 26 rows), the residual layers, concatenated operands - all windows against the torch port at the literal
+    bound, the level-by-level form bit-identical (same tiles), and the whole-tile packing (R3D_NO_NB, hooks build) within rounding."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    from oracle import torch_port
+    if os.environ.get("R3D_BF16X3") == "1":
+        pytest.skip("bf16x3 handles run these layers on the bf16 matrix cores")
+    mc = ray3d_amd.default_model_config(ARCHITECTURE=arch)
+
+    def lift(staged=False):
+        pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+        lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+        lifter.set_staged(staged)
+        x = synth.synth_rays(B, cp, seed=77)
+        p = synth.synth_param(B, seed=78)
+        with torch.no_grad():
+            out = lifter(torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda())
+        lifter.check_status()
+        return out, (cp, sp, ct, st, x, p)
+    out, (cp, sp, ct, st, x, p) = lift()
+    sds = [{k: torch.from_numpy(np.asarray(v)) for k, v in s_.items()} for s_ in (sp, st)]
+    with torch.no_grad():
+        ref = (torch_port.forward(cp, sds[0], torch.from_numpy(x), torch.from_numpy(p)) +
+               torch_port.forward(ct, sds[1], torch.from_numpy(x), torch.from_numpy(p))).numpy()
+    check_parity(out, ref, "narrow tiles vs torch port")
+    if os.environ.get("R3D_STAGED") != "1":
+        assert torch.equal(lift(staged=True)[0], out)
+    dev_switch(monkeypatch, "R3D_NO_NB", "1")
+    whole, _ = lift()
+    check_parity(whole, ref, "whole tiles vs torch port")
+    assert not torch.equal(whole, out)                        # (the switch really selects the other tiling)
+    assert (whole - out).abs().max().item() <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+
+
 def test_two_lifters_side_by_side_on_half_chip_streams():
     """R3D_OPT_CU_LIMIT (Ray3DLifter.set_cu_limit) + ray3d_amd.masked_stream: two pairs of handles, each on a CU-masked stream
     of 128 CUs (disjoint halves of the chip), lift different batches at the same time - the single persistent launch with at
