@@ -23,7 +23,10 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int C = 256, K0 = 64, NCB = C / 16, TR = 128, WROWS = 16;
 #ifndef ABL
-#define ABL 0      // ablations (timing only): 1 no slab staging / barrier, 2 no LDS reads in the K loop, 3 both
+#define ABL 0      // ablations (timing only): 1 no slab staging / barrier, 2 no LDS reads in the K loop, 3 both, 4 weights per wavefront from L2 (exact), 5 barrier only, 6 staging without the barrier
+#endif
+#ifndef SYNC
+#define SYNC 1     // 1: slabs handed over by LDS counters (wavefronts free-run, no s_barrier in the K loop); 0: one s_barrier per slab
 #endif
 #ifndef SLAB_STEPS_
 #define SLAB_STEPS_ 8
@@ -63,8 +66,24 @@ __global__ __launch_bounds__(512) void chain_tile(const Args a) {
 #pragma unroll
         for (int i = 0; i < SV; ++i) *reinterpret_cast<f32x4 *>(dst + i * 2048) = stg[i];
     };
+    // SYNC == 1: ready[stage] counts the wavefronts that have written their share of the slab now in the stage (8 per generation),
+    // done[stage] those that have finished reading it; a wavefront polls only when it is more than a slab ahead of the slowest one
+    unsigned *ctr = reinterpret_cast<unsigned *>(lds + NSTAGE * SLAB_FLOATS);      // ready[0..NSTAGE), done[NSTAGE..2 NSTAGE)
+    auto ctr_add = [&](int idx) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(ctr + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto ctr_wait = [&](int idx, unsigned need) {
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+#ifdef STAGGER
+    for (int i = 0; i < (int)(blockIdx.x % 32) * STAGGER; ++i) __builtin_amdgcn_s_sleep(16);   // (workgroups out of phase: do they fight for the same L2 lines?)
+#endif
+    if (SYNC && tid < 2 * NSTAGE) ctr[tid] = 0u;
+    if (SYNC) __syncthreads();
     int slab = 0;                                              // running slab index (the ring position)
-    for (int p = 0; p < AHEAD; ++p) { slab_issue(p); slab_commit(p); }
+    for (int p = 0; p < AHEAD; ++p) { slab_issue(p); slab_commit(p); if (SYNC) ctr_add(p % NSTAGE); }
     __syncthreads();
     f32x4 D1[NCB], D2[NCB];
     for (int tile = 0; tile < a.tiles_per_wg; ++tile) {
@@ -100,7 +119,7 @@ __global__ __launch_bounds__(512) void chain_tile(const Args a) {
         };
 #else
         auto run_slab = [&](auto bsrc, f32x4 (&acc)[NCB]) {
-#if ABL != 1 && ABL != 3
+#if ABL != 1 && ABL != 3 && ABL != 5
             slab_issue(slab + AHEAD);
 #endif
             __builtin_amdgcn_sched_barrier(0);                 // (the requests stay HERE: the compiler would sink them to their LDS writes)
@@ -127,11 +146,25 @@ __global__ __launch_bounds__(512) void chain_tile(const Args a) {
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
-#if ABL != 1 && ABL != 3
+#if SYNC && ABL == 0
+            ctr_add(NSTAGE + slab % NSTAGE);                                       // this wavefront is done reading slab `slab`
+            {   // slab + AHEAD goes into the stage that held slab + AHEAD - NSTAGE: every wavefront must be done with that one
+                const int m = slab + AHEAD;
+                if (m >= NSTAGE) ctr_wait(NSTAGE + m % NSTAGE, 8u * (unsigned)(m / NSTAGE));
+                slab_commit(m);
+                ctr_add(m % NSTAGE);
+            }
+            ++slab;
+            ctr_wait(slab % NSTAGE, 8u * (unsigned)(slab / NSTAGE + 1));           // the next slab is complete
+#else
+#if ABL != 1 && ABL != 3 && ABL != 5
             slab_commit(slab + AHEAD);
+#endif
+#if ABL != 1 && ABL != 3 && ABL != 6
             __syncthreads();
 #endif
             ++slab;
+#endif
         };
 #endif
         float xv[K0 / 4];                                      // this lane's operand values of the NEXT expand_conv, requested a phase ahead
@@ -230,7 +263,7 @@ int main(int argc, char **argv) {
     hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dw, wsl.data(), wsl.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(db0, b0.data(), C * 4, hipMemcpyHostToDevice); hipMemcpy(db1, b1.data(), C * 4, hipMemcpyHostToDevice); hipMemcpy(db2, b2.data(), C * 4, hipMemcpyHostToDevice);
     a.x = dx; a.wsl = dw; a.b0 = db0; a.b1 = db1; a.b2 = db2; a.out = dout; a.tiles_per_wg = tiles_per_wg;
-    const int lds_bytes = NSTAGE * SLAB_FLOATS * 4;
+    const int lds_bytes = NSTAGE * SLAB_FLOATS * 4 + 64;
     hipFuncSetAttribute(reinterpret_cast<const void *>(chain_tile), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     chain_tile<<<nwg, 512, lds_bytes>>>(a);
     if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
