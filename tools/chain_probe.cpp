@@ -26,13 +26,14 @@ constexpr int C = 256, K0 = 64, NCB = C / 16, TR = 128, WROWS = 16;
 #define ABL 0      // ablations (timing only): 1 no slab staging / barrier, 2 no LDS reads in the K loop, 3 both, 4 weights per wavefront from L2 (exact), 5 barrier only, 6 staging without the barrier
 #endif
 #ifndef SYNC
-#define SYNC 1     // 1: slabs handed over by LDS counters (wavefronts free-run, no s_barrier in the K loop); 0: one s_barrier per slab
+#define SYNC 1     // 1: slabs handed over by LDS counters (wavefronts free-run, no s_barrier in the K loop); 0: one s_barrier per slab;
+                   // 2: counters + direct-to-LDS loads (global_load_lds_dwordx4: no VGPR staging, no ds_write), four stages
 #endif
 #ifndef SLAB_STEPS_
 #define SLAB_STEPS_ 8
 #endif
 constexpr int SLAB_STEPS = SLAB_STEPS_, SLAB_FLOATS = SLAB_STEPS * NCB * 64;    // 8 steps: 8192 floats = 32 KB
-constexpr int NSTAGE = SLAB_STEPS == 8 ? 3 : 2, AHEAD = NSTAGE - 1;       // slabs requested AHEAD slabs before their use
+constexpr int NSTAGE = SYNC == 2 ? 4 : SLAB_STEPS == 8 ? 3 : 2, AHEAD = SYNC == 2 ? 2 : NSTAGE - 1;   // slabs requested AHEAD slabs before their use
 // slabs per layer: a layer with Kc input features has Kc / 4 steps
 constexpr int SL_EXP = K0 / 4 / SLAB_STEPS, SL_C = C / 4 / SLAB_STEPS;       // 2, 8
 constexpr int SLABS_PER_TILE = 3 * (SL_EXP + SL_C) + SL_C + SL_EXP;         // + the residual tap's expand_conv again
@@ -82,8 +83,21 @@ __global__ __launch_bounds__(512) void chain_tile(const Args a) {
 #endif
     if (SYNC && tid < 2 * NSTAGE) ctr[tid] = 0u;
     if (SYNC) __syncthreads();
+    // SYNC == 2: this wavefront's eighth of slab s straight into its ring stage: 4 x 1 KiB per wavefront (LDS address = uniform base + 16 lane)
+    auto slab_dma = [&](int s) {
+        const float *src = a.wsl + (size_t)(s % SLABS_PER_TILE) * SLAB_FLOATS + wave * 1024 + lane * 4;
+        float *dst = lds + (s % NSTAGE) * SLAB_FLOATS + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * 256),
+                                             (__attribute__((address_space(3))) void *)(dst + i * 256), 16, 0, 0);
+    };
     int slab = 0;                                              // running slab index (the ring position)
-    for (int p = 0; p < AHEAD; ++p) { slab_issue(p); slab_commit(p); if (SYNC) ctr_add(p % NSTAGE); }
+    for (int p = 0; p < AHEAD; ++p) {
+        if (SYNC == 2) { slab_dma(p); __builtin_amdgcn_s_waitcnt(0x0F70); }
+        else { slab_issue(p); slab_commit(p); }
+        if (SYNC) ctr_add(p % NSTAGE);
+    }
     __syncthreads();
     f32x4 D1[NCB], D2[NCB];
     for (int tile = 0; tile < a.tiles_per_wg; ++tile) {
@@ -119,7 +133,13 @@ __global__ __launch_bounds__(512) void chain_tile(const Args a) {
         };
 #else
         auto run_slab = [&](auto bsrc, f32x4 (&acc)[NCB]) {
-#if ABL != 1 && ABL != 3 && ABL != 5
+#if SYNC == 2 && ABL == 0
+            {   // slab + AHEAD goes into the stage that held slab + AHEAD - NSTAGE (two slabs back): every wavefront done with that one?
+                const int m = slab + AHEAD;
+                if (m >= NSTAGE) ctr_wait(NSTAGE + m % NSTAGE, 8u * (unsigned)(m / NSTAGE));
+                slab_dma(m);
+            }
+#elif ABL != 1 && ABL != 3 && ABL != 5
             slab_issue(slab + AHEAD);
 #endif
             __builtin_amdgcn_sched_barrier(0);                 // (the requests stay HERE: the compiler would sink them to their LDS writes)
@@ -146,7 +166,13 @@ __global__ __launch_bounds__(512) void chain_tile(const Args a) {
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
-#if SYNC && ABL == 0
+#if SYNC == 2 && ABL == 0
+            ctr_add(NSTAGE + slab % NSTAGE);                                       // done reading slab `slab`
+            __builtin_amdgcn_s_waitcnt(0x0F70);                                    // vmcnt(0): this wavefront's share of slab + AHEAD has landed
+            ctr_add((slab + AHEAD) % NSTAGE);
+            ++slab;
+            ctr_wait(slab % NSTAGE, 8u * (unsigned)(slab / NSTAGE + 1));           // the next slab is complete
+#elif SYNC && ABL == 0
             ctr_add(NSTAGE + slab % NSTAGE);                                       // this wavefront is done reading slab `slab`
             {   // slab + AHEAD goes into the stage that held slab + AHEAD - NSTAGE: every wavefront must be done with that one
                 const int m = slab + AHEAD;
