@@ -462,16 +462,17 @@ static bool pack_nb(const std::vector<SchedProb> &probs, int nwg, int max_units,
         unit_max = std::max(unit_max, unit_cycles(probs[i].nk, 1));
         whole_tiles += (long long)((probs[i].M + 31) / 32) * ((probs[i].N + 255) / 256);
     }
-    if (whole_tiles > nwg || classic.T > 1.05 * unit_max) return false;
-    double best_T = classic.T * 0.97;                  // (modelled gains of a few percent do not materialise)
+    const bool force = hook_on("R3D_NB_FORCE");        // (hooks build: A/B of the cost model's verdict)
+    if (whole_tiles > nwg || (classic.T > 1.05 * unit_max && !force)) return false;
+    double best_T = force ? 1e30 : classic.T * 0.97;   // (modelled gains of a few percent do not materialise)
     int best_nb = 0;
     Packed best_rest;
-    for (int nbmax = 5; nbmax <= 7; ++nbmax) {
+    for (int nbmax = force ? 4 : 5; nbmax <= 7; ++nbmax) {
         long long ntiles = 0;
         double T_nb = 0;
         for (int i : elig) {
             const int nblk = probs[i].N / 32, per_row = (nblk + nbmax - 1) / nbmax, widest = (nblk + per_row - 1) / per_row;
-            if (widest < 5 || nblk / per_row < 4) { ntiles = nwg + 1; break; }   // (the kernel's tile kinds: 4 .. 7 blocks, 8 = the whole tile)
+            if ((widest < 5 && !force) || nblk / per_row < 4) { ntiles = nwg + 1; break; }   // (the kernel's tile kinds: 4 .. 7 blocks, 8 = the whole tile)
             ntiles += (long long)((probs[i].M + 31) / 32) * per_row;
             T_nb = std::max(T_nb, nb_cycles(probs[i].nk, widest));
         }
