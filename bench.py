@@ -34,7 +34,12 @@ Prints ONE JSON line (rank 0).  Besides the driver's keys it carries
                   forward for the very weights this bench builds), checked BEFORE anything is timed: > 1e-4 aborts;
   cfg4, cfg5      poses/s + roofline of the shipped RF-9 configurations (see --workload);
   cpu_baseline    the PyTorch-CPU port of the same module graph (oracle/torch_port.py) and the C restatement
-                  (oracle/ray3d_oracle.c) timed on this host's cores on a bounded sample of the same workload.
+                  (oracle/ray3d_oracle.c) timed on this host's cores on a bounded sample of the same workload (rank 0, every N);
+  eval_pass       (windows mode, whenever a process group exists - the driver's --gpus N > 1 command, or any run under a
+                  launcher) north_star's multi-GPU split: the --mode eval workload, clips sharded over the ranks, one RCCL
+                  all_gather of the per-clip rows per pass: poses/s (strong scaling), shard_frames, pass_ms_per_rank,
+                  pass_ms_imbalance, all_gather_ms, the gathered MPJPE + checksum (independent of N), world_size_observed,
+                  cross_rank_rows_bit_equal (every rank re-lifts one clip of its neighbour's shard: same bits).
 """
 import argparse
 import json
@@ -492,6 +497,95 @@ def eval_summary(allrows):
             "checksum": float(allrows[allrows[:, 0].argsort()][:, 3].sum().item())}
 
 
+def eval_pass(lifter, dev, dist, world, rank, n_clips, steps, warmup, barrier, max_over_ranks, all_ranks, cross_check=True):
+    """BASELINE configs[2] / north_star's multi-GPU split on this process group: the synthetic clip set sharded over the ranks as
+    whole clips (longest first), every clip lifted with in-kernel sliding windows and reduced to one row on the device, ONE
+    all_gather of the rows per pass (lib/train_val/trainer.py:399-403,473-477 reduce them per action).  Strong scaling: the
+    set is fixed.  Returns (on every rank) a dict; the fields that need the gathered rows are complete on rank 0.
+    `cross_check`: every rank also lifts the first clip of the NEXT rank's shard, and the row it computes must equal the
+    gathered one bit for bit - what a clip's row is does not depend on which rank (or how many ranks) lifted it."""
+    from ray3d_amd import evaluate
+    part = eval_partition(n_clips, world)
+    lengths, cams, shards, aid = part["lengths"], part["cams"], part["shards"], part["aid"]
+
+    def resident(idx):
+        c = make_clip(idx, lengths[idx], cams)
+        padded = torch.from_numpy(evaluate.pad_clip(c.rays, 121)).to(dev)
+        return (c, padded, torch.from_numpy(c.camera.param()).to(dev), torch.from_numpy(c.gt_norm).to(dev))
+
+    t0 = time.perf_counter()
+    mine = [resident(idx) for idx in shards[rank]]
+    sizes = sorted(set(b for c, _, _, _ in mine for b in lifter.clip_batch_sizes(c.rays.shape[0])))
+    lifter.prepare(sizes, dev)
+    setup_s = time.perf_counter() - t0
+    # the rank's per-clip rows: header columns (clip, action, frames) uploaded ONCE, error columns written on the device
+    local_rows = evaluate.partial_rows([(c.clip_id, aid[c.action], c.rays.shape[0]) for c, _, _, _ in mine], dev)
+    counts = [len(s_) for s_ in shards]
+
+    def lift_mine():
+        for k, (c, padded, prow, gt) in enumerate(mine):
+            evaluate.clip_partials_hip(lifter.forward_clip(padded, prow), c, aid[c.action], gt_dev=gt, out=local_rows[k])
+
+    def one_pass():
+        lift_mine()
+        return evaluate.gather_partials(local_rows, counts) if dist is not None else local_rows
+
+    with torch.no_grad():
+        one_pass()                          # first touch: workspace allocation
+        elapsed_own, dev_s, allrows = timed_steps(one_pass, steps, warmup, barrier, dev)
+        # this rank's own pass (its clips, no gather, device time): what the shard costs without waiting for the others
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        barrier()
+        e0.record(torch.cuda.current_stream(dev))
+        lift_mine()
+        e1.record(torch.cuda.current_stream(dev))
+        # ... and the single exchange step by itself, behind a barrier (host wall clock: the collective runs on RCCL's stream)
+        barrier()
+        tg = time.perf_counter()
+        if dist is not None:
+            evaluate.gather_partials(local_rows, counts)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        own_pass_ms = e0.elapsed_time(e1)
+        cross_ok = None
+        if cross_check and world > 1 and shards[(rank + 1) % world]:
+            idx = shards[(rank + 1) % world][0]
+            c, padded, prow, gt = resident(idx)
+            row = evaluate.partial_rows([(c.clip_id, aid[c.action], c.rays.shape[0])], dev)
+            evaluate.clip_partials_hip(lifter.forward_clip(padded, prow), c, aid[c.action], gt_dev=gt, out=row[0])
+            theirs = allrows[allrows[:, 0] == float(idx)]
+            cross_ok = float(theirs.shape[0] == 1 and bool(torch.equal(theirs[0], row[0])))
+    elapsed = max_over_ranks(elapsed_own)
+    per_rank_pass_ms = all_ranks(own_pass_ms)
+    gather_ms = max_over_ranks(gather_ms)
+    cross = all_ranks(cross_ok) if cross_ok is not None else None
+    shard_frames = [sum(lengths[i] for i in sh) for sh in shards]
+    frames = sum(lengths)
+    res = {"value": round(frames * steps / elapsed, 1), "unit": "poses/s", "ms_per_pass": round(elapsed / steps * 1e3, 3),
+           "passes": steps, "warmup_passes": warmup, "scaling": "strong",
+           "clips": n_clips, "frames": frames, "receptive_field": 243, "joints": 17,
+           "batch_sizes": sizes if world == 1 else None,
+           "world_size_observed": world if dist is None else dist.get_world_size(),
+           "backend": None if dist is None else dist.get_backend(),
+           "shard_frames": shard_frames,
+           "shard_imbalance": round(max(shard_frames) / (sum(shard_frames) / world), 4),   # max / mean frames per rank
+           "pass_ms_per_rank": [round(v, 3) for v in per_rank_pass_ms],                    # device time of each rank's own clips
+           "pass_ms_imbalance": round(max(per_rank_pass_ms) / (sum(per_rank_pass_ms) / world), 4),
+           "all_gather_ms": round(gather_ms, 3),
+           "all_gather": "ONE all_gather of %d x %d float64 per pass (%d bytes per rank after padding to the largest shard)"
+                         % (n_clips, evaluate.PARTIAL_COLS, max(max(counts), 1) * evaluate.PARTIAL_COLS * 8),
+           "cross_rank_rows_bit_equal": None if cross is None else bool(all(v == 1.0 for v in cross)),
+           "setup_s": round(setup_s, 2)}
+    if rank == 0:
+        assert allrows.shape[0] == n_clips and sorted(int(v) for v in allrows[:, 0].tolist()) == list(range(n_clips))
+        res["mpjpe_mm"] = eval_summary(allrows)       # action-wise averages + checksum: neither depends on the number of ranks
+        # every window is 251.7 MFLOP of the reference's arithmetic (SURVEY 8d), whatever the clip path shares between windows
+        res["algorithmic_tflops"] = round(frames * steps / elapsed * 251.7e6 / 1e12, 2)
+        res["frac_of_fp32_mfma_peak_all_gpus"] = round(res["algorithmic_tflops"] / (PEAK_FP32_MFMA_TFLOPS * world), 4)
+    res["_mine"] = mine
+    return res
+
+
 def self_launch(args):
     """--gpus N without a launcher: start N ranks through torch.distributed.run, forward their output."""
     n = torch.cuda.device_count()
@@ -519,6 +613,8 @@ def main():
     ap.add_argument("--no-shipped-cfgs", action="store_true", help="windows mode: skip the secondary cfg4 / cfg5 objects")
     ap.add_argument("--clips", type=int, default=EVAL_CLIPS, help="eval mode: number of clips in the set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eval-pass", action="store_true",
+                    help="windows mode under a process group: skip the secondary clip-sharded evaluation pass (`eval_pass`)")
     ap.add_argument("--no-b1024", action="store_true", help="windows mode: skip the roofline point at 1024 windows")
     ap.add_argument("--no-bf16x3", action="store_true", help="windows mode: skip the secondary bf16x3 (fp32-equivalent) measurement")
     ap.add_argument("--two-stream", action="store_true", help="also time Ray3DLifter.forward_overlapped (two half batches on two streams)")
@@ -632,6 +728,18 @@ def main():
         per_rank_ms = all_ranks(elapsed_own / args.steps * 1e3)
         parity_err = max_over_ranks(parity_err)
         assert torch.isfinite(out).all()
+        # With a process group (the driver's N > 1 command; any run under a launcher): north_star's multi-GPU split as a
+        # SECONDARY object of the same line - one strong-scaling pass set over the 240-clip evaluation shape, clips sharded
+        # over the ranks, ONE all_gather of the per-clip rows per pass.  The windows-mode `value` above has no collective on
+        # its data path; without this object an N-GPU run of this command would say nothing about clip sharding.
+        ev = None
+        if dist is not None and args.batch == BATCH and not args.no_eval_pass and lifter.precision(dev) == "f32":
+            try:
+                ev = eval_pass(lifter, dev, dist, world, rank, args.clips, 2, 1, barrier, max_over_ranks, all_ranks)
+                ev.pop("_mine")
+            except Exception as e:                          # noqa: BLE001 - reported in the line, never costs the headline
+                ev = {"error": "%s: %s" % (type(e).__name__, e)}
+                print("bench.py: eval_pass failed on rank %d: %r" % (rank, e), file=sys.stderr)
         if rank == 0:
             line.update({
                 "value": round(world * args.batch * args.steps / elapsed, 1),
@@ -695,67 +803,38 @@ def main():
                                               "note": "same work as `value`, issued as 2 half batches on 2 streams"}
             if world == 1 and args.half_chip_streams and lifter.precision(dev) == "f32":
                 guarded("two_stream_variant", lambda: half_chip_variant(dev, x, p, out, args.steps, args.warmup))
-            if world == 1 and not args.no_cpu_baseline:
+            if ev is not None:
+                ev["note"] = ("SECONDARY: BASELINE configs[2]'s shape on this run's process group - %d synthetic clips (%d frames) sharded over "
+                              "%d rank(s) as whole clips, in-kernel sliding windows, device metrics, one all_gather of the per-clip rows per "
+                              "pass; strong scaling (the set is fixed): compare `value` / `ms_per_pass` across N, `mpjpe_mm` must not change"
+                              % (ev.get("clips", 0), ev.get("frames", 0), world)) if "error" not in ev else ev.get("error")
+                line["eval_pass"] = ev
+            if not args.no_cpu_baseline:
+                # (rank 0 only, at every N: the reference's CPU path timed on this host beside the GPU numbers)
                 guarded("cpu_baseline", lambda: cpu_baseline(states, x_np, p_np))
             print(json.dumps(line))
     else:
         # ---- clip-sharded evaluation (configs[2]): whole clips per rank, resident in HBM, one all_gather per pass
-        part = eval_partition(args.clips, world)
-        lengths, cams, shards, aid = part["lengths"], part["cams"], part["shards"], part["aid"]
-        mine = []
-        for idx in shards[rank]:
-            c = make_clip(idx, lengths[idx], cams)
-            padded = torch.from_numpy(evaluate.pad_clip(c.rays, 121)).to(dev)
-            mine.append((c, padded, torch.from_numpy(c.camera.param()).to(dev), torch.from_numpy(c.gt_norm).to(dev)))
-        sizes = sorted(set(b for c, _, _, _ in mine for b in lifter.clip_batch_sizes(c.rays.shape[0])))
-        lifter.prepare(sizes, dev)
-        # the rank's per-clip rows: header columns (clip, action, frames) uploaded ONCE, error columns written on the device
-        local_rows = evaluate.partial_rows([(c.clip_id, aid[c.action], c.rays.shape[0]) for c, _, _, _ in mine], dev)
-        counts = [len(s) for s in shards]
-
-        def one_pass():
-            for k, (c, padded, prow, gt) in enumerate(mine):
-                evaluate.clip_partials_hip(lifter.forward_clip(padded, prow), c, aid[c.action], gt_dev=gt, out=local_rows[k])
-            return evaluate.gather_partials(local_rows, counts) if dist is not None else local_rows
-
-        with torch.no_grad():
-            one_pass()                          # first touch: workspace allocation
-            elapsed_own, dev_s, allrows = timed_steps(one_pass, args.steps, args.warmup, barrier, dev)
-            # this rank's own pass (its clips, no gather, device time): what the shard costs without waiting for the others
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(torch.cuda.current_stream(dev))
-            for k, (c, padded, prow, gt) in enumerate(mine):
-                evaluate.clip_partials_hip(lifter.forward_clip(padded, prow), c, aid[c.action], gt_dev=gt, out=local_rows[k])
-            e1.record(torch.cuda.current_stream(dev))
-            e1.synchronize()
-            own_pass_ms = e0.elapsed_time(e1)
-        elapsed = max_over_ranks(elapsed_own)
-        per_rank_pass_ms = all_ranks(own_pass_ms)
-        shard_frames = [sum(lengths[i] for i in sh) for sh in shards]
-        frames = sum(lengths)
+        ev = eval_pass(lifter, dev, dist, world, rank, args.clips, args.steps, args.warmup, barrier, max_over_ranks, all_ranks)
+        mine = ev.pop("_mine")
         if rank == 0:
-            assert allrows.shape[0] == args.clips and sorted(int(v) for v in allrows[:, 0].tolist()) == list(range(args.clips))
+            frames = ev["frames"]
             line.update({
-                "value": round(frames * args.steps / elapsed, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-                "scaling": "strong",
+                "value": ev["value"], "ms_per_step": ev["ms_per_pass"], "scaling": "strong",
                 "config": {"workload": "BASELINE configs[2] stand-in: %d synthetic clips of U(1000,6000) frames (%d frames), 17 joints, "
                                        "RF 243, whole clips sharded over the ranks longest-first, in-kernel sliding windows, device "
                                        "metrics, one RCCL all_gather of the per-clip partial rows per pass" % (args.clips, frames),
                            "clips": args.clips, "frames": frames, "receptive_field": 243, "joints": 17,
-                           "batch_sizes": sizes if world == 1 else None,
-                           "world_size_observed": world if dist is None else dist.get_world_size(),
-                           "shard_frames": shard_frames,
-                           "shard_imbalance": round(max(shard_frames) / (sum(shard_frames) / world), 4),   # max / mean frames per rank
-                           "pass_ms_per_rank": [round(v, 3) for v in per_rank_pass_ms],                    # device time of each rank's own clips
-                           "pass_ms_imbalance": round(max(per_rank_pass_ms) / (sum(per_rank_pass_ms) / world), 4),
-                           "parallelism": "clips sharded over %d rank(s); collective = all_gather of %d x %d float64"
-                                          % (world, args.clips, evaluate.PARTIAL_COLS)},
-                "mpjpe_mm": eval_summary(allrows)})
-            # the whole pass as a rate: every window is 251.7 MFLOP of the reference's arithmetic, whatever the
-            # clip path shares between windows - and the roofline of its dominant kernel on ONE full chunk of the first clip
-            flops_per_window = 251.7e6
-            line["algorithmic_tflops"] = round(frames * args.steps / elapsed * flops_per_window / 1e12, 2)
-            line["frac_of_fp32_mfma_peak"] = round(line["algorithmic_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
+                           "batch_sizes": ev["batch_sizes"],
+                           "world_size_observed": ev["world_size_observed"],
+                           "shard_frames": ev["shard_frames"], "shard_imbalance": ev["shard_imbalance"],
+                           "pass_ms_per_rank": ev["pass_ms_per_rank"], "pass_ms_imbalance": ev["pass_ms_imbalance"],
+                           "all_gather_ms": ev["all_gather_ms"], "cross_rank_rows_bit_equal": ev["cross_rank_rows_bit_equal"],
+                           "parallelism": "clips sharded over %d rank(s); collective = %s" % (world, ev["all_gather"])},
+                "mpjpe_mm": ev["mpjpe_mm"]})
+            # the whole pass as a rate - and the roofline of its dominant kernel on ONE full chunk of the first clip
+            line["algorithmic_tflops"] = ev["algorithmic_tflops"]
+            line["frac_of_fp32_mfma_peak"] = round(ev["algorithmic_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
             if world == 1 and mine and lifter.precision(dev) == "f32":
                 def _clip_roofline():
                     nb = lifter.CLIP_CHUNK

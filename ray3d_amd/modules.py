@@ -401,20 +401,30 @@ class Ray3DLifter(nn.Module):
             cur.wait_stream(s)
         return out
 
-    CLIP_CHUNK = 4096      # windows per forward in clip mode (0.89 of the fp32-MFMA peak at this size, 0.87 at 2048)
-    CLIP_ROUND = 128       # the last chunk is rounded up to a multiple of this many windows (0: exact sizes)
+    CLIP_CHUNK = 4096      # most windows per forward in clip mode (0.96 of the fp32-MFMA peak at this size, 0.87 at 1024)
+    CLIP_ROUND = 128       # call sizes are rounded up to a multiple of this many windows (0: exact sizes)
+    CLIP_BALANCED = True   # cut a long clip into near-equal calls (False: CLIP_CHUNK at a time + the rest, rounds 1-5)
 
     def clip_batch_sizes(self, n: int):
-        """Batch sizes of the forwards that lift an n-window clip: CLIP_CHUNK at a time, the rest rounded up to a
-        multiple of CLIP_ROUND - to 32 or 64 when it is that short - so that clips of any lengths share a handful of
-        tile schedules (the library builds and uploads one per batch size).  CLIP_ROUND = 0 lifts exact sizes."""
-        sizes = [self.CLIP_CHUNK] * (n // self.CLIP_CHUNK)
-        r = n % self.CLIP_CHUNK
-        if r:
-            if self.CLIP_ROUND <= 0:
+        """Batch sizes of the forwards that lift an n-window clip: ceil(n / CLIP_CHUNK) near-equal calls, each rounded up to a
+        multiple of CLIP_ROUND (a short clip: to 1, 2, 4 ... 64 when it is that short), so that clips of any lengths share a
+        handful of tile schedules (the library builds and uploads one per batch size) and no clip ends in a short,
+        inefficient rest call: a 5000-window clip is 2560 + 2560 (60 surplus windows), not 4096 + 1024 (120).  The sum
+        exceeds n by less than CLIP_ROUND.  CLIP_ROUND = 0 lifts exact sizes."""
+        chunk, rnd = self.CLIP_CHUNK, self.CLIP_ROUND
+        k = -(-n // chunk)
+        sizes = []
+        if k > 1:
+            each = -(-n // k) if self.CLIP_BALANCED else chunk
+            if rnd > 0:
+                each = min(chunk, -(-each // rnd) * rnd)
+            sizes = [each] * (k - 1)
+        r = n - sum(sizes)
+        if r > 0:
+            if rnd <= 0:
                 sizes.append(r)
             else:
-                up = -(-r // self.CLIP_ROUND) * self.CLIP_ROUND
+                up = -(-r // rnd) * rnd
                 # (short rests: the sizes whose schedules hold the GEMV / latency tiles of calls of a few windows - a
                 #  one-window rest lifted as 32 would do 2-30 times the work)
                 for small in (1, 2, 4, 8, 16, 32, 64):

@@ -903,25 +903,32 @@ def test_camera_augmentation_grid_matches_the_reference_script():
 
 
 def test_clip_batch_sizes_share_a_handful_of_schedules():
-    """Ray3DLifter.clip_batch_sizes: 4096-window chunks, the rest rounded up to a multiple of 128 - to 1, 2, 4 ... 64 when it
-    is that short (the GEMV / latency schedules of calls of a few windows) - so that clips of any length use at most 39
-    batch sizes; CLIP_ROUND = 0 lifts exact sizes."""
+    """Ray3DLifter.clip_batch_sizes: ceil(n / 4096) near-equal calls, each rounded up to a multiple of 128 - a short clip to
+    1, 2, 4 ... 64 when it is that short (the GEMV / latency schedules of calls of a few windows) - so that clips of any
+    length use at most 39 batch sizes and none ends in a short rest call; CLIP_ROUND = 0 lifts exact sizes; CLIP_BALANCED =
+    False is the chunking of rounds 1-5 (4096 at a time + the rest)."""
     mc = default_model_config(ARCHITECTURE="3,3")
     fac = ray3d_amd.Model(mc, {}, is_train=False)
     lifter = ray3d_amd.Ray3DLifter(fac.get_pos_model(), fac.get_trj_model())
     assert lifter.clip_batch_sizes(1) == [1] and lifter.clip_batch_sizes(3) == [4] and lifter.clip_batch_sizes(17) == [32]
     assert lifter.clip_batch_sizes(33) == [64] and lifter.clip_batch_sizes(65) == [128]
     assert lifter.clip_batch_sizes(128) == [128] and lifter.clip_batch_sizes(129) == [256]
-    assert lifter.clip_batch_sizes(4096) == [4096] and lifter.clip_batch_sizes(4097) == [4096, 1]
-    assert lifter.clip_batch_sizes(5000) == [4096, 1024] and lifter.clip_batch_sizes(9000) == [4096, 4096, 896]
+    assert lifter.clip_batch_sizes(4096) == [4096] and lifter.clip_batch_sizes(4097) == [2176, 2048]
+    assert lifter.clip_batch_sizes(5000) == [2560, 2560] and lifter.clip_batch_sizes(9000) == [3072, 3072, 2944]
+    assert lifter.clip_batch_sizes(8192) == [4096, 4096] and lifter.clip_batch_sizes(12288) == [4096] * 3
     seen = set()
     for n in range(1, 13000, 7):
         sizes = lifter.clip_batch_sizes(n)
         assert sum(sizes) >= n and sum(sizes) - n < 128
+        assert len(sizes) == -(-n // 4096) and max(sizes) <= 4096
+        assert len(sizes) == 1 or min(sizes) >= max(sizes) - 128 * (len(sizes) - 1)     # near-equal: no short rest call
         seen.update(sizes)
     assert len(seen) <= 39
     lifter.CLIP_ROUND = 0
-    assert lifter.clip_batch_sizes(5000) == [4096, 904]
+    assert lifter.clip_batch_sizes(5000) == [2500, 2500] and lifter.clip_batch_sizes(4097) == [2049, 2048]
+    lifter.CLIP_ROUND, lifter.CLIP_BALANCED = 128, False
+    assert lifter.clip_batch_sizes(4097) == [4096, 1] and lifter.clip_batch_sizes(5000) == [4096, 1024]
+    assert lifter.clip_batch_sizes(9000) == [4096, 4096, 896]
 
 
 # ------------------------------------------------------------------ profile tooling
