@@ -157,19 +157,22 @@ def settle_clocks(fn, dev, group=10, max_groups=60, tol=0.01):
 def timed_steps(fn, steps, warmup, barrier, dev):
     """W untimed + exactly K timed steps between barriers; host wall time and the device time between two HIP events
     recorded on the launch stream around the same K steps."""
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    on_gpu = torch.device(dev).type == "cuda"          # (the clip-sharded pass's host logic is also run on CPU ranks over gloo: tests/test_host.py)
+    e0, e1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if on_gpu else (None, None)
     out = None
     for _ in range(warmup):
         out = fn()
     barrier()
     t0 = time.perf_counter()
-    e0.record(torch.cuda.current_stream(dev))
+    if on_gpu:
+        e0.record(torch.cuda.current_stream(dev))
     for _ in range(steps):
         out = fn()
-    e1.record(torch.cuda.current_stream(dev))
+    if on_gpu:
+        e1.record(torch.cuda.current_stream(dev))
     barrier()
     elapsed = time.perf_counter() - t0
-    return elapsed, e0.elapsed_time(e1) * 1e-3, out
+    return elapsed, (e0.elapsed_time(e1) * 1e-3 if on_gpu else elapsed), out
 
 
 def pmc_figures(key, kernel):
@@ -497,62 +500,90 @@ def eval_summary(allrows):
             "checksum": float(allrows[allrows[:, 0].argsort()][:, 3].sum().item())}
 
 
-def eval_pass(lifter, dev, dist, world, rank, n_clips, steps, warmup, barrier, max_over_ranks, all_ranks, cross_check=True):
+def eval_pass(lifter, dev, dist, world, rank, n_clips, steps, warmup, barrier, max_over_ranks, all_ranks, cross_check=True,
+              length_div=1, lift=None):
     """BASELINE configs[2] / north_star's multi-GPU split on this process group: the synthetic clip set sharded over the ranks as
     whole clips (longest first), every clip lifted with in-kernel sliding windows and reduced to one row on the device, ONE
     all_gather of the rows per pass (lib/train_val/trainer.py:399-403,473-477 reduce them per action).  Strong scaling: the
     set is fixed.  Returns (on every rank) a dict; the fields that need the gathered rows are complete on rank 0.
     `cross_check`: every rank also lifts the first clip of the NEXT rank's shard, and the row it computes must equal the
-    gathered one bit for bit - what a clip's row is does not depend on which rank (or how many ranks) lifted it."""
+    gathered one bit for bit - what a clip's row is does not depend on which rank (or how many ranks) lifted it.
+    `lift(clip, out_row)` replaces the HIP path (forward_clip + r3d_clip_metrics) and `length_div` shortens the clips: the CPU
+    test of this function's own sharding / rows / gather / cross-check / summary logic (tests/test_host.py, world size 8 over gloo)."""
     from ray3d_amd import evaluate
-    part = eval_partition(n_clips, world)
+    dev = torch.device(dev)
+    on_gpu = dev.type == "cuda"
+    part = eval_partition(n_clips, world, length_div=length_div)
     lengths, cams, shards, aid = part["lengths"], part["cams"], part["shards"], part["aid"]
 
     def resident(idx):
         c = make_clip(idx, lengths[idx], cams)
+        if lift is not None:
+            return (c, None, None, None)
         padded = torch.from_numpy(evaluate.pad_clip(c.rays, 121)).to(dev)
         return (c, padded, torch.from_numpy(c.camera.param()).to(dev), torch.from_numpy(c.gt_norm).to(dev))
 
+    def lift_row(item, out_row):
+        c, padded, prow, gt = item
+        if lift is not None:
+            lift(c, out_row)
+        else:
+            evaluate.clip_partials_hip(lifter.forward_clip(padded, prow), c, aid[c.action], gt_dev=gt, out=out_row)
+
     t0 = time.perf_counter()
     mine = [resident(idx) for idx in shards[rank]]
-    sizes = sorted(set(b for c, _, _, _ in mine for b in lifter.clip_batch_sizes(c.rays.shape[0])))
-    lifter.prepare(sizes, dev)
+    sizes = None
+    if lift is None:
+        sizes = sorted(set(b for c, _, _, _ in mine for b in lifter.clip_batch_sizes(c.rays.shape[0])))
+        lifter.prepare(sizes, dev)
     setup_s = time.perf_counter() - t0
     # the rank's per-clip rows: header columns (clip, action, frames) uploaded ONCE, error columns written on the device
     local_rows = evaluate.partial_rows([(c.clip_id, aid[c.action], c.rays.shape[0]) for c, _, _, _ in mine], dev)
     counts = [len(s_) for s_ in shards]
 
     def lift_mine():
-        for k, (c, padded, prow, gt) in enumerate(mine):
-            evaluate.clip_partials_hip(lifter.forward_clip(padded, prow), c, aid[c.action], gt_dev=gt, out=local_rows[k])
+        for k, item in enumerate(mine):
+            lift_row(item, local_rows[k])
 
     def one_pass():
         lift_mine()
         return evaluate.gather_partials(local_rows, counts) if dist is not None else local_rows
 
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
+
     with torch.no_grad():
         one_pass()                          # first touch: workspace allocation
         elapsed_own, dev_s, allrows = timed_steps(one_pass, steps, warmup, barrier, dev)
-        # this rank's own pass (its clips, no gather, device time): what the shard costs without waiting for the others
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        # this rank's own pass (its clips, no gather): what the shard costs without waiting for the others
         barrier()
-        e0.record(torch.cuda.current_stream(dev))
+        t1 = time.perf_counter()
+        if on_gpu:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(dev))
         lift_mine()
-        e1.record(torch.cuda.current_stream(dev))
+        if on_gpu:
+            e1.record(torch.cuda.current_stream(dev))
+            e1.synchronize()
+            own_pass_ms = e0.elapsed_time(e1)             # device time
+        else:
+            own_pass_ms = (time.perf_counter() - t1) * 1e3
         # ... and the single exchange step by itself, behind a barrier (host wall clock: the collective runs on RCCL's stream)
         barrier()
         tg = time.perf_counter()
         if dist is not None:
             evaluate.gather_partials(local_rows, counts)
-        torch.cuda.synchronize()
+        sync()
         gather_ms = (time.perf_counter() - tg) * 1e3
-        own_pass_ms = e0.elapsed_time(e1)
         cross_ok = None
         if cross_check and world > 1 and shards[(rank + 1) % world]:
             idx = shards[(rank + 1) % world][0]
-            c, padded, prow, gt = resident(idx)
+            item = resident(idx)
+            c = item[0]
             row = evaluate.partial_rows([(c.clip_id, aid[c.action], c.rays.shape[0])], dev)
-            evaluate.clip_partials_hip(lifter.forward_clip(padded, prow), c, aid[c.action], gt_dev=gt, out=row[0])
+            lift_row(item, row[0])
+            sync()
             theirs = allrows[allrows[:, 0] == float(idx)]
             cross_ok = float(theirs.shape[0] == 1 and bool(torch.equal(theirs[0], row[0])))
     elapsed = max_over_ranks(elapsed_own)

@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libray3d_hip.so")
 # The hooks build (the same sources with -DR3D_TEST_HOOKS): the r3d_debug_* exports and the development switches read from
 # the environment.  tests/ and tools/ select it with use_hooks(True); nothing in this package does.
-HOOKS_LIB_PATH = os.path.join(_HERE, "libray3d_hip_hooks.so")
+# (R3D_HOOKS_LIB: another build of the hooks library, e.g. libray3d_hip_san.so - `make -C ray3d_amd/csrc san`: host objects under ASan / UBSan)
+HOOKS_LIB_PATH = os.environ.get("R3D_HOOKS_LIB") or os.path.join(_HERE, "libray3d_hip_hooks.so")
 
 R3D_KIND_POS, R3D_KIND_TRJ = 0, 1
 R3D_INPUT_RAYS, R3D_INPUT_UV = 0, 1

@@ -195,6 +195,12 @@ int fill_prob(const Plan *pl, const ProbSpec &q, int64_t B, const Model *a, cons
         tg[13] = tg[14] = TA;
         g.K3 = L3.Kpad;
         g.slope3 = L3.slope;
+        // the register-chained form of the same three layers (r3d_chain.hpp): gathered rays, fp32 tiles (R3D_NO_CHAIN=1, hooks build: off)
+        if (L.chain_off != 0 && L.chain_l1 == q.layer2 && L.chain_l2 == q.layer3 && !cs.uv && !cs.shared && g.lut != nullptr &&
+            !hook_on("R3D_NO_CHAIN")) {
+            g.wchain = arena_ptr(L.chain_off);
+            tg[18] = TA;
+        }
     }
     if (tags) memcpy(tags, tg, sizeof tg);
     return R3D_OK;

@@ -69,6 +69,9 @@ struct GemmProb {
     // ray = ((u-cx)/fx, c*y+s, -s*y+c), y = (v-cy)/fy, in float64 then cast (lib/camera/camera.py:423-471).
     const double *cam;        // rows {fx, fy, cx, cy, cos(pitch), sin(pitch), 0, 0}
     long long cam_stride;     // doubles between consecutive windows' rows (0: one camera for all)
+    // --- the fused first level again as a register-chained tile (wchain != nullptr; r3d_chain.hpp): the three layers' weights as
+    // ONE stream of 16 KiB slabs in the order the tile multiplies them (r3d_model.cpp, pack_chain) ---
+    const float *wchain;
 };
 
 // Kernel argument of one persistent GEMM launch.  `tiles`/`wg_off` live in HBM (built once per
@@ -109,7 +112,7 @@ struct FwdArgs {
     long long *dbg;
 };
 enum { FWD_KERNEL_F32 = 0, FWD_KERNEL_B3 = 1, FWD_KERNEL_LAT = 2, FWD_KERNEL_CLIP = 3, FWD_KERNEL_COUNT = 4 };   // specialisations of the single-launch forward
-constexpr int BIND_NPTR = 18;  // pointer fields of a GemmProb, in the order r3d_bind_f32 walks them
+constexpr int BIND_NPTR = 19;  // pointer fields of a GemmProb, in the order r3d_bind_f32 walks them
 enum { BIND_NULL = 0, BIND_WS, BIND_ARENA0, BIND_ARENA1, BIND_IARENA0, BIND_IARENA1, BIND_X, BIND_PARAM, BIND_CAM, BIND_NBASE };
 struct BindArgs {
     const GemmProb *rel;           // problems with byte OFFSETS in their pointer fields
@@ -214,6 +217,10 @@ struct Layer {
     // (shared_split = first current-frame column of the source layer), linear (slope 1), bias in E.
     int shared_of = -1;
     int shared_split = 0;
+    // expand_conv of a TemporalBlock whose fused first level can run as the register-chained tile (256 channels, K0 = 64):
+    // offset (floats) of the three layers' slab stream in the arena, (K0 / 16 + 64) slabs of 4096 floats; 0: none
+    size_t chain_off = 0;
+    int chain_l1 = -1, chain_l2 = -1;   // the level's 3-tap and 1x1 layers
 };
 
 struct Model {
@@ -463,6 +470,16 @@ int device_cu_count();
 
 // kernel launchers (r3d_kernels.hip)
 enum { STAGE_BIG = 0, STAGE_ENC = 1 };   // r3d_gemm_f32 / r3d_gemm_enc_f32
+// the kernels live in one translation unit per family (r3d_k_*.hip, compiled side by side); each exports its entry points
+typedef void (*GemmKernel)(const LaunchArgs);
+typedef void (*FwdKernel)(const FwdArgs);
+GemmKernel gemm_kernel_f32(bool uv);      // r3d_gemm_f32 / r3d_gemm_uv_f32             (r3d_k_gemm.hip)
+GemmKernel gemm_kernel_enc(bool uv);      // r3d_gemm_enc_f32 / r3d_gemm_enc_uv_f32     (r3d_k_gemm_enc.hip)
+GemmKernel gemm_kernel_b3(bool uv);       // r3d_gemm_b3 / r3d_gemm_uv_b3               (r3d_k_gemm_b3.hip)
+FwdKernel fwd_kernel_f32(bool uv);        // r3d_forward_f32 / r3d_forward_uv_f32       (r3d_k_fwd_f32.hip)
+FwdKernel fwd_kernel_b3(bool uv);         // r3d_forward_b3 / r3d_forward_uv_b3         (r3d_k_fwd_b3.hip)
+FwdKernel fwd_kernel_lat(bool uv);        // r3d_forward_lat / r3d_forward_uv_lat       (r3d_k_fwd_lat.hip)
+FwdKernel fwd_kernel_clip(bool uv);       // r3d_forward_clip_f32 / _clip_uv_f32        (r3d_k_fwd_clip.hip)
 hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, int kind, bool uv, hipStream_t stream);   // uv: the launch gathers pixel keypoints
 hipError_t launch_decode(const DecodeArgs &args, hipStream_t stream);
 hipError_t launch_forward(const FwdArgs &args, int nwg, int kind, bool uv, hipStream_t stream);

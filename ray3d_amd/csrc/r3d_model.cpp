@@ -107,6 +107,9 @@ struct Grammar {
             const int la = layer(p + ".layers_conv." + a, m->cfg.dense ? 2 * dil + 1 : 3, C, C, false, p + ".layers_bn." + a, 0.2f, true);
             const int lb = layer(p + ".layers_conv." + b, 1, C, C, false, p + ".layers_bn." + b, 0.2f, true);
             m->layers[la].bf3_conv = m->layers[lb].bf3_conv = fl_b3;   // (level 1: in the fused first level; further levels: fused pairs)
+            // the register-chained first-level tile (r3d_chain.hpp): 256 channels, an operand of 64 gathered columns, strided 3-tap level
+            // (whether the gathered operand is 64 columns wide is known once the first layers are folded: model_finalize)
+            if (i == 1 && C == 256 && !m->cfg.dense) { m->layers[le].chain_l1 = la; m->layers[le].chain_l2 = lb; }
         }
         layer(p + ".shrink", 1, C, m->cfg.latent, true, "", 1.0f, true);
     }
@@ -397,6 +400,12 @@ int model_finalize(Model *m) {
             L.wb3_off = off;
             off += (size_t)L.Npad * L.Kpad;
         }
+        L.chain_off = 0;
+        if (L.chain_l1 >= 0 && L.Kpad == 64 && !L.colmap.empty()) {
+            off = (off + 255) / 256 * 256;                 // 1 KiB aligned slabs
+            L.chain_off = off;
+            off += (size_t)(L.Kpad / 16 + 64) * 4096;
+        }
     }
     m->arena.assign(off, 0.0f);
     Folder f{m};
@@ -493,6 +502,39 @@ int model_finalize(Model *m) {
                     pk[((((size_t)(nb * nk + kt) * 2 + h) * 2 + j) * 64 + lane) * 4 + e] = v;
                 }
         }
+    }
+    // ---- the fused first levels once more as slab streams of the register-chained tile (r3d_chain.hpp).  A slab is 16 fragments of
+    // 1 KiB [half group hg][fragment f][lane][element e]; lane l = (channel l & 15 of the fragment's block, feature quarter
+    // gq = l >> 4).  WIDE slab m of a layer: output channel 16 (4 hg + f) + (l & 15), K step 4 m + e; NARROW slab m of output group G:
+    // output channel 16 (4 G + f) + (l & 15), K step 16 m + 4 hg + e.  The feature a K step takes from lane quarter gq: gathered
+    // layer (expand_conv): operand column 4 step + gq (the four lanes of a row gather four consecutive columns); chained layers: channel 16 (step >> 2) + 4 gq + (step & 3) - register
+    // step & 3 of channel block step >> 2 of the previous layer's accumulators.  Stream: expand_conv (K0 / 16 slabs), the three taps
+    // of the 3-tap convolution in the order the tile visits them (residual tap last; 16 slabs each), the 1x1 convolution (4 groups
+    // x 4 slabs).  Values are read back from the fragment-ordered copies, which hold the folded (and column-mapped) weights.
+    for (auto &L : m->layers) {
+        if (L.chain_off == 0) continue;
+        const Layer &L1 = m->layers[L.chain_l1], &L2 = m->layers[L.chain_l2];
+        const int C = L.N, K0 = L.Kpad, sl_exp = K0 / 16;
+        const float *w0 = m->arena.data() + L.w_off, *w1 = m->arena.data() + L1.w_off, *w2 = m->arena.data() + L2.w_off;
+        const int nk0 = L.Kpad / BK, nk1 = L1.Kpad / BK, nk2 = L2.Kpad / BK;
+        float *img = m->arena.data() + L.chain_off;
+        auto chained = [](int step, int gq) { return 16 * (step >> 2) + 4 * gq + (step & 3); };
+        auto put = [&](int slab, int hg, int f, int l, int e, float v) { img[(size_t)slab * 4096 + ((hg * 4 + f) * 64 + l) * 4 + e] = v; };
+        const int res_tap = 1 + (m->cfg.causal ? 1 : 0);
+        const int order[3] = {0, 3 - res_tap, res_tap};
+        for (int hg = 0; hg < 4; ++hg)
+            for (int f = 0; f < 4; ++f)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 4; ++e) {
+                        const int o = 16 * (4 * hg + f) + (l & 15), gq = l >> 4;
+                        for (int ms = 0; ms < sl_exp; ++ms) put(ms, hg, f, l, e, w0[frag_index(o, 4 * (4 * ms + e) + gq, nk0)]);
+                        for (int ts = 0; ts < 3; ++ts)
+                            for (int ms = 0; ms < 16; ++ms)
+                                put(sl_exp + ts * 16 + ms, hg, f, l, e, w1[frag_index(o, order[ts] * C + chained(4 * ms + e, gq), nk1)]);
+                        for (int G = 0; G < 4; ++G)
+                            for (int ms = 0; ms < 4; ++ms)
+                                put(sl_exp + 48 + G * 4 + ms, hg, f, l, e, w2[frag_index(16 * (4 * G + f) + (l & 15), chained(16 * ms + 4 * hg + e, gq), nk2)]);
+                    }
     }
     // ---- upload
     int dev = 0;

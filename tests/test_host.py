@@ -379,6 +379,14 @@ def _gloo_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _free_port():
+    """A TCP port nobody listens on right now (a fixed port derived from the pid can collide between parallel test runs)."""
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
 def test_two_rank_gather_matches_single_process():
     import torch.multiprocessing as mp
     _, clips = _evalcore_clips()
@@ -386,7 +394,7 @@ def test_two_rank_gather_matches_single_process():
     named1, avg1, rows1 = evaluate.evaluate_clips(_oracle_lift_clip(), clips, 27, "cpu")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -445,7 +453,7 @@ def test_bench_eval_sharding_and_gather_at_world_size_8_matches_world_size_1():
     assert sorted(len(s) for s in bench.eval_partition(n_clips, 8)["shards"]) == [30] * 8
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_gloo_eval_worker, args=(r, 8, port, q, n_clips, div)) for r in range(8)]
     for p in procs:
         p.start()
@@ -460,6 +468,69 @@ def test_bench_eval_sharding_and_gather_at_world_size_8_matches_world_size_1():
             # the per-clip sums are computed by the same code on the same data whatever the rank; only the row ORDER of the
             # gathered matrix differs, and the summary sorts / groups before it adds
             assert abs(got[k] - want[k]) <= 1e-9 * max(1.0, abs(want[k])), (rank, k, got[k], want[k])
+
+
+def _gloo_eval_pass_worker(rank, world, port, q, n_clips, length_div):
+    import torch.distributed as dist
+    import bench
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+
+        def max_over_ranks(v):
+            t = torch.tensor([v], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        def all_ranks(v):
+            t = torch.tensor([v], dtype=torch.float64)
+            bucket = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(bucket, t)
+            return [float(b.item()) for b in bucket]
+
+        def lift(c, out_row):
+            out_row[3:8] = evaluate.clip_partials(_standin_pred(c), c, 0)[3:8]
+
+        res = bench.eval_pass(None, "cpu", dist, world, rank, n_clips, 1, 0, dist.barrier, max_over_ranks, all_ranks,
+                              length_div=length_div, lift=lift)
+        res.pop("_mine")
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_eval_pass_object_at_world_size_8_over_gloo():
+    """bench.eval_pass - the object the driver's `bench.py --gpus N` line carries under a process group (north_star's split:
+    whole clips sharded over the ranks, ONE all_gather of the per-clip rows) - run as the bench runs it, on eight CPU ranks
+    over gloo with a stand-in for the lifted poses: the gathered MPJPE / checksum equal the single-process values, every
+    rank's re-lift of a neighbour's clip equals the gathered row bit for bit, and the line's fields are there."""
+    import torch.multiprocessing as mp
+    import bench
+    n_clips, div, world = 240, 40, 8
+    rows1, part1 = _bench_eval_rows(1, 0, n_clips, div, lambda local, counts: local)
+    want = bench.eval_summary(rows1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_eval_pass_worker, args=(r, world, port, q, n_clips, div)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    r0 = res[0]
+    for k in ("value", "ms_per_pass", "shard_frames", "shard_imbalance", "pass_ms_per_rank", "pass_ms_imbalance", "all_gather_ms",
+              "world_size_observed", "cross_rank_rows_bit_equal", "mpjpe_mm", "frames", "clips"):
+        assert k in r0, k
+    assert r0["world_size_observed"] == world and r0["backend"] == "gloo" and r0["scaling"] == "strong"
+    assert len(r0["shard_frames"]) == world and sum(r0["shard_frames"]) == r0["frames"] == sum(part1["lengths"])
+    assert len(r0["pass_ms_per_rank"]) == world and r0["pass_ms_imbalance"] >= 1.0
+    assert all(res[r]["cross_rank_rows_bit_equal"] is True for r in range(world))
+    for k in want:
+        assert abs(r0["mpjpe_mm"][k] - want[k]) <= 1e-9 * max(1.0, abs(want[k])), (k, r0["mpjpe_mm"][k], want[k])
+    assert "mpjpe_mm" not in res[3]                      # (the gathered summary is rank 0's to print)
 
 
 def test_partial_rows_header_is_uploaded_once_and_kept():
@@ -929,6 +1000,42 @@ def test_clip_batch_sizes_share_a_handful_of_schedules():
     lifter.CLIP_ROUND, lifter.CLIP_BALANCED = 128, False
     assert lifter.clip_batch_sizes(4097) == [4096, 1] and lifter.clip_batch_sizes(5000) == [4096, 1024]
     assert lifter.clip_batch_sizes(9000) == [4096, 4096, 896]
+
+
+# ------------------------------------------------------------------ sanitizers on the host code
+
+def test_host_schedule_plan_and_model_code_under_asan_and_ubsan():
+    """SURVEY section 5 promised sanitizers on the host code: `make -C ray3d_amd/csrc san` builds the hooks library with its four
+    host objects (weight packing, plans, tile schedules, the C ABI: ~3000 lines of index arithmetic) under
+    -fsanitize=address,undefined, and the host-side schedule / plan / dependency-machine / model tests of this file run
+    against it in a subprocess (the ASan runtime has to be the first library loaded: LD_PRELOAD).  Any report fails the run
+    (halt_on_error; UBSan does not recover).  Skipped when hipcc or the ASan runtime are absent (the GPU box has both)."""
+    import glob
+    import shutil
+    import subprocess
+    import sys
+    hipcc = "/opt/rocm/bin/hipcc"
+    rts = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not os.path.exists(hipcc) or not rts or shutil.which("make") is None:
+        pytest.skip("hipcc / the ASan runtime / make are not here")
+    csrc = os.path.join(ROOT, "ray3d_amd", "csrc")
+    if not all(os.path.exists(os.path.join(csrc, "build", f)) for f in ("r3d_kernels.o", "r3d_k_fwd_f32.o")):
+        pytest.skip("the device objects have not been built yet (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run(["make", "-C", csrc, "san", "ARCH=gfx950"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    san = os.path.join(ROOT, "ray3d_amd", "libray3d_hip_san.so")
+    env = dict(os.environ, R3D_HOOKS_LIB=san, LD_PRELOAD=rts[-1],
+               ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0:exitcode=66",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1:exitcode=67")
+    sel = ("schedule or plan or forward_check or dependency or single_launch or narrow or tiles or workspace or pairs or grammar or "
+           "set_weight or create_rejects or before_finalize")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_host.py"), "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "(%s) and not asan" % sel], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    out = r.stdout + r.stderr
+    assert "AddressSanitizer" not in out and "runtime error:" not in out, out[-4000:]
+    assert r.returncode == 0, out[-4000:]
+    m = __import__("re").search(r"(\d+) passed", out)
+    assert m and int(m.group(1)) >= 9, out[-2000:]       # (the selection really ran the host-side tests)
 
 
 # ------------------------------------------------------------------ profile tooling

@@ -5,7 +5,7 @@
 #   build (here, no GPU needed):   bash tools/b3_split_bound.sh build
 #   measure (through gpurun):      bash tools/b3_split_bound.sh run  > gpurun_out/b3_split_bound.txt
 cd "$(dirname "$0")/.."
-SRC="ray3d_amd/csrc/r3d_kernels.hip ray3d_amd/csrc/r3d_metrics.hip ray3d_amd/csrc/r3d_model.cpp ray3d_amd/csrc/r3d_plan.cpp ray3d_amd/csrc/r3d_schedule.cpp ray3d_amd/csrc/r3d_api.cpp"
+SRC="ray3d_amd/csrc/r3d_kernels.hip ray3d_amd/csrc/r3d_k_gemm.hip ray3d_amd/csrc/r3d_k_gemm_enc.hip ray3d_amd/csrc/r3d_k_gemm_b3.hip ray3d_amd/csrc/r3d_k_fwd_f32.hip ray3d_amd/csrc/r3d_k_fwd_b3.hip ray3d_amd/csrc/r3d_k_fwd_lat.hip ray3d_amd/csrc/r3d_k_fwd_clip.hip ray3d_amd/csrc/r3d_metrics.hip ray3d_amd/csrc/r3d_model.cpp ray3d_amd/csrc/r3d_plan.cpp ray3d_amd/csrc/r3d_schedule.cpp ray3d_amd/csrc/r3d_api.cpp"
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Iray3d_amd/csrc -Wno-unused-result -x hip -shared"
 if [ "$1" = build ]; then
   /opt/rocm/bin/hipcc $F -DR3D_EXP_NOSPLIT_W -o tools/libray3d_hip_exp_w.so $SRC &
