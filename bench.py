@@ -356,6 +356,41 @@ def half_chip_variant(dev, x, p, out_ref, steps, warmup):
                     "handles, R3D_OPT_CU_LIMIT); throughput of back-to-back independent batches - not the headline's step" % B}
 
 
+def c1024_line(dev, steps, warmup, barrier, batches=(256,)):
+    """SURVEY 8 f4 / lib/model/rie.py:14: TemporalBlock's class default is channels = 1024 (no shipped cfg uses it: every cfg file
+    sets 256).  Such models run the LEVEL-BY-LEVEL form - the single persistent launch holds tiles of at most 256 channels - so
+    this object carries what that form costs: poses/s, the roofline of its dominant kernel (r3d_gemm_f32, twelve launches per
+    step), and the gaps between its launches (step time minus the sum of the kernels' own times)."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    lifter, states = build(dev, CHANNELS=1024)
+    cfg = states["pos"][0]
+    res = {"workload": "J 17, RF 243, CHANNELS = 1024 (the reference's class default, rie.py:14), latent 256, stage 3, pos + trj; "
+                       "level-by-level form (models of more than 256 channels do not run as one persistent launch)",
+           "params_M": round(sum(float(np.asarray(v).size) for st in (states["pos"][1], states["trj"][1]) for v in st.values()) / 1e6, 1),
+           "parity": "tests/test_gpu_parity.py::test_other_widths_match_oracle (C = 512 / 1024 against the oracle at the literal 1e-4 bound)"}
+    with torch.no_grad():
+        for B in batches:
+            x = torch.from_numpy(synth.synth_rays(B, cfg, seed=100)).to(dev)
+            p = torch.from_numpy(synth.synth_param(B, seed=0, vary=False)).to(dev)
+            lifter.prepare([B], dev)
+            run = lambda: lifter(x, p)
+            assert torch.isfinite(run()).all()
+            settle_clocks(run, dev, group=5, max_groups=20)
+            el, dev_s, _ = timed_steps(run, steps, warmup, barrier, dev)
+            rl = roofline(lifter, x, p, dev_s / steps * 1e3, batch=B, key="c1024_b%d" % B)
+            kern = sum(rl["kernels_us_per_step"].values())
+            res["b%d" % B] = {"value": round(B * steps / el, 1), "unit": "poses/s", "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
+                              "roofline": rl,
+                              "launches_per_step": sum(1 for _ in lifter.profile_call(run, dev)) - 1,
+                              # bracketed launches scaled to the step: what is left of the step is launch gaps (scale_to_step < 1 means the
+                              # bracketed kernels alone already exceed the free-running step: no gap can be read off then)
+                              "kernels_us_per_step_sum": round(kern, 1),
+                              "gaps_us_per_step": round(max(rl["step_us"] - kern, 0.0), 1) if rl["scale_to_step"] >= 1.0 else None}
+    del lifter
+    return res
+
+
 def parity_gate(lifter, dev, batch):
     """no timing counts before parity.  The reference's own outputs for the weights this bench
     builds (seeds 1 / 2, decoder scale 1: tests/golden/model_j17_rf243_s3.npz, written by the reference's PyTorch-CPU
@@ -647,10 +682,12 @@ def main():
     ap.add_argument("--no-eval-pass", action="store_true",
                     help="windows mode under a process group: skip the secondary clip-sharded evaluation pass (`eval_pass`)")
     ap.add_argument("--no-b1024", action="store_true", help="windows mode: skip the roofline point at 1024 windows")
+    ap.add_argument("--no-c1024", action="store_true", help="windows mode: skip the secondary object of the 1024-channel model (level-by-level form)")
+    ap.add_argument("--c1024", action="store_true", help="only the 1024-channel object, at 64 and 256 windows, as its own JSON line (profile recipes)")
     ap.add_argument("--no-bf16x3", action="store_true", help="windows mode: skip the secondary bf16x3 (fp32-equivalent) measurement")
     ap.add_argument("--two-stream", action="store_true", help="also time Ray3DLifter.forward_overlapped (two half batches on two streams)")
     ap.add_argument("--half-chip-streams", action="store_true",
-                    help="also time two independent forwards side by side on two CU-masked streams of 128 CUs (secondary object `two_stream_variant`)")
+                    help="also time two independent forwards side by side on two CU-masked streams of 128 CUs (secondary object `half_chip_streams_variant`; `two_stream_variant` keeps its round-4 meaning: --two-stream)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 50 if args.mode == "windows" else 3
@@ -721,6 +758,17 @@ def main():
                            "ms_per_step_per_rank": per_rank},
                 "roofline": res["roofline"], "rays_mode": res.get("rays_mode"), "uv_vs_rays_ms_delta": res.get("uv_vs_rays_ms_delta"),
                 "uv_equals_rays_mode": res.get("uv_equals_rays_mode")}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if args.mode == "windows" and args.c1024:
+        res = c1024_line(dev, args.steps, args.warmup, barrier, batches=(64, 256))
+        if rank == 0:
+            print(json.dumps({"metric": "lifted poses/sec (17-joint, 243-frame window, CHANNELS 1024)", "unit": "poses/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None, "dtype": "f32",
+                              "data": "synthetic", "scaling": "weak", "value": res["b256"]["value"], "ms_per_step": res["b256"]["ms_per_step"],
+                              "config": {"workload": res["workload"], "batch_per_gpu": 256}, "roofline": res["b256"]["roofline"], "c1024": res}))
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -821,6 +869,9 @@ def main():
                 guarded("cfg4", lambda: {"rf9": uv_workload("cfg4_rf9", dev, 1, 0, nsh, 3, barrier),
                                          "rf243": uv_workload("cfg4_rf243", dev, 1, 0, max(nsh // 2, 5), 2, barrier)})
                 guarded("cfg5", lambda: uv_workload("cfg5", dev, 1, 0, nsh, 3, barrier))
+            if world == 1 and args.batch == BATCH and not args.no_c1024:
+                # the reference's class-default width (1024 channels): the level-by-level form's cost, with its roofline
+                guarded("c1024", lambda: c1024_line(dev, max(args.steps // 4, 5), 2, barrier))
             if world == 1 and not args.no_bf16x3 and lifter.precision(dev) == "f32":
                 # secondary line: the same workload with r3d_config.bf16x3 = 1 - every big GEMM on the bf16 matrix cores with exact
                 # three-term splits of both operands (fp32-equivalent results: tests/test_gpu_parity.py holds it to the
@@ -829,11 +880,11 @@ def main():
             if world == 1 and args.two_stream:
                 with torch.no_grad():
                     el2, _, _ = timed_steps(lambda: lifter.forward_overlapped(x, p), args.steps, args.warmup, barrier, dev)
-                line["two_half_batches_variant"] = {"value": round(args.batch * args.steps / el2, 1), "unit": "poses/s",
+                line["two_stream_variant"] = {"value": round(args.batch * args.steps / el2, 1), "unit": "poses/s",
                                               "ms_per_step": round(el2 / args.steps * 1e3, 4),
                                               "note": "same work as `value`, issued as 2 half batches on 2 streams"}
             if world == 1 and args.half_chip_streams and lifter.precision(dev) == "f32":
-                guarded("two_stream_variant", lambda: half_chip_variant(dev, x, p, out, args.steps, args.warmup))
+                guarded("half_chip_streams_variant", lambda: half_chip_variant(dev, x, p, out, args.steps, args.warmup))
             if ev is not None:
                 ev["note"] = ("SECONDARY: BASELINE configs[2]'s shape on this run's process group - %d synthetic clips (%d frames) sharded over "
                               "%d rank(s) as whole clips, in-kernel sliding windows, device metrics, one all_gather of the per-clip rows per "

@@ -177,11 +177,21 @@ int r3d_status(r3d_model *m, void *hip_stream);
 #define R3D_OPT_SPIN_TIMEOUT_MS 2 /* how long a tile of the single-launch forward waits for its producers before the
                                    * forward gives up (default 1000)                                                    */
 #define R3D_OPT_CU_LIMIT 3        /* value = n > 0: this handle's forwards are launched on a CU-masked stream that can use n CUs
-                                   * (hipExtStreamCreateWithCUMask): the single-launch forward uses at most n workgroups, and
-                                   * it is NOT ordered against single-launch forwards of other streams - the caller guarantees
-                                   * that streams used concurrently have DISJOINT masks of at least n CUs each (two half-chip
-                                   * forwards side by side: DESIGN.md 5.2).  0 (default): the whole device.  Drops the
-                                   * handle's cached tile schedules; for a pair set it on both handles.                      */
+                                   * (hipExtStreamCreateWithCUMask): the single-launch forward uses at most n workgroups and is
+                                   * NOT ordered against masked forwards of OTHER streams (two half-chip forwards side by side:
+                                   * DESIGN.md 5.2).  The caller guarantees:
+                                   *  - streams used concurrently have DISJOINT masks;
+                                   *  - a mask enables at least ceil(n / 8) CUs in EVERY XCD (workgroups are dealt round-robin to
+                                   *    the eight XCDs: n enabled CUs anywhere are not enough for n co-resident workgroups);
+                                   *  - one handle (pair) per masked stream: a handle has ONE control region; used on a second
+                                   *    masked stream its forwards are ordered behind those on the first one.
+                                   * The library orders whole-device forwards (n = 0 handles) behind every masked forward issued
+                                   * before them and masked forwards behind the last whole-device forward, so the two kinds never
+                                   * share the chip.  A violated guarantee ends in the bounded spin (R3D_OPT_SPIN_TIMEOUT_MS), NaN
+                                   * outputs and R3D_ERR_ABORTED from r3d_status - never in a hang.  0 (default): the whole device.
+                                   * Changing the value waits for the handle's device and drops its cached tile schedules; it
+                                   * fails with R3D_ERR_STATE while the handle has prepared (pinned) schedules - r3d_release them
+                                   * first.  For a pair set it on both handles.                                              */
 int r3d_set_option(r3d_model *m, int32_t option, int64_t value);
 
 /* ---- instrumentation (bench.py / tests) ---- */

@@ -195,9 +195,10 @@ int fill_prob(const Plan *pl, const ProbSpec &q, int64_t B, const Model *a, cons
         tg[13] = tg[14] = TA;
         g.K3 = L3.Kpad;
         g.slope3 = L3.slope;
-        // the register-chained form of the same three layers (r3d_chain.hpp): gathered rays, fp32 tiles (R3D_NO_CHAIN=1, hooks build: off)
+        // the register-chained form of the same three layers (r3d_chain.hpp): gathered rays, fp32 tiles - an experiment that only the
+        // hooks build switches on (R3D_CHAIN=1, at r3d_finalize AND here): faster stand-alone, slower inside the forward
         if (L.chain_off != 0 && L.chain_l1 == q.layer2 && L.chain_l2 == q.layer3 && !cs.uv && !cs.shared && g.lut != nullptr &&
-            !hook_on("R3D_NO_CHAIN")) {
+            hook_on("R3D_CHAIN")) {
             g.wchain = arena_ptr(L.chain_off);
             tg[18] = TA;
         }
@@ -218,32 +219,56 @@ struct FwdOrder {
     hipEvent_t ev[64] = {nullptr};
     hipStream_t last[64] = {nullptr};
     bool have[64] = {false};
+    // R3D_OPT_CU_LIMIT: forwards on CU-masked streams are not ordered against EACH OTHER (disjoint masks: that is their point), but
+    // a whole-device forward and a masked one must never share the chip either: the streams that have run a masked forward since
+    // the last whole-device forward waited for them
+    std::vector<hipStream_t> masked[64];
 };
 static FwdOrder g_fwd_order;
 
-static hipError_t order_single_launch(hipStream_t stream, bool before) {
+// `behind`: make `stream` wait (device-side) for everything `other` has been given so far.  A stream that is gone or capturing is skipped.
+static hipError_t wait_behind(hipStream_t stream, hipStream_t other, hipEvent_t &ev) {
+    if (other == stream) return hipSuccess;
+    hipStreamCaptureStatus ocs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(other, &ocs) != hipSuccess || ocs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return hipSuccess; }
+    if (!ev) {
+        hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipEventRecord(ev, other);
+    if (e != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }      // (the other stream is gone: nothing of it can still run)
+    return hipStreamWaitEvent(stream, ev, 0);
+}
+
+// masked: the forward runs on a CU-masked stream with R3D_OPT_CU_LIMIT workgroups.  Rules: whole-device forwards are ordered among
+// themselves and behind every masked forward issued before them; a masked forward is ordered behind the last whole-device forward;
+// masked forwards of different streams are not ordered against each other.
+static hipError_t order_single_launch(hipStream_t stream, bool before, bool masked = false) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipSuccess;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }
     if (cs != hipStreamCaptureStatusNone) return hipSuccess;
     std::lock_guard<std::mutex> lock(g_fwd_order.mu);
+    FwdOrder &o = g_fwd_order;
     if (!before) {                                   // (after the launch: just remember whose it was - no event on the one-stream path)
-        g_fwd_order.last[dev] = stream;
-        g_fwd_order.have[dev] = true;
+        if (masked) {
+            if (std::find(o.masked[dev].begin(), o.masked[dev].end(), stream) == o.masked[dev].end()) o.masked[dev].push_back(stream);
+        } else {
+            o.last[dev] = stream;
+            o.have[dev] = true;
+        }
         return hipSuccess;
     }
-    if (!g_fwd_order.have[dev] || g_fwd_order.last[dev] == stream) return hipSuccess;
-    // another stream ran the previous one: an event behind everything that stream has been given so far, and wait for it
-    if (!g_fwd_order.ev[dev]) {
-        hipError_t e = hipEventCreateWithFlags(&g_fwd_order.ev[dev], hipEventDisableTiming);
-        if (e != hipSuccess) return e;
+    // another stream ran the previous whole-device forward: an event behind everything that stream has been given so far, and wait for it
+    if (o.have[dev] && o.last[dev] != stream)
+        if (hipError_t e = wait_behind(stream, o.last[dev], o.ev[dev]); e != hipSuccess) return e;
+    if (!masked) {
+        for (hipStream_t ms : o.masked[dev])
+            if (hipError_t e = wait_behind(stream, ms, o.ev[dev]); e != hipSuccess) return e;
+        o.masked[dev].clear();                       // (they re-enter the list with their next masked forward)
     }
-    hipStreamCaptureStatus ocs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(g_fwd_order.last[dev], &ocs) != hipSuccess || ocs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return hipSuccess; }
-    hipError_t e = hipEventRecord(g_fwd_order.ev[dev], g_fwd_order.last[dev]);
-    if (e != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }      // (the other stream is gone: nothing of it can still run)
-    return hipStreamWaitEvent(stream, g_fwd_order.ev[dev], 0);
+    return hipSuccess;
 }
 
 static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *out, float *out_trj, void *ws,
@@ -407,7 +432,12 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         for (int k = 0; bound && k < BIND_NBASE; ++k) bound = bd.base[k] == ba.base[k];
         const int bank = bound ? bd.bank ^ 1 : 0;
         unsigned *cnt = reinterpret_cast<unsigned *>(ctrl + (own ? bank : 0) * bank_bytes);
-        if (cu_limit == 0 && (e = order_single_launch(stream, true)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
+        if ((e = order_single_launch(stream, true, cu_limit > 0)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
+        // one handle on two masked streams: its counter banks and control region are one per handle - the second stream waits for the first
+        if (cu_limit > 0 && a->last_fwd_stream && a->last_fwd_stream != stream) {
+            if ((e = wait_behind(stream, (hipStream_t)a->last_fwd_stream, a->order_ev)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
+        }
+        a->last_fwd_stream = stream;
         if (!bound) {
             ba.cnt = reinterpret_cast<unsigned *>(ctrl);
             ba.ncnt = own ? (int)(2 * bank_bytes / sizeof(unsigned)) - 4 : fw.ncnt;      // (the kernel zeroes ncnt + 4 words: both banks)
@@ -449,7 +479,8 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         fa.spin_ticks = (long long)std::max(a->spin_timeout_ms, 1) * 100000LL;          // 100 MHz wall clock
         if (const char *ft = hook_env("R3D_FAULT_TILE")) fa.fault_tile1 = atoi(ft) + 1;   // (hooks build only: see FwdArgs)
         const bool uv_launch = uv && fw.uses_gather;
-        const int fwd_kernel = shared ? FWD_KERNEL_CLIP : fw.kernel;     // (shared: fw.kernel is FWD_KERNEL_F32 - `single` above)
+        int fwd_kernel = shared ? FWD_KERNEL_CLIP : fw.kernel;           // (shared: fw.kernel is FWD_KERNEL_F32 - `single` above)
+        if (fwd_kernel == FWD_KERNEL_F32 && !uv_launch && hook_on("R3D_CHAIN")) fwd_kernel = FWD_KERNEL_CHAIN;   // (experiment: fill_prob has set wchain)
         if ((e = rec.begin(forward_kernel_name(fwd_kernel, uv_launch), stage_no, fw.grid, fw.flops, fw.bytes)) != hipSuccess)
             return hip_fail(e, "hipEventRecord");
 #ifdef R3D_TIMING
@@ -463,7 +494,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
 #endif
         if ((e = launch_forward(fa, fw.grid, fwd_kernel, uv_launch, stream)) != hipSuccess) return hip_fail(e, "launch r3d_forward_f32");
         a->last_clk_dev = cap == hipStreamCaptureStatusNone ? cnt + fw.ncnt + 2 : nullptr;   // (a captured call runs later, maybe never)
-        if (cu_limit == 0 && (e = order_single_launch(stream, false)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        if ((e = order_single_launch(stream, false, cu_limit > 0)) != hipSuccess) return hip_fail(e, "hipEventRecord");
         if (own) {                     // the next call on these buffers needs no bind
             bd.valid = true;
             bd.bank = bank;
@@ -1022,10 +1053,22 @@ int r3d_set_option(r3d_model *m, int32_t option, int64_t value) {
         case R3D_OPT_CU_LIMIT:
             if (value < 0 || value > 4096) { r3d::set_error("r3d_set_option: CU limit must be 0 .. 4096 (got %lld)", (long long)value); return R3D_ERR_ARG; }
             if (mm->cu_limit != (int)value) {
-                // the cached schedules were packed for another workgroup count; their launches may still be in flight
+                // The cached schedules were packed for another workgroup count: they are dropped - which must not happen under a
+                // captured graph (r3d_prepare pins the schedules a graph's kernels point into) or while a capture is being recorded.
+                if (r3d::plans_pinned(mm)) {
+                    r3d::set_error("r3d_set_option(R3D_OPT_CU_LIMIT): the handle has prepared (pinned) schedules - r3d_release them first; "
+                                   "a captured hipGraph would be left with dangling tile lists");
+                    return R3D_ERR_STATE;
+                }
+                // ... and their launches may still be in flight on the handle's device
+                int cur = 0;
+                const bool have_dev = mm->device >= 0 && hipGetDevice(&cur) == hipSuccess;
+                if (have_dev && cur != mm->device) (void)hipSetDevice(mm->device);
                 if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+                if (have_dev && cur != mm->device) (void)hipSetDevice(cur);
                 r3d::plans_drop(mm);
                 mm->cu_limit = (int)value;
+                mm->last_fwd_stream = nullptr;
             }
             return R3D_OK;
         default: r3d::set_error("r3d_set_option: unknown option %d", option); return R3D_ERR_ARG;

@@ -181,7 +181,7 @@ __device__ __forceinline__ void first_level_chain(ProbRef P, const int4 *tile_li
                     // (the next slab landed a whole slab ago: its first fragments are read early in the last half group, away from the barrier)
                     if (n < 4) wq[0][n] = *reinterpret_cast<const f32x4 *>(nxt + n * 256);
                     if (n == 10) {
-#ifdef R3D_TIMING
+#if defined(R3D_TIMING) && defined(R3D_TIMING_BARRIERS)   // (two clock reads per slab in every wavefront: ~7 us per tile of their own - off unless asked for)
                         const long long tb = wall_clock64();
                         wg_barrier();
                         bar_ticks += wall_clock64() - tb;

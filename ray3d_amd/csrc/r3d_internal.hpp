@@ -111,7 +111,7 @@ struct FwdArgs {
                               // its n-th GEMV tile neither stores nor reports (0: none; n + 1 stored)
     long long *dbg;
 };
-enum { FWD_KERNEL_F32 = 0, FWD_KERNEL_B3 = 1, FWD_KERNEL_LAT = 2, FWD_KERNEL_CLIP = 3, FWD_KERNEL_COUNT = 4 };   // specialisations of the single-launch forward
+enum { FWD_KERNEL_F32 = 0, FWD_KERNEL_B3 = 1, FWD_KERNEL_LAT = 2, FWD_KERNEL_CLIP = 3, FWD_KERNEL_CHAIN = 4, FWD_KERNEL_COUNT = 5 };   // specialisations of the single-launch forward
 constexpr int BIND_NPTR = 19;  // pointer fields of a GemmProb, in the order r3d_bind_f32 walks them
 enum { BIND_NULL = 0, BIND_WS, BIND_ARENA0, BIND_ARENA1, BIND_IARENA0, BIND_IARENA1, BIND_X, BIND_PARAM, BIND_CAM, BIND_NBASE };
 struct BindArgs {
@@ -258,6 +258,8 @@ struct Model {
     bool opt_staged = false;          // this handle's forwards run one launch per level (no co-residency assumption)
     int spin_timeout_ms = 1000;       // bound of a dependency wait of the single-launch forward
     int cu_limit = 0;                 // R3D_OPT_CU_LIMIT: CUs of the (masked) stream this handle's forwards run on; 0 = the whole device
+    void *last_fwd_stream = nullptr;  // ... the stream of its last masked forward (a second masked stream waits for it: one control region per handle)
+    hipEvent_t order_ev = nullptr;
     const unsigned *last_clk_dev = nullptr;   // the clock stamp of the last single-launch forward (two words of its counter bank: r3d_last_clock)
     unsigned *status_host = nullptr;  // pinned host word the decoder kernel raises when a wait gave up (r3d_status reads and clears it)
     // profiling
@@ -434,6 +436,7 @@ int plan_kind(int64_t B);                       // the plan a call of B windows 
 std::vector<int64_t> plan_kind_edges();         // the largest window count of every plan kind that has one (r3d_workspace_bytes)
 Plan *plan_get(Model *a, Model *b, int kind);
 void plans_drop(const Model *m);   // delete every cached plan (and its schedules) that names `m`
+bool plans_pinned(const Model *m); // some schedule of a plan that names `m` is pinned (r3d_prepare: a captured graph may point into it)
 constexpr int STAGE_SPILL_IN = 1 << 30;   // flag on a Plan::stages entry: the spilled rows of that problem
 constexpr int GEMM_SCHED_MAX_UNITS = 6;   // widest tile of r3d_gemm_f32: 6 x 32 rows
 struct SchedProb {
@@ -480,6 +483,7 @@ FwdKernel fwd_kernel_f32(bool uv);        // r3d_forward_f32 / r3d_forward_uv_f3
 FwdKernel fwd_kernel_b3(bool uv);         // r3d_forward_b3 / r3d_forward_uv_b3         (r3d_k_fwd_b3.hip)
 FwdKernel fwd_kernel_lat(bool uv);        // r3d_forward_lat / r3d_forward_uv_lat       (r3d_k_fwd_lat.hip)
 FwdKernel fwd_kernel_clip(bool uv);       // r3d_forward_clip_f32 / _clip_uv_f32        (r3d_k_fwd_clip.hip)
+FwdKernel fwd_kernel_chain(bool uv);      // r3d_forward_chain_f32 (experiment, rays only) (r3d_k_fwd_chain.hip)
 hipError_t launch_gemm_stage(const LaunchArgs &args, int nwg, int kind, bool uv, hipStream_t stream);   // uv: the launch gathers pixel keypoints
 hipError_t launch_decode(const DecodeArgs &args, hipStream_t stream);
 hipError_t launch_forward(const FwdArgs &args, int nwg, int kind, bool uv, hipStream_t stream);

@@ -12,7 +12,7 @@ namespace r3d {
         (void)args_;                                                                                    \
         gemm_persistent<false, UV_, true, B3_, NARROW_, CLIP_, CHAIN_>(smem);                       \
     }
-R3D_FORWARD_KERNEL(r3d_forward_f32, false, false, false, false, true)      // (+ the register-chained first level)
+R3D_FORWARD_KERNEL(r3d_forward_f32, false, false, false, false, false)
 R3D_FORWARD_KERNEL(r3d_forward_uv_f32, true, false, false, false, false)
 FwdKernel fwd_kernel_f32(bool uv) { return uv ? r3d_forward_uv_f32 : r3d_forward_f32; }
 

@@ -9,7 +9,7 @@ namespace r3d {
 extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_f32(const LaunchArgs args_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     (void)args_;
-    gemm_persistent<false, false, false, false, true, true, true>(smem);     // (+ the register-chained first level)
+    gemm_persistent<false, false, false, false>(smem);
 }
 // the same for launches whose gathered operands are pixel keypoints (UV input mode: rays encoded while staging)
 extern "C" __global__ __launch_bounds__(GEMM_THREADS) void r3d_gemm_uv_f32(const LaunchArgs args_) {

@@ -92,6 +92,7 @@ static FwdKernel forward_kernel(int kind, bool uv) {
         case FWD_KERNEL_B3: return fwd_kernel_b3(uv);
         case FWD_KERNEL_LAT: return fwd_kernel_lat(uv);
         case FWD_KERNEL_CLIP: return fwd_kernel_clip(uv);
+        case FWD_KERNEL_CHAIN: return fwd_kernel_chain(uv);
         default: return fwd_kernel_f32(uv);
     }
 }
@@ -100,6 +101,7 @@ const char *forward_kernel_name(int kind, bool uv) {
         case FWD_KERNEL_B3: return uv ? "r3d_forward_uv_b3" : "r3d_forward_b3";
         case FWD_KERNEL_LAT: return uv ? "r3d_forward_uv_lat" : "r3d_forward_lat";
         case FWD_KERNEL_CLIP: return uv ? "r3d_forward_clip_uv_f32" : "r3d_forward_clip_f32";
+        case FWD_KERNEL_CHAIN: return "r3d_forward_chain_f32";
         default: return uv ? "r3d_forward_uv_f32" : "r3d_forward_f32";
     }
 }

@@ -138,6 +138,7 @@ Model::~Model() {
     if (d_arena) (void)hipFree(d_arena);
     if (d_iarena) (void)hipFree(d_iarena);
     if (status_host) (void)hipHostFree(status_host);
+    if (order_ev) (void)hipEventDestroy(order_ev);
     for (auto &r : recs) {
         (void)hipEventDestroy(r.e0);
         (void)hipEventDestroy(r.e1);
@@ -401,7 +402,7 @@ int model_finalize(Model *m) {
             off += (size_t)L.Npad * L.Kpad;
         }
         L.chain_off = 0;
-        if (L.chain_l1 >= 0 && L.Kpad == 64 && !L.colmap.empty()) {
+        if (L.chain_l1 >= 0 && L.Kpad == 64 && !L.colmap.empty() && hook_on("R3D_CHAIN")) {   // (experiment: hooks build with R3D_CHAIN=1 only)
             off = (off + 255) / 256 * 256;                 // 1 KiB aligned slabs
             L.chain_off = off;
             off += (size_t)(L.Kpad / 16 + 64) * 4096;

@@ -508,4 +508,13 @@ void plans_drop(const Model *m) {
     }
 }
 
+bool plans_pinned(const Model *m) {
+    std::lock_guard<std::mutex> lock(g_plans_mutex);
+    for (const auto &kv : g_plans)
+        if (kv.first.first.first == m->id || kv.first.first.second == m->id)
+            for (const auto &sc : kv.second->schedules)
+                if (sc.second && sc.second->pinned) return true;
+    return false;
+}
+
 }  // namespace r3d

@@ -904,6 +904,7 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
                     if (c > 0) cap = cap > 0 ? std::min(cap, c) : c;
                 };
                 if (fw.uses_gather && pl->m[0]->cfg.in_features == 3) also(fw.kernel, true);
+                if (fw.kernel == FWD_KERNEL_F32 && hook_on("R3D_CHAIN")) also(FWD_KERNEL_CHAIN, false);   // (experiment: r3d_forward_chain_f32 runs these lists)
                 if (pl->frame_buf >= 0 && fw.kernel == FWD_KERNEL_F32) {
                     also(FWD_KERNEL_CLIP, false);
                     if (pl->m[0]->cfg.in_features == 3) also(FWD_KERNEL_CLIP, true);

@@ -20,6 +20,7 @@ import math
 from typing import Dict, Optional
 
 import numpy as np
+import os
 import torch
 import torch.nn as nn
 
@@ -578,33 +579,54 @@ def load_checkpoint(path: str, pos_model, trj_model=None) -> dict:
     return {k: v for k, v in ckpt.items() if k not in ("model_pos", "model_trj", "optimizer")}
 
 
+_masked_streams: Dict[tuple, "torch.cuda.ExternalStream"] = {}
+
+
+def _loaded_hip_runtime():
+    """The HIP runtime THIS process has already loaded (the one torch drives the GPU through) as a ctypes handle: its path is taken
+    from /proc/self/maps, so that no second copy of libamdhip64 (a system ROCm next to the one bundled with the wheel) gets
+    initialised - a hipStream_t of another runtime instance would be an invalid handle for torch and for the library's launches."""
+    import ctypes
+    path = None
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    path = line.split()[-1]
+                    break
+    except OSError:
+        pass
+    if path is None:
+        raise _capi.Ray3DHipError("no HIP runtime (libamdhip64) is loaded in this process: is torch a ROCm build with a GPU visible?")
+    mode = getattr(os, "RTLD_NOLOAD", 0) | getattr(os, "RTLD_NOW", 2)
+    return ctypes.CDLL(path, mode=mode)
+
+
 def masked_stream(cu_bits, device=None):
     """A HIP stream restricted to the CUs whose bits are set in `cu_bits` (an iterable of CU indices), as a
-    torch.cuda.ExternalStream: hipExtStreamCreateWithCUMask through ctypes on the HIP runtime torch has loaded.  Bit i of the
-    mask is CU i // 8 of XCD i % 8 on MI355X's 8 x 32 CUs (the driver deals consecutive bits to consecutive XCDs), so
-    `range(0, 128)` and `range(128, 256)` are two disjoint halves that both span all eight XCDs (and their L2s).
-    The stream lives until the process ends (torch does not own it)."""
+    torch.cuda.ExternalStream: hipExtStreamCreateWithCUMask through ctypes on the HIP runtime torch has loaded (found in
+    /proc/self/maps, opened RTLD_NOLOAD).  Bit i of the mask is CU i // 8 of XCD i % 8 on MI355X's 8 x 32 CUs (the driver deals
+    consecutive bits to consecutive XCDs), so `range(0, 128)` and `range(128, 256)` are two disjoint halves that both span all
+    eight XCDs (and their L2s) - what R3D_OPT_CU_LIMIT needs: at least ceil(n / 8) enabled CUs in EVERY XCD, disjoint masks for
+    streams used concurrently, one lifter per masked stream (include/ray3d_hip.h).  Streams are cached per (device, mask): asking
+    again returns the same stream; they live until the process ends (torch does not own them)."""
     import ctypes
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-    bits = sorted(set(int(b) for b in cu_bits))
+    bits = tuple(sorted(set(int(b) for b in cu_bits)))
     if not bits or bits[0] < 0:
         raise ValueError("masked_stream needs at least one CU index >= 0")
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), bits)
+    if key in _masked_streams:
+        return _masked_streams[key]
     words = (bits[-1] // 32) + 1
     mask = (ctypes.c_uint32 * words)()
     for b in bits:
         mask[b // 32] |= 1 << (b % 32)
-    hip = None
-    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
-        try:
-            hip = ctypes.CDLL(name)
-            break
-        except OSError:
-            continue
-    if hip is None:
-        raise _capi.Ray3DHipError("the HIP runtime (libamdhip64.so) could not be loaded")
+    hip = _loaded_hip_runtime()
     stream = ctypes.c_void_p()
     with torch.cuda.device(dev):
         rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(stream), ctypes.c_uint32(words), mask)
     if rc != 0 or not stream.value:
         raise _capi.Ray3DHipError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
-    return torch.cuda.ExternalStream(stream.value, device=dev)
+    _masked_streams[key] = torch.cuda.ExternalStream(stream.value, device=dev)
+    return _masked_streams[key]

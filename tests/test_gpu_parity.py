@@ -1050,6 +1050,42 @@ def test_bf16x3_error_against_float64_is_the_fp32_paths(monkeypatch):
     assert errs["1"] <= 1.25 * errs["0"] + 1e-6
 
 
+# ---------------------------------------------------------------- the register-chained first-level tile (experiment)
+
+@pytest.mark.parametrize("B", [100, 256])
+def test_register_chained_first_level_tile_against_the_oracle_chain(B, monkeypatch):
+    """r3d_chain.hpp / r3d_forward_chain_f32 (hooks build, R3D_CHAIN=1): the fused first level of the five body-part branches as
+    a register-chained tile - four MFMA wavefronts of 16 rows x 256 channels on v_mfma_f32_16x16x4_f32, four loader wavefronts
+    streaming the weights global -> LDS.  An experiment kept for its A/B (faster stand-alone, slower inside the forward:
+    DESIGN.md 4.6), so it stays held to the same bars as the product's tile: the torch port of the reference graph
+    (lib/model/rie.py:85-97 is the arithmetic) at the literal bound, the float64 error budget, the kernel's name in the launch
+    records - and the product's own result to fp32 rounding."""
+    import ray3d_amd
+    from ray3d_amd import synth
+    dev_switch(monkeypatch, "R3D_CHAIN", "1")
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3,3,3")
+    pos, trj, (cp, sp), (ct, st) = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    x, p = synth.synth_rays(B, cp, seed=71), synth.synth_param(B, seed=72)
+    xd, pd = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    with torch.no_grad():
+        out = lifter(xd, pd).cpu().numpy()
+        recs = lifter.profile(xd, pd)
+    lifter.check_status()
+    assert any(r["kernel"] == "r3d_forward_chain_f32" for r in recs), [r["kernel"] for r in recs]
+    ref, cpu = _f64_and_cpu_errors(cp, sp, ct, st, x, p)
+    check_parity(out, cpu, "chained first level vs torch port")
+    e_hip, e_cpu = float(np.abs(out.astype(np.float64) - ref).max()), float(np.abs(cpu.astype(np.float64) - ref).max())
+    print("chained tile, %d windows: error vs float64 %.3e, torch-CPU fp32 %.3e" % (B, e_hip, e_cpu))
+    assert e_hip <= 2.0 * e_cpu + float(np.abs(ref).max()) * 2.0 ** -23
+    monkeypatch.setenv("R3D_CHAIN", "0")
+    pos2, trj2, _, _ = build_modules(mc)
+    with torch.no_grad():
+        base = ray3d_amd.Ray3DLifter(pos2, trj2).eval()(xd, pd).cpu().numpy()
+    check_parity(out, base, "chained first level vs first_level_taps (HIP against HIP)", tol=2e-5 * max(1.0, float(np.abs(base).max())))
+    assert not np.array_equal(out, base)        # (it did take the other tile)
+
+
 # ---------------------------------------------------------------- the fp32 tiles' error budget
 
 def _f64_and_cpu_errors(cp, sp, ct, st, x, p):

@@ -15,6 +15,7 @@
 // convolution (four channel blocks of the output at a time): chain_probe3.cpp.
 // build: hipcc -O3 --offload-arch=gfx950 tools/chain_probe4.cpp -o tools/chain_probe4.bin   (-DABL=1: no loaders, no barriers)
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -42,6 +43,15 @@ constexpr int C = 256, K0 = 64, NCB = C / 16, TR = 64;
 #ifndef LOADER_DMA
 #define LOADER_DMA 0      // 1: the loaders use buffer_load ... lds (LDS-DMA) instead of global_load + ds_write_b128 (with HANDOVER 0)
 #endif
+#ifndef GATHER_SCALAR
+#define GATHER_SCALAR 0   // 1: the operand gather as the product does it (4-byte loads)
+#endif
+#ifndef STORE_SC1
+#define STORE_SC1 0       // 1: write-through output stores, as the product's hand-off needs them
+#endif
+#ifndef STAGGER
+#define STAGGER 0         // n: workgroup b starts (37 b mod 64) * n * 64 * 64 cycles late
+#endif
 #ifndef NIMG
 #define NIMG 1
 #endif
@@ -59,6 +69,7 @@ __device__ __forceinline__ float lrelu(float v) { return __builtin_fmaxf(v, v * 
 #define CFENCE() __atomic_signal_fence(__ATOMIC_SEQ_CST)
 
 struct Args {
+    long long *clk;        // per workgroup: shader cycles and 100 MHz wall-clock ticks of its run (the clock the tile code sustains)
     const float *x;        // [tiles][3 * TR expand rows][K0]
     const float *wsl;      // SLABS_PER_TILE slabs
     const float *b0, *b1, *b2;
@@ -77,6 +88,9 @@ __global__ __launch_bounds__(512) void chain_tile(const Args a) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         CFENCE();
     };
+#if STAGGER
+    for (int i = 0; i < (int)((blockIdx.x * 37) % 64) * STAGGER; ++i) __builtin_amdgcn_s_sleep(64);   // (workgroups out of phase, as in the persistent kernel)
+#endif
     const __amdgpu_buffer_rsrc_t rw = rsrc_of(a.wsl + (size_t)(blockIdx.x % NIMG) * SLABS_PER_TILE * SLAB_FLOATS);   // (NIMG copies of the stream: the product has five branches)
     const int total = a.tiles_per_wg * SLABS_PER_TILE;          // slabs this workgroup consumes; barrier t ends slab t
     // HANDOVER 1: prog[0..3] = slabs written by loader 0..3, prog[4..7] = slabs finished by MFMA wavefront 0..3
@@ -193,6 +207,7 @@ __global__ __launch_bounds__(512) void chain_tile(const Args a) {
     }
     // -------------------------------------------------------------------- MFMA wavefront: 16 rows x 256 channels
     const int j = lane & 15, g = lane >> 4;
+    const long long c_start = __builtin_readcyclecounter(), w_start = wall_clock64();
     f32x4 wq[2][4];                                             // weight fragments of the current / the next half group
     int slab_t = 0;                                             // the slab this wavefront is multiplying (HANDOVER 1)
     if (ABL != 1) {
@@ -271,9 +286,19 @@ __global__ __launch_bounds__(512) void chain_tile(const Args a) {
         const int x_tile = (int)(t_idx * (3 * TR) * K0 * 4);   // byte offset of the tile's operand rows
         // lane (j, g): features 16 g .. 16 g + 15 of its row (K step s = the features {s, s + 16, s + 32, s + 48}); piece i = 4 of them
         auto gather_piece = [&](int tile_off, int tap, int i) {
+#if GATHER_SCALAR
+            // as the product gathers: sixteen 4-byte loads per lane, the four lanes of a row on four consecutive elements
+            // (the values are not the ones the weights expect: timing only)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int voff = ((3 * row + tap) * K0 + 4 * (4 * i + e) + g) * 4;
+                xv[4 * i + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff, tile_off, 0));
+            }
+#else
             const int voff = ((3 * row + tap) * K0 + 16 * g) * 4;
             const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, tile_off + i * 16, 0));
             xv[4 * i] = v[0]; xv[4 * i + 1] = v[1]; xv[4 * i + 2] = v[2]; xv[4 * i + 3] = v[3];
+#endif
         };
         if (tile == 0) {
 #pragma unroll
@@ -321,7 +346,7 @@ __global__ __launch_bounds__(512) void chain_tile(const Args a) {
             f32x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = lrelu(O[G & 1][f][r] + b[r]) + DA[cb][r];
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, o_voff, cb * 64, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, o_voff, cb * 64, STORE_SC1 ? 16 : 0);
         };
         auto group_rec = [&](auto self, auto g_tag) {
             constexpr int G = decltype(g_tag)::value;
@@ -357,6 +382,7 @@ __global__ __launch_bounds__(512) void chain_tile(const Args a) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) out_block(NCB / 4 - 1, f);
     }
+    if (tid == 0 && a.clk) { a.clk[2 * blockIdx.x] = __builtin_readcyclecounter() - c_start; a.clk[2 * blockIdx.x + 1] = wall_clock64() - w_start; }
 }
 
 static float frand(unsigned &s) { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; }
@@ -408,7 +434,8 @@ int main(int argc, char **argv) {
     (void)hipMalloc(&dout, tiles * TR * C * 4);
     (void)hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice); for (int im = 0; im < NIMG; ++im) (void)hipMemcpy(dw + (size_t)im * wsl.size(), wsl.data(), wsl.size() * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(db0, b0.data(), C * 4, hipMemcpyHostToDevice); (void)hipMemcpy(db1, b1.data(), C * 4, hipMemcpyHostToDevice); (void)hipMemcpy(db2, b2.data(), C * 4, hipMemcpyHostToDevice);
-    a.x = dx; a.wsl = dw; a.b0 = db0; a.b1 = db1; a.b2 = db2; a.out = dout; a.tiles_per_wg = tiles_per_wg;
+    long long *dclk; (void)hipMalloc(&dclk, 2 * nwg * 8); (void)hipMemset(dclk, 0, 2 * nwg * 8);
+    a.clk = dclk; a.x = dx; a.wsl = dw; a.b0 = db0; a.b1 = db1; a.b2 = db2; a.out = dout; a.tiles_per_wg = tiles_per_wg;
     const int lds_bytes = NSTAGE * SLAB_FLOATS * 4 + 64;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_tile), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     chain_tile<<<nwg, 512, lds_bytes>>>(a);
@@ -450,10 +477,19 @@ int main(int argc, char **argv) {
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     const double us_tile = ms * 1e3 / reps / tiles_per_wg;
+    {
+        std::vector<long long> hc(2 * nwg);
+        (void)hipMemcpy(hc.data(), dclk, hc.size() * 8, hipMemcpyDeviceToHost);
+        std::vector<double> ghz;
+        for (int w = 0; w < nwg; ++w) if (hc[2 * w + 1] > 0) ghz.push_back((double)hc[2 * w] / (hc[2 * w + 1] * 10.0));
+        std::sort(ghz.begin(), ghz.end());
+        if (!ghz.empty()) printf("shader clock during the run (cycle counter / 100 MHz wall clock, per workgroup): median %.2f GHz, %.2f .. %.2f; cycles per tile %.0f\n",
+                                 ghz[ghz.size() / 2], ghz.front(), ghz.back(), us_tile * 1e3 * ghz[ghz.size() / 2]);
+    }
     const double mfma = 4.0 * SLABS_PER_TILE * 64;     // per workgroup and tile
     const double flop_alg = 2.0 * TR * (3.0 * K0 * C + 3.0 * C * C + (double)C * C);
-    printf("NIMG=%d HANDOVER=%d LOADER_DMA=%d LOADER_ABL=%d ABL=%d LOAD_AHEAD=%d: %d tiles of %d rows per workgroup, 256 workgroups: %.1f us per tile of 64 rows (the product's 64-row tile: ~79 us, ~88 in its timing build)\n",
-           NIMG, HANDOVER, LOADER_DMA, LOADER_ABL, ABL, LOAD_AHEAD, tiles_per_wg, TR, us_tile);
+    printf("STAGGER=%d GATHER_SCALAR=%d STORE_SC1=%d NIMG=%d HANDOVER=%d LOADER_DMA=%d LOADER_ABL=%d ABL=%d LOAD_AHEAD=%d: %d tiles of %d rows per workgroup, 256 workgroups: %.1f us per tile of 64 rows (the product's 64-row tile: ~79 us, ~88 in its timing build)\n",
+           STAGGER, GATHER_SCALAR, STORE_SC1, NIMG, HANDOVER, LOADER_DMA, LOADER_ABL, ABL, LOAD_AHEAD, tiles_per_wg, TR, us_tile);
     printf("MFMA issue bound (%.0f x 16x16x4 per tile, 32 cycles each, 4 SIMDs at 2.4 GHz): %.1f us per tile -> %.2f of it; algorithmic %.1f TFLOP/s of 157.3 chip-wide\n",
            mfma, mfma * 32 / 4 / 2.4e3, mfma * 32 / 4 / 2.4e3 / us_tile, flop_alg * 256 / us_tile / 1e6);
     return 0;
