@@ -356,6 +356,54 @@ def half_chip_variant(dev, x, p, out_ref, steps, warmup):
                     "handles, R3D_OPT_CU_LIMIT); throughput of back-to-back independent batches - not the headline's step" % B}
 
 
+def lanes_variant(lifter, dev, x, p, out_ref, steps, warmup, n):
+    """SECONDARY object (never `value`): R3D_OPT_LANES = n on the run's OWN pair of handles - n library-owned CU-masked streams that
+    share one packed weight image - lifting n independent batches per round side by side.  What round 5 measured with two model
+    copies and caller-made streams (`half_chip_streams_variant`), through one pair.  Reports the device memory the lanes added."""
+    B = x.shape[0]
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    lifter.set_lanes(n, dev)
+    xs, ps = [x.clone() for _ in range(n)], [p.clone() for _ in range(n)]
+    outs = [None] * n
+
+    def round_():
+        for k in range(n):
+            with lifter.lane(k):
+                outs[k] = lifter(xs[k], ps[k])
+
+    try:
+        with torch.no_grad():
+            lifter.prepare([B], dev)
+            round_()
+            lifter.join_lanes()
+            torch.cuda.synchronize()
+            lifter.check_status(dev)
+            added = free0 - torch.cuda.mem_get_info(dev)[0]
+            err = max(float((o - out_ref).abs().max().item()) for o in outs)
+            for _ in range(max(warmup, 30)):
+                round_()
+            lifter.join_lanes()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                round_()
+            lifter.join_lanes()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+    finally:
+        torch.cuda.synchronize()
+        lifter.set_lanes(0, dev)
+    from ray3d_amd import _capi
+    ws_bytes = _capi.workspace_bytes(lifter.pos.handle(dev), lifter.trj.handle(dev), B)
+    return {"lanes": n, "value": round(n * B * steps / el, 1), "unit": "poses/s", "ms_per_round": round(el / steps * 1e3, 4),
+            "rounds": steps, "windows_per_round": n * B, "max_abs_diff_vs_whole_chip_path_m": err,
+            "device_bytes_added_by_lanes": int(added), "workspace_bytes_per_lane": int(ws_bytes),
+            "device_bytes_added_minus_workspaces_and_inputs": int(added - n * ws_bytes - sum(t.numel() * 4 for t in xs + ps) - n * B * 51 * 4),
+            "note": "SECONDARY: %d independent %d-window forwards per round on %d library-owned lanes (R3D_OPT_LANES) of ONE pair of handles - "
+                    "one weight image; throughput of back-to-back independent batches, not the headline's step" % (n, B, n)}
+
+
 def c1024_line(dev, steps, warmup, barrier, batches=(256,)):
     """SURVEY 8 f4 / lib/model/rie.py:14: TemporalBlock's class default is channels = 1024 (no shipped cfg uses it: every cfg file
     sets 256).  Such models run the LEVEL-BY-LEVEL form - the single persistent launch holds tiles of at most 256 channels - so
@@ -536,7 +584,7 @@ def eval_summary(allrows):
 
 
 def eval_pass(lifter, dev, dist, world, rank, n_clips, steps, warmup, barrier, max_over_ranks, all_ranks, cross_check=True,
-              length_div=1, lift=None):
+              length_div=1, lift=None, lanes=0):
     """BASELINE configs[2] / north_star's multi-GPU split on this process group: the synthetic clip set sharded over the ranks as
     whole clips (longest first), every clip lifted with in-kernel sliding windows and reduced to one row on the device, ONE
     all_gather of the rows per pass (lib/train_val/trainer.py:399-403,473-477 reduce them per action).  Strong scaling: the
@@ -562,6 +610,10 @@ def eval_pass(lifter, dev, dist, world, rank, n_clips, steps, warmup, barrier, m
         c, padded, prow, gt = item
         if lift is not None:
             lift(c, out_row)
+        elif lanes:
+            # R3D_OPT_LANES: the clip's forward AND its metrics on the next lane's stream (clips are independent: `lanes` of them share the chip)
+            with lifter.lane():
+                evaluate.clip_partials_hip(lifter.forward_clip(padded, prow), c, aid[c.action], gt_dev=gt, out=out_row)
         else:
             evaluate.clip_partials_hip(lifter.forward_clip(padded, prow), c, aid[c.action], gt_dev=gt, out=out_row)
 
@@ -579,6 +631,8 @@ def eval_pass(lifter, dev, dist, world, rank, n_clips, steps, warmup, barrier, m
     def lift_mine():
         for k, item in enumerate(mine):
             lift_row(item, local_rows[k])
+        if lanes:
+            lifter.join_lanes()
 
     def one_pass():
         lift_mine()
@@ -679,6 +733,9 @@ def main():
     ap.add_argument("--no-shipped-cfgs", action="store_true", help="windows mode: skip the secondary cfg4 / cfg5 objects")
     ap.add_argument("--clips", type=int, default=EVAL_CLIPS, help="eval mode: number of clips in the set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lanes", type=int, default=0, choices=(0, 2, 4),
+                    help="also measure R3D_OPT_LANES = N on the run's own handles: windows mode `lanes_variant` (N independent batches per round), "
+                         "eval mode `lanes` (clips on N lanes; same MPJPE)")
     ap.add_argument("--no-eval-pass", action="store_true",
                     help="windows mode under a process group: skip the secondary clip-sharded evaluation pass (`eval_pass`)")
     ap.add_argument("--no-b1024", action="store_true", help="windows mode: skip the roofline point at 1024 windows")
@@ -883,6 +940,8 @@ def main():
                 line["two_stream_variant"] = {"value": round(args.batch * args.steps / el2, 1), "unit": "poses/s",
                                               "ms_per_step": round(el2 / args.steps * 1e3, 4),
                                               "note": "same work as `value`, issued as 2 half batches on 2 streams"}
+            if world == 1 and args.lanes > 1 and lifter.precision(dev) == "f32":
+                guarded("lanes_variant", lambda: lanes_variant(lifter, dev, x, p, out, args.steps, args.warmup, args.lanes))
             if world == 1 and args.half_chip_streams and lifter.precision(dev) == "f32":
                 guarded("half_chip_streams_variant", lambda: half_chip_variant(dev, x, p, out, args.steps, args.warmup))
             if ev is not None:
@@ -937,6 +996,23 @@ def main():
                     line["roofline"] = _clip_roofline()
                 except Exception as e:                      # noqa: BLE001 - reported, not swallowed
                     line["roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            if world == 1 and args.lanes > 1 and lifter.precision(dev) == "f32":
+                # SECONDARY: the same pass with the clips dealt to N library-owned lanes (R3D_OPT_LANES): one weight image, N clips in flight
+                try:
+                    lifter.set_lanes(args.lanes, dev)
+                    ev2 = eval_pass(lifter, dev, dist, world, rank, args.clips, args.steps, args.warmup, barrier, max_over_ranks, all_ranks,
+                                    lanes=args.lanes)
+                    ev2.pop("_mine")
+                    line["lanes"] = {"lanes": args.lanes, "value": ev2["value"], "unit": "poses/s", "ms_per_pass": ev2["ms_per_pass"],
+                                     "mpjpe_mm": ev2["mpjpe_mm"],
+                                     "mpjpe_abs_diff_mm": abs(ev2["mpjpe_mm"]["action_average"] - ev["mpjpe_mm"]["action_average"]),
+                                     "checksum_rel_diff": abs(ev2["mpjpe_mm"]["checksum"] - ev["mpjpe_mm"]["checksum"]) / max(abs(ev["mpjpe_mm"]["checksum"]), 1e-30),
+                                     "speedup_vs_one_lane": round(ev2["value"] / ev["value"], 4),
+                                     "note": "SECONDARY: R3D_OPT_LANES on the pass's own handles; tile schedules of a lane are cut for its share of "
+                                             "the CUs, so sums may differ from the whole-chip pass in the last bits (split-K pieces)"}
+                    lifter.set_lanes(0, dev)
+                except Exception as e:                      # noqa: BLE001 - reported, not swallowed
+                    line["lanes"] = {"error": "%s: %s" % (type(e).__name__, e)}
             print(json.dumps(line))
     if dist is not None:
         dist.barrier()

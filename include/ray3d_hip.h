@@ -42,7 +42,7 @@ extern "C" {
 
 /* Mirrors the constructor arguments the reference factory passes
  * (lib/model/__init__.py:23-46 -> lib/model/rie.py:178-181 / :443-446). */
-#define R3D_ABI_VERSION 5 /* bumped whenever a struct below changes size or layout: r3d_abi_version() returns the
+#define R3D_ABI_VERSION 6 /* bumped whenever a struct below changes size or layout: r3d_abi_version() returns the
                            * library's; a binding compares it with the header it was written against       */
 
 typedef struct {
@@ -192,7 +192,30 @@ int r3d_status(r3d_model *m, void *hip_stream);
                                    * Changing the value waits for the handle's device and drops its cached tile schedules; it
                                    * fails with R3D_ERR_STATE while the handle has prepared (pinned) schedules - r3d_release them
                                    * first.  For a pair set it on both handles.                                              */
+#define R3D_OPT_LANES 4           /* value = n in {2, 4} (0 / 1: off): the LIBRARY creates n CU-masked streams on the handle's device -
+                                   * lane k: the CUs c of every XCD with c % n == k, so every lane spans all eight XCDs - each with
+                                   * its own tile schedules and control regions; the packed weights stay ONE image per handle.  n
+                                   * independent forwards then share the chip side by side (a level that holds 192 - 224 tiles
+                                   * leaves a quarter of 256 CUs idle and runs as two full rounds on 128): the throughput mode for
+                                   * callers with independent batches in flight - the clip evaluation has 240 clips
+                                   * (lib/train_val/trainer.py:295-353).  How a forward finds its lane:
+                                   *  - `stream` IS a lane's stream (r3d_lane_stream): it runs there, in order with whatever else the
+                                   *    caller enqueues on that stream (the metrics of the clip, ...);
+                                   *  - any other stream: lanes are served round-robin; the lane's stream waits for everything the
+                                   *    caller's stream holds so far, runs the forward, and the caller's stream sees the outputs
+                                   *    after r3d_lanes_join(m, stream) - NOT at return as without lanes.
+                                   * One workspace per lane in flight (the caller's, as always).  Set it on both handles of a pair,
+                                   * after r3d_finalize; it waits for the device, drops cached schedules and fails with
+                                   * R3D_ERR_STATE while prepared (pinned) schedules exist.  r3d_prepare prepares every lane.
+                                   * Abort contract as without lanes: a lane's forward that cannot get its workgroups resident
+                                   * ends in NaN outputs and R3D_ERR_ABORTED from r3d_status (which waits for the lanes too).    */
 int r3d_set_option(r3d_model *m, int32_t option, int64_t value);
+
+/* R3D_OPT_LANES: the stream of lane `lane` (0 .. n - 1) of the handle (for a pair: the pos handle's lanes are the pair's) - a
+ * hipStream_t the library owns; replaces nothing in the reference (its evaluation loop is sequential: trainer.py:295-353). */
+int r3d_lane_stream(r3d_model *m, int32_t lane, void **stream);
+/* ... and: make `stream` wait (device-side) for every forward that was relayed to a lane from another stream and not joined yet. */
+int r3d_lanes_join(r3d_model *m, void *stream);
 
 /* ---- instrumentation (bench.py / tests) ---- */
 

@@ -11,7 +11,7 @@ import os
 import sys
 
 here = os.path.dirname(os.path.abspath(__file__))
-rounds = sys.argv[1:] or ["r05"]
+rounds = sys.argv[1:] or ["r06"]
 out = {"_source": "rocprofv3 --pmc passes of profiles/prof_recipe.sh (separate passes; FETCH_SIZE x2 gfx950 correction, SQ quad-cycle "
                   "counters x4), summarised per kernel name by profiles/summarize_pmc.py; key = workload of the bench line "
                   "(b<windows> for BASELINE configs[1]'s shape, eval_b<windows> for one clip call of --mode eval, else bench.py --workload)",

@@ -19,7 +19,7 @@ HOOKS_LIB_PATH = os.environ.get("R3D_HOOKS_LIB") or os.path.join(_HERE, "libray3
 R3D_KIND_POS, R3D_KIND_TRJ = 0, 1
 R3D_INPUT_RAYS, R3D_INPUT_UV = 0, 1
 R3D_ERR_ABORTED = -7
-R3D_OPT_STAGED, R3D_OPT_SPIN_TIMEOUT_MS, R3D_OPT_CU_LIMIT = 1, 2, 3
+R3D_OPT_STAGED, R3D_OPT_SPIN_TIMEOUT_MS, R3D_OPT_CU_LIMIT, R3D_OPT_LANES = 1, 2, 3, 4
 
 # every symbol include/ray3d_hip.h declares (tests check the library exports exactly these)
 EXPORTS = (
@@ -27,9 +27,10 @@ EXPORTS = (
     "r3d_set_weight", "r3d_finalize", "r3d_workspace_bytes", "r3d_forward", "r3d_forward_pair",
     "r3d_profile_enable", "r3d_profile_read", "r3d_clip_metrics", "r3d_last_error", "r3d_version",
     "r3d_prepare", "r3d_release", "r3d_abi_version", "r3d_precision", "r3d_status", "r3d_set_option", "r3d_last_clock",
+    "r3d_lane_stream", "r3d_lanes_join",
 )
 HOOK_EXPORTS = ("r3d_debug_schedule_check", "r3d_debug_plan_check", "r3d_debug_forward_check")   # libray3d_hip_hooks.so only
-ABI_VERSION = 5                                                          # R3D_ABI_VERSION of the header this binding follows
+ABI_VERSION = 6                                                          # R3D_ABI_VERSION of the header this binding follows
 METRIC_NAMES = ("mpjpe", "p_mpjpe", "n_mpjpe", "velocity", "root")     # R3D_METRIC_* order
 METRIC_OUT_DOUBLES = 5 * (1 + 128)                                      # R3D_METRIC_OUT_DOUBLES
 
@@ -109,6 +110,8 @@ def load():
     lib.r3d_status.argtypes = [vp, vp]
     lib.r3d_set_option.argtypes = [vp, C.c_int32, C.c_int64]
     lib.r3d_last_clock.argtypes = [vp, vp, C.POINTER(C.c_double)]
+    lib.r3d_lane_stream.argtypes = [vp, C.c_int32, C.POINTER(vp)]
+    lib.r3d_lanes_join.argtypes = [vp, vp]
     lib.r3d_profile_enable.argtypes = [vp, C.c_int]
     lib.r3d_profile_read.argtypes = [vp, C.POINTER(LaunchRecord), C.c_int]
     lib.r3d_clip_metrics.argtypes = [vp, vp, C.c_int64, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp, vp]
@@ -171,6 +174,16 @@ class Handle:
 
     def set_option(self, option: int, value: int):
         check(self._lib.r3d_set_option(self.ptr, option, value), "r3d_set_option")
+
+    def lane_stream(self, lane: int) -> int:
+        """r3d_lane_stream: the hipStream_t of lane `lane` of a handle with R3D_OPT_LANES (the library owns it)."""
+        st = C.c_void_p()
+        check(self._lib.r3d_lane_stream(self.ptr, lane, C.byref(st)), "r3d_lane_stream")
+        return int(st.value)
+
+    def lanes_join(self, stream: int):
+        """r3d_lanes_join: `stream` waits for the forwards the library relayed to lanes from other streams."""
+        check(self._lib.r3d_lanes_join(self.ptr, stream), "r3d_lanes_join")
 
     def status(self, stream: int) -> bool:
         """r3d_status: synchronises `stream`; True when every forward of this handle since the last call finished, False

@@ -223,12 +223,35 @@ struct FwdOrder {
     // a whole-device forward and a masked one must never share the chip either: the streams that have run a masked forward since
     // the last whole-device forward waited for them
     std::vector<hipStream_t> masked[64];
+    // ... and a masked stream waits behind the last whole-device forward ONCE, not with every call: `gen` counts the device's
+    // whole-device forwards, `seen` which one each masked stream has waited for.  (An event per call would be recorded on the
+    // whole-device forward's stream - usually the legacy default stream, where an event is behind the work of EVERY blocking
+    // stream, the other lanes' forwards in flight included: the masked streams would run one after the other.)
+    struct Seen { hipStream_t s; unsigned long long gen; };
+    std::vector<Seen> seen[64];
+    unsigned long long gen[64] = {0};
 };
 static FwdOrder g_fwd_order;
+
+// A stream of the library's own is about to be destroyed: nothing may record events on it any more.
+static void order_forget(hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_fwd_order.mu);
+    FwdOrder &o = g_fwd_order;
+    for (int d = 0; d < 64; ++d) {
+        o.masked[d].erase(std::remove(o.masked[d].begin(), o.masked[d].end(), stream), o.masked[d].end());
+        o.seen[d].erase(std::remove_if(o.seen[d].begin(), o.seen[d].end(), [&](const FwdOrder::Seen &x) { return x.s == stream; }), o.seen[d].end());
+        if (o.have[d] && o.last[d] == stream) o.have[d] = false;
+    }
+}
 
 // `behind`: make `stream` wait (device-side) for everything `other` has been given so far.  A stream that is gone or capturing is skipped.
 static hipError_t wait_behind(hipStream_t stream, hipStream_t other, hipEvent_t &ev) {
     if (other == stream) return hipSuccess;
+    if (other == nullptr) {          // the legacy default stream: a blocking stream is behind its work already (and an event on it would be
+        unsigned flags = 0;          // behind every other blocking stream's work too - see FwdOrder::seen)
+        if (hipStreamGetFlags(stream, &flags) == hipSuccess && !(flags & hipStreamNonBlocking)) return hipSuccess;
+        (void)hipGetLastError();
+    }
     hipStreamCaptureStatus ocs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(other, &ocs) != hipSuccess || ocs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return hipSuccess; }
     if (!ev) {
@@ -257,12 +280,22 @@ static hipError_t order_single_launch(hipStream_t stream, bool before, bool mask
         } else {
             o.last[dev] = stream;
             o.have[dev] = true;
+            ++o.gen[dev];
         }
         return hipSuccess;
     }
     // another stream ran the previous whole-device forward: an event behind everything that stream has been given so far, and wait for it
-    if (o.have[dev] && o.last[dev] != stream)
-        if (hipError_t e = wait_behind(stream, o.last[dev], o.ev[dev]); e != hipSuccess) return e;
+    if (o.have[dev] && o.last[dev] != stream) {
+        bool wait = true;
+        if (masked) {                                // (once per whole-device forward and masked stream)
+            auto it = std::find_if(o.seen[dev].begin(), o.seen[dev].end(), [&](const FwdOrder::Seen &x) { return x.s == stream; });
+            if (it == o.seen[dev].end()) o.seen[dev].push_back({stream, o.gen[dev]});
+            else if (it->gen == o.gen[dev]) wait = false;
+            else it->gen = o.gen[dev];
+        }
+        if (wait)
+            if (hipError_t e = wait_behind(stream, o.last[dev], o.ev[dev]); e != hipSuccess) return e;
+    }
     if (!masked) {
         for (hipStream_t ms : o.masked[dev])
             if (hipError_t e = wait_behind(stream, ms, o.ev[dev]); e != hipSuccess) return e;
@@ -303,6 +336,37 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         return R3D_ERR_WORKSPACE;
     }
     hipStream_t stream = (hipStream_t)stream_v;
+    // R3D_OPT_LANES: which lane runs this forward - the one whose stream the caller passed, or the next one round-robin (then the
+    // lane's stream waits for the caller's, runs the forward, and the caller's stream joins later: r3d_lanes_join)
+    const int lanes = a->lanes;
+    if (b && b->lanes != lanes) { set_error("pos and trj handles disagree on R3D_OPT_LANES (%d / %d): set it on both", a->lanes, b->lanes); return R3D_ERR_STATE; }
+    int lane = 0;
+    Model::Lane *relay = nullptr;          // round-robin: the lane this call is relayed to
+    if (lanes > 1) {
+        lane = -1;
+        for (int k = 0; k < lanes; ++k)
+            if (a->lane[k].stream == stream) lane = k;
+        if (lane < 0) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+                (void)hipGetLastError();
+                set_error("a handle with R3D_OPT_LANES cannot be captured from a caller's stream: capture on a lane's own stream (r3d_lane_stream)");
+                return R3D_ERR_STATE;
+            }
+            lane = a->next_lane;
+            a->next_lane = (a->next_lane + 1) % lanes;
+            relay = &a->lane[lane];
+            hipError_t e0;
+            // (the lane is in order: a forward still pending on it for another stream simply runs first)
+            // (a caller on the legacy default stream: the lanes' streams are blocking ones and behind its work as they are - an
+            //  event recorded there would also be behind the other lanes' forwards, and the lanes would take turns)
+            if (stream != nullptr &&
+                ((e0 = hipEventRecord(relay->in, stream)) != hipSuccess || (e0 = hipStreamWaitEvent(relay->stream, relay->in, 0)) != hipSuccess))
+                return hip_fail(e0, "hipStreamWaitEvent(lane)");
+            stream = relay->stream;
+        }
+        lane += 1;                         // schedules of lane k live under key k + 1 (0: the handle without lanes)
+    }
     float *act_base = (float *)ws;         // (poll mode: the schedule's own activation bank of this call)
     auto buf_ptr = [&](int id) -> float * { return act_base + (size_t)pl->buffers[id].offset_per_window * (size_t)B; };
     Recorder rec{a, stream};
@@ -332,8 +396,8 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
     shape.frames = frames;
 
     // (R3D_OPT_CU_LIMIT: a CU-masked stream - fewer workgroups, and no ordering against other streams' forwards below)
-    const int cu_limit = std::max(a->cu_limit, b ? b->cu_limit : 0);
-    Schedule *sched = schedule_get(pl, B, cu_limit > 0 ? std::min(cu_limit, device_cu_count()) : device_cu_count());
+    const int cu_limit = lanes > 1 ? device_cu_count() / lanes : std::max(a->cu_limit, b ? b->cu_limit : 0);
+    Schedule *sched = schedule_get(pl, B, cu_limit > 0 ? std::min(cu_limit, device_cu_count()) : device_cu_count(), false, lane);
     if (!sched) return R3D_ERR_HIP;
     const unsigned *abort_flag = nullptr;
     // Clip calls (window stride one frame, lib/train_val/trainer.py:47-58): consecutive windows share all but one of their
@@ -434,7 +498,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         unsigned *cnt = reinterpret_cast<unsigned *>(ctrl + (own ? bank : 0) * bank_bytes);
         if ((e = order_single_launch(stream, true, cu_limit > 0)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
         // one handle on two masked streams: its counter banks and control region are one per handle - the second stream waits for the first
-        if (cu_limit > 0 && a->last_fwd_stream && a->last_fwd_stream != stream) {
+        if (cu_limit > 0 && lanes <= 1 && a->last_fwd_stream && a->last_fwd_stream != stream) {
             if ((e = wait_behind(stream, (hipStream_t)a->last_fwd_stream, a->order_ev)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
         }
         a->last_fwd_stream = stream;
@@ -673,7 +737,42 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
     if ((e = launch_decode(da, stream)) != hipSuccess) return hip_fail(e, "launch r3d_decode_f32");
     if ((e = rec.end()) != hipSuccess) return hip_fail(e, "hipEventRecord");
     if (rec.on()) a->nrec = (int)rec.n;
+    if (relay) {                           // the caller's stream sees the outputs once it has joined this lane (r3d_lanes_join)
+        if ((e = hipEventRecord(relay->done, relay->stream)) != hipSuccess) return hip_fail(e, "hipEventRecord(lane)");
+        relay->pending = true;
+        relay->for_stream = stream_v;
+    }
     return R3D_OK;
+}
+
+// CU mask of lane k of n: CUs c of every XCD with c % n == k (mask bit i is CU i / 8 of XCD i % 8: consecutive bits go to consecutive
+// XCDs) - every lane spans all eight XCDs and their L2s with device CUs / n CUs
+static int lanes_create(Model *m, int n) {
+    const int cus = device_cu_count();
+    const int words = (cus + 31) / 32;
+    for (int k = 0; k < n; ++k) {
+        std::vector<uint32_t> mask((size_t)std::max(words, 1), 0u);
+        for (int i = 0; i < cus; ++i)
+            if ((i / 8) % n == k) mask[(size_t)i / 32] |= 1u << (i % 32);
+        hipError_t e = hipExtStreamCreateWithCUMask(&m->lane[k].stream, (uint32_t)mask.size(), mask.data());
+        if (e != hipSuccess) return hip_fail(e, "hipExtStreamCreateWithCUMask");
+        if ((e = hipEventCreateWithFlags(&m->lane[k].done, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
+        if ((e = hipEventCreateWithFlags(&m->lane[k].in, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
+    }
+    return R3D_OK;
+}
+void lanes_destroy(Model *m) {
+    for (auto &ln : m->lane) {
+        if (ln.done) (void)hipEventDestroy(ln.done);
+        if (ln.in) (void)hipEventDestroy(ln.in);
+        if (ln.stream) {
+            order_forget(ln.stream);
+            (void)hipStreamSynchronize(ln.stream);
+            (void)hipStreamDestroy(ln.stream);
+        }
+        ln = Model::Lane();
+    }
+    m->next_lane = 0;
 }
 
 }  // namespace r3d
@@ -744,6 +843,11 @@ int r3d_prepare(r3d_model *pos, r3d_model *trj, int64_t B) {
     for (Model *m : {a, b})
         if (m && (!m->finalized || m->dirty)) { set_error("r3d_prepare called before r3d_finalize (or weights changed since)"); return R3D_ERR_STATE; }
     if (b && !same_input_shape(a, b)) { set_error("pos and trj models disagree on J / F / levels / extrinsic_dim"); return R3D_ERR_ARG; }
+    if (a->lanes > 1) {                    // every lane's schedule of this size
+        for (int k = 1; k <= a->lanes; ++k)
+            if (!schedule_get(plan_get(a, b, plan_kind(B)), B, device_cu_count() / a->lanes, /*pin=*/true, k)) return R3D_ERR_HIP;
+        return R3D_OK;
+    }
     const int cu_limit = std::max(a->cu_limit, b ? b->cu_limit : 0);
     return schedule_get(plan_get(a, b, plan_kind(B)), B, cu_limit > 0 ? std::min(cu_limit, device_cu_count()) : device_cu_count(), /*pin=*/true) ? R3D_OK : R3D_ERR_HIP;
 }
@@ -753,9 +857,12 @@ int r3d_release(r3d_model *pos, r3d_model *trj, int64_t B) {
     Model *a = p ? p : t, *b = p ? t : nullptr;
     if (!a || B <= 0) { set_error("r3d_release: no model given or B <= 0"); return R3D_ERR_ARG; }
     Plan *pl = plan_get(a, b, plan_kind(B));
-    auto it = pl->schedules.find(B);
-    if (it == pl->schedules.end() || !it->second->pinned) { set_error("r3d_release: %lld windows were never prepared for this pair", (long long)B); return R3D_ERR_ARG; }
-    it->second->pinned = false;
+    bool any = false;
+    for (int k = 0; k <= 4; ++k) {         // (the handle without lanes: key 0; lane k: key k + 1)
+        auto it = pl->schedules.find(schedule_key(B, k));
+        if (it != pl->schedules.end() && it->second->pinned) { it->second->pinned = false; any = true; }
+    }
+    if (!any) { set_error("r3d_release: %lld windows were never prepared for this pair", (long long)B); return R3D_ERR_ARG; }
     return R3D_OK;
 }
 
@@ -1071,8 +1178,51 @@ int r3d_set_option(r3d_model *m, int32_t option, int64_t value) {
                 mm->last_fwd_stream = nullptr;
             }
             return R3D_OK;
+        case R3D_OPT_LANES: {
+            if (value != 0 && value != 1 && value != 2 && value != 4) { r3d::set_error("r3d_set_option: R3D_OPT_LANES is 0, 1, 2 or 4 (got %lld)", (long long)value); return R3D_ERR_ARG; }
+            const int n = value <= 1 ? 0 : (int)value;
+            if (n == mm->lanes) return R3D_OK;
+            if (!mm->finalized) { r3d::set_error("r3d_set_option(R3D_OPT_LANES): r3d_finalize the handle first (the lanes live on its device)"); return R3D_ERR_STATE; }
+            if (r3d::plans_pinned(mm)) {
+                r3d::set_error("r3d_set_option(R3D_OPT_LANES): the handle has prepared (pinned) schedules - r3d_release them first");
+                return R3D_ERR_STATE;
+            }
+            int cur = 0;
+            const bool have_dev = mm->device >= 0 && hipGetDevice(&cur) == hipSuccess;
+            if (have_dev && cur != mm->device) (void)hipSetDevice(mm->device);
+            if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+            r3d::plans_drop(mm);
+            r3d::lanes_destroy(mm);
+            mm->lanes = 0;
+            int rc = R3D_OK;
+            if (n > 1 && (rc = r3d::lanes_create(mm, n)) == R3D_OK) mm->lanes = n;
+            if (rc != R3D_OK) r3d::lanes_destroy(mm);
+            if (have_dev && cur != mm->device) (void)hipSetDevice(cur);
+            return rc;
+        }
         default: r3d::set_error("r3d_set_option: unknown option %d", option); return R3D_ERR_ARG;
     }
+}
+
+int r3d_lane_stream(r3d_model *m, int32_t lane, void **stream) {
+    Model *mm = reinterpret_cast<Model *>(m);
+    if (!mm || !stream) { r3d::set_error("r3d_lane_stream: null argument"); return R3D_ERR_ARG; }
+    if (lane < 0 || lane >= mm->lanes) { r3d::set_error("r3d_lane_stream: lane %d of %d", lane, mm->lanes); return R3D_ERR_ARG; }
+    *stream = mm->lane[lane].stream;
+    return R3D_OK;
+}
+
+int r3d_lanes_join(r3d_model *m, void *stream) {
+    Model *mm = reinterpret_cast<Model *>(m);
+    if (!mm) { r3d::set_error("r3d_lanes_join: null model"); return R3D_ERR_ARG; }
+    for (int k = 0; k < mm->lanes; ++k) {
+        r3d::Model::Lane &ln = mm->lane[k];
+        if (!ln.pending) continue;
+        hipError_t e = hipStreamWaitEvent((hipStream_t)stream, ln.done, 0);
+        if (e != hipSuccess) return r3d::hip_fail(e, "hipStreamWaitEvent(lane)");
+        ln.pending = false;
+    }
+    return R3D_OK;
 }
 
 int r3d_last_clock(r3d_model *m, void *stream, double *ghz) {
@@ -1093,6 +1243,8 @@ int r3d_status(r3d_model *m, void *stream) {
     if (!mm) { r3d::set_error("r3d_status: null model"); return R3D_ERR_ARG; }
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return r3d::hip_fail(e, "hipStreamSynchronize");
+    for (int k = 0; k < mm->lanes; ++k)            // (R3D_OPT_LANES: the forwards ran on the lanes' streams)
+        if ((e = hipStreamSynchronize(mm->lane[k].stream)) != hipSuccess) return r3d::hip_fail(e, "hipStreamSynchronize(lane)");
     if (mm->status_host && *reinterpret_cast<volatile unsigned *>(mm->status_host) != 0u) {
         *reinterpret_cast<volatile unsigned *>(mm->status_host) = 0u;
         r3d::set_error("a dependency wait of the single-launch forward gave up after %d ms (workgroups not co-resident: the GPU is shared "
@@ -1104,7 +1256,7 @@ int r3d_status(r3d_model *m, void *stream) {
 }
 
 const char *r3d_last_error(void) { return r3d::last_error(); }
-const char *r3d_version(void) { return "ray3d_hip 0.5 (gfx950, ABI 5)"; }
+const char *r3d_version(void) { return "ray3d_hip 0.6 (gfx950, ABI 6)"; }
 int r3d_abi_version(void) { return R3D_ABI_VERSION; }
 int r3d_precision(const r3d_model *m) {
     if (!m) { r3d::set_error("r3d_precision: null model"); return R3D_ERR_ARG; }

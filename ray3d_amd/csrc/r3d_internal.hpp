@@ -260,6 +260,14 @@ struct Model {
     int cu_limit = 0;                 // R3D_OPT_CU_LIMIT: CUs of the (masked) stream this handle's forwards run on; 0 = the whole device
     void *last_fwd_stream = nullptr;  // ... the stream of its last masked forward (a second masked stream waits for it: one control region per handle)
     hipEvent_t order_ev = nullptr;
+    // R3D_OPT_LANES = n (2 | 4): n CU-masked streams the LIBRARY owns - lane k: CUs c of every XCD with c % n == k - each with its own
+    // schedules / control regions (Plan::schedules by (B, lane)); the packed weights are this handle's, shared by all lanes.  A forward
+    // whose stream IS a lane's stream runs there; any other stream is served round-robin: the lane waits for the caller's stream,
+    // and the caller's stream waits for the lanes at r3d_lanes_join (or when the same lane comes round again).
+    int lanes = 0;
+    struct Lane { hipStream_t stream = nullptr; hipEvent_t done = nullptr, in = nullptr; bool pending = false; void *for_stream = nullptr; };
+    Lane lane[4];
+    int next_lane = 0;
     const unsigned *last_clk_dev = nullptr;   // the clock stamp of the last single-launch forward (two words of its counter bank: r3d_last_clock)
     unsigned *status_host = nullptr;  // pinned host word the decoder kernel raises when a wait gave up (r3d_status reads and clears it)
     // profiling
@@ -436,6 +444,7 @@ int plan_kind(int64_t B);                       // the plan a call of B windows 
 std::vector<int64_t> plan_kind_edges();         // the largest window count of every plan kind that has one (r3d_workspace_bytes)
 Plan *plan_get(Model *a, Model *b, int kind);
 void plans_drop(const Model *m);   // delete every cached plan (and its schedules) that names `m`
+void lanes_destroy(Model *m);       // R3D_OPT_LANES: the lanes' streams and events (r3d_api.cpp)
 bool plans_pinned(const Model *m); // some schedule of a plan that names `m` is pinned (r3d_prepare: a captured graph may point into it)
 constexpr int STAGE_SPILL_IN = 1 << 30;   // flag on a Plan::stages entry: the spilled rows of that problem
 constexpr int GEMM_SCHED_MAX_UNITS = 6;   // widest tile of r3d_gemm_f32: 6 x 32 rows
@@ -448,11 +457,11 @@ struct SchedProb {
     int row0 = 0;    // first row this launch computes (a multiple of 32): rows [row0, M)
     bool gemv = false;   // M <= GEMV_ROWS rows of a plain layer: 32-column GEMV tiles (tile code ks == 8), r3d_kernels.hip gemv_tile
     bool lat = false;    // ... of up to 32 rows: 32-column latency tiles on the matrix cores (tile code 16), lat_tile
-    bool nb_ok = false;  // a plain fp32 layer of whole 32-column blocks whose single-unit tiles may be 5 - 7 blocks wide (gemm_tile_nb)
+    bool nb_ok = false;  // a plain fp32 layer of whole 32-column blocks whose single-unit tiles may be 4 - 7 blocks wide (gemm_tile_nb)
 };
 constexpr int GEMV_ROWS = 4;          // == GEMV_MAX_M of the kernels (at eight rows the MFMA split-K tiles are the faster ones: 0.207 against 0.222 ms)
 constexpr int COL_GRANULE = 32;       // ready counters and cover checks count columns in granules of this many
-constexpr int NB_CODE = 64;           // tile code NB_CODE + nb: one 32-row unit x nb column blocks of 32, nb = 5 .. 7 (r3d_kernels.hip, gemm_tile_nb)
+constexpr int NB_CODE = 64;           // tile code NB_CODE + nb: one 32-row unit x nb column blocks of 32, nb = 4 .. 7 (r3d_tiles.hpp, gemm_tile_nb)
 constexpr bool tile_is_nb(int ks) { return ks > NB_CODE; }
 constexpr bool tile_is_narrow(int ks) { return ks >= 8 && ks < NB_CODE; }    // GEMV (8) / latency (16) tiles
 constexpr int tile_width(int ks) { return ks > NB_CODE ? (ks - NB_CODE) * 32 : ks >= 8 ? 32 : 256 / ks; }   // columns of a tile by its code
@@ -468,7 +477,8 @@ const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t
 bool schedule_build_fwd(const Plan *pl, int64_t B, int nwg, const std::vector<std::vector<int>> &levels, const std::vector<StageSchedule> &stages,
                         const std::vector<int4> &tiles, const std::vector<int> &wgoff, Schedule::Fwd &fw, std::vector<int> &out_tiles,
                         std::vector<int> &out_wgoff);
-Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin = false);   // nullptr + set_error on failure
+Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin = false, int lane = 0);   // nullptr + set_error on failure
+inline int64_t schedule_key(int64_t B, int lane) { return B | ((int64_t)lane << 48); }    // key of Plan::schedules (lane 0: handles without lanes)
 int device_cu_count();
 
 // kernel launchers (r3d_kernels.hip)

@@ -139,6 +139,7 @@ Model::~Model() {
     if (d_iarena) (void)hipFree(d_iarena);
     if (status_host) (void)hipHostFree(status_host);
     if (order_ev) (void)hipEventDestroy(order_ev);
+    lanes_destroy(this);         // (also takes the lanes' streams off the forward-ordering lists: r3d_api.cpp)
     for (auto &r : recs) {
         (void)hipEventDestroy(r.e0);
         (void)hipEventDestroy(r.e1);

@@ -442,7 +442,7 @@ void pack(const std::vector<SchedProb> &probs, int nbins_max, int max_units, Pac
 }  // namespace
 
 // One-tile-deep launches (the M = B levels of a 256-window call: 160 - 224 whole 32 x 256 tiles for 256 CUs): the launch is
-// as long as one tile whatever the packing, and a quarter of the chip idles.  gemm_tile_nb's tiles of 5 - 7 column blocks are
+// as long as one tile whatever the packing, and a quarter of the chip idles.  gemm_tile_nb's tiles of 4 - 7 column blocks are
 // proportionally shorter, so the eligible problems' rows of N / 32 blocks are cut into more, narrower tiles - one per
 // workgroup - and the rest of the launch (pyramid riders, short layers) is packed classically into the workgroups left.
 // Returns false when that is not shorter than the classic packing by the cost model.
@@ -498,8 +498,8 @@ static bool pack_nb(const std::vector<SchedProb> &probs, int nwg, int max_units,
         for (int t = 0; t < per_row; ++t) {
             const int w = (nblk - b0 + (per_row - t) - 1) / (per_row - t);      // evenly sized, wider ones first
             for (int u = 0; u < units; ++u) {
-                out.a.bins.push_back({Run{i, b0 * 32, w == 8 ? 1 : NB_CODE + w, u, 1, 1}});
-                out.total += w == 8 ? unit_cycles(probs[i].nk, 1) : nb_cycles(probs[i].nk, w);
+                out.a.bins.push_back({Run{i, b0 * 32, NB_CODE + w, u, 1, 1}});          // (4 <= w <= 7: best_nb is 5 .. 7, rows split evenly)
+                out.total += nb_cycles(probs[i].nk, w);
             }
             b0 += w;
         }
@@ -780,11 +780,14 @@ const std::vector<std::vector<int>> *schedule_build_host(const Plan *pl, int64_t
     return levels;
 }
 
-Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
-    auto it = pl->schedules.find(B);
+Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin, int lane) {
+    // (R3D_OPT_LANES: every lane has its own schedule of a batch size - its own tile lists for its share of the CUs and, above all,
+    //  its own control region: forwards of different lanes run at the same time)
+    const int64_t key = schedule_key(B, lane);
+    auto it = pl->schedules.find(key);
     if (it != pl->schedules.end()) {
         // least recently USED goes first: a hit moves the size to the back of the queue
-        auto pos = std::find(pl->schedule_lru.begin(), pl->schedule_lru.end(), B);
+        auto pos = std::find(pl->schedule_lru.begin(), pl->schedule_lru.end(), key);
         if (pos != pl->schedule_lru.end() && pos + 1 != pl->schedule_lru.end()) std::rotate(pos, pos + 1, pl->schedule_lru.end());
         if (pin) it->second->pinned = true;
         return it->second;
@@ -920,8 +923,8 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
                     }
                     fw = Schedule::Fwd();
                     s->pinned = pin;
-                    pl->schedules[B] = s;
-                    pl->schedule_lru.push_back(B);
+                    pl->schedules[key] = s;
+                    pl->schedule_lru.push_back(key);
                     return s;
                 }
             }
@@ -940,8 +943,8 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin) {
         }
     }
     s->pinned = pin;
-    pl->schedules[B] = s;
-    pl->schedule_lru.push_back(B);
+    pl->schedules[key] = s;
+    pl->schedule_lru.push_back(key);
     return s;
 }
 

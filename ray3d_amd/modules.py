@@ -290,6 +290,7 @@ class Ray3DLifter(nn.Module):
         self._ws = _Workspace()
         self._side_ws: list = []
         self._side_streams: list = []
+        self._prepared: set = set()
 
     def receptive_field(self) -> int:
         return self.pos.receptive_field()
@@ -308,12 +309,88 @@ class Ray3DLifter(nn.Module):
         single persistent launch then uses at most `n` workgroups and is not ordered against forwards of other streams.
         For two lifters side by side on disjoint halves of the chip (ray3d_amd.masked_stream) - an experiment reported
         by bench.py --half-chip-streams, not the default path."""
+        self.release_prepared()
         self.pos.set_cu_limit(n)
         self.trj.set_cu_limit(n)
 
+    def set_lanes(self, n: int, device=None):
+        """R3D_OPT_LANES: `n` (2 or 4; 0: off) library-owned CU-masked streams per pair - lane k: the CUs c of every XCD with
+        c % n == k - each with its own tile schedules and control regions, ONE packed weight image for all of them.  For
+        callers with independent batches in flight (the clip evaluation: 240 clips, lib/train_val/trainer.py:295-353): n
+        forwards share the chip side by side.  Use :meth:`lane` to run a clip's forward AND what consumes its poses on a
+        lane's stream; :meth:`join_lanes` makes the current stream wait for all lanes.  A forward issued on any other
+        stream is relayed to the next lane round-robin (its result is ordered behind :meth:`join_lanes`, not behind the call).
+        Both handles are finalised on `device` first (the lanes live on the handles' device)."""
+        dev = torch.device(device) if device is not None else (getattr(self.pos, "_device", None) or torch.device("cuda", torch.cuda.current_device()))
+        n = int(n)
+        n = 0 if n <= 1 else n
+        hp, ht = self.pos.handle(dev), self.trj.handle(dev)
+        self.release_prepared()
+        with torch.cuda.device(dev):
+            hp.set_option(_capi.R3D_OPT_LANES, n)
+            ht.set_option(_capi.R3D_OPT_LANES, n)
+        self._lanes = n
+        self._lane_dev = dev
+        self._lane_streams = [torch.cuda.ExternalStream(hp.lane_stream(k), device=dev) for k in range(n)]
+        self._lane_ws = [_Workspace() for _ in range(n)]
+        self._lane_rr = 0
+        self._lane_pending = [False] * n
+
+    def num_lanes(self) -> int:
+        return getattr(self, "_lanes", 0)
+
+    def lane_stream(self, k: int):
+        """Lane k's stream as a torch.cuda.ExternalStream (library-owned: valid while the pos handle lives)."""
+        return self._lane_streams[k]
+
+    def lane(self, k: Optional[int] = None):
+        """Context manager: lane k's stream (the next lane round-robin when k is None) as the current stream, behind everything
+        the caller's stream holds so far.  Forwards and whatever consumes their outputs inside the block run on that lane; the
+        caller's stream sees the results after :meth:`join_lanes`."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            if not self.num_lanes():
+                yield None
+                return
+            kk = self._lane_rr if k is None else int(k)
+            if k is None:
+                self._lane_rr = (self._lane_rr + 1) % self._lanes
+            st = self._lane_streams[kk]
+            cur = torch.cuda.current_stream(self._lane_dev)
+            if cur.cuda_stream != 0:
+                # (the legacy default stream needs no event: the lanes' streams are blocking streams and behind its work as they
+                #  are - and an event recorded on it would be behind the OTHER lanes' work in flight: the lanes would take turns)
+                st.wait_stream(cur)
+            self._lane_pending[kk] = True
+            with torch.cuda.stream(st):
+                yield kk
+        return _cm()
+
+    def join_lanes(self):
+        """The current stream waits for every lane that has run something since the last join (device-side)."""
+        if not self.num_lanes():
+            return
+        cur = torch.cuda.current_stream(self._lane_dev)
+        for kk, st in enumerate(self._lane_streams):
+            if self._lane_pending[kk]:
+                cur.wait_stream(st)
+                self._lane_pending[kk] = False
+        self.pos.handle(self._lane_dev).lanes_join(cur.cuda_stream)      # (forwards the library itself relayed from this stream)
+
+    def _lane_of_current_stream(self, dev):
+        if not self.num_lanes():
+            return None
+        cur = torch.cuda.current_stream(dev).cuda_stream
+        for kk, st in enumerate(self._lane_streams):
+            if st.cuda_stream == cur:
+                return kk
+        return None
+
     def check_status(self, device=None) -> None:
         """Synchronise and raise if a forward of the pair gave up waiting for its own tiles (the pair's flag lives in the
-        pos handle)."""
+        pos handle; with lanes r3d_status waits for the lanes' streams too)."""
         self.pos.check_status(device)
 
     def checked(self, fn, device=None):
@@ -322,6 +399,7 @@ class Ray3DLifter(nn.Module):
         process's kernel on the same GPU can prevent - the pair is switched to the level-by-level form for good, `fn` runs
         once more, and only a second failure raises: two processes lifting on one device both get correct outputs."""
         out = fn()
+        self.join_lanes()
         dev = device if device is not None else (out.device if torch.is_tensor(out) else getattr(self.pos, "_device", None))
         try:
             self.check_status(dev)
@@ -332,6 +410,7 @@ class Ray3DLifter(nn.Module):
                           "switching this lifter to the level-by-level form (R3D_OPT_STAGED) and repeating the call")
             self.set_staged(True)
         out = fn()
+        self.join_lanes()
         self.check_status(dev)
         return out
 
@@ -346,6 +425,19 @@ class Ray3DLifter(nn.Module):
         if out is None:
             out = torch.empty((B, 1, self.pos.num_joints_in, 3), dtype=torch.float32, device=dev)
         out_trj = torch.empty((B, 1, 1, 3), dtype=torch.float32, device=dev) if return_trj else None
+        if workspace is None and self.num_lanes():
+            # one workspace per lane (forwards of different lanes are in flight together); a forward on a stream that is no lane's
+            # is run on the next lane here, exactly as the library would relay it - so that the workspace is that lane's
+            kk = self._lane_of_current_stream(dev)
+            if kk is None:
+                caller = torch.cuda.current_stream(dev)
+                with self.lane() as k2:
+                    res = self._run(mode, x, window_stride, B, param, param_stride, cam, cam_stride, return_trj, out, self._lane_ws[k2])
+                for t in (res if isinstance(res, tuple) else (res,)):
+                    if t is not None:
+                        t.record_stream(caller)        # (allocated under the lane's stream, consumed on the caller's after join_lanes)
+                return res
+            workspace = self._lane_ws[kk]
         ws = (workspace or self._ws).get(_capi.workspace_bytes(hp, ht, B), dev)
         inp = _capi.make_input(mode, x.data_ptr(), window_stride,
                                param.data_ptr() if param is not None else None, param_stride,
@@ -472,6 +564,18 @@ class Ray3DLifter(nn.Module):
         with torch.cuda.device(dev):
             for b in batch_sizes:
                 _capi.prepare(hp, ht, int(b))
+                self._prepared.add((dev, int(b)))
+
+    def release_prepared(self):
+        """r3d_release every batch size this lifter has prepared (nothing captured into a hipGraph may still point into them): what
+        set_lanes / set_cu_limit do before they change how schedules are cut - the library refuses to drop pinned schedules."""
+        for dev, b in sorted(self._prepared, key=lambda t: t[1]):
+            try:
+                with torch.cuda.device(dev):
+                    _capi.release(self.pos.handle(dev), self.trj.handle(dev), b)
+            except _capi.Ray3DHipError:
+                pass
+        self._prepared.clear()
 
     def forward_uv(self, uv: torch.Tensor, cam_rows: torch.Tensor, param: Optional[torch.Tensor] = None,
                    window_stride: Optional[int] = None):

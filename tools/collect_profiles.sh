@@ -1,7 +1,7 @@
 #!/bin/bash
 # gpurun_out/<round>_* (tools/final_measure.sh) -> profiles/: the committed summaries, then profiles/pmc.json
 cd /root/repo
-RND=${RND:-r05}
+RND=${RND:-r06}
 for d in gpurun_out/${RND}_*/; do
   n=$(basename $d)
   mkdir -p profiles/$n
