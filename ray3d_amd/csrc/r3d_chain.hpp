@@ -25,6 +25,15 @@
 // Measured stand-alone (tools/chain_probe4.cpp -DLOADER_DMA=1): 71.2 us per 64-row tile against ~79 for first_level_taps.
 #pragma once
 
+#ifndef R3D_CHAIN_V
+#define R3D_CHAIN_V 2           // 0: round 6's first form; 1: + no vmcnt wait with a write-through store pending; 2: + bias quads two half groups ahead
+#endif
+#ifndef R3D_CHAIN_ABL
+#define R3D_CHAIN_ABL 0         // ablations (wrong results, timing only): 1 loaders request nothing, 2 no output stores, 4 no gathers, 8 no bias loads
+#endif
+// s_waitcnt vmcnt(0) as an INSTRUCTION THE COMPILER SEES (its wait-count pass clears its scoreboard; an asm string would not):
+// gfx9 encoding vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14]
+#define CHAIN_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
 constexpr int CHAIN_SLAB_FLOATS = 4096;                     // 16 KiB: 16 fragments of 1 KiB
 constexpr int CHAIN_NSTAGE = 6;                             // ring stages: one being read, one ahead of it, one landed, three in flight (96 KiB)
 constexpr int CHAIN_NCB = 16;                               // channel blocks of 16: C = 256
@@ -75,10 +84,14 @@ __device__ __forceinline__ void first_level_chain(ProbRef P, const int4 *tile_li
             }
             const int off = __builtin_amdgcn_readfirstlane(s * SLAB_FLOATS * 4);
             float *d = smem + stage * SLAB_FLOATS + lw * 1024;
+#if !(R3D_CHAIN_ABL & 1)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void *)(d + i * 256), 16, lane * 16,
                                                          off + (lw * 1024 + i * 256) * 4, 0, 0);
+#else
+            (void)off; (void)d;
+#endif
             pos = pos + 1 == SLABS_PER_TILE ? 0 : pos + 1;
             stage = stage + 1 == NSTAGE ? 0 : stage + 1;
         };
@@ -122,7 +135,11 @@ __device__ __forceinline__ void first_level_chain(ProbRef P, const int4 *tile_li
     auto rsrc_of = [](const float *p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, 0x7fffffff, 0x00020000); };
     const __amdgpu_buffer_rsrc_t rb0 = rsrc_of(P.bias), rb1 = rsrc_of(P.bias2), rb2 = rsrc_of(P.bias3);
     auto bias_quad = [&](__amdgpu_buffer_rsrc_t rs, int cb) {      // channels 16 cb + 4 g .. + 3: the lane's registers of block cb
+#if R3D_CHAIN_ABL & 8
+        return f32x4{0.f, 0.f, 0.f, 0.f};
+#else
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * g, cb * 64, 0));
+#endif
     };
     f32x4 wq[2][4];                                             // weight fragments of the current / the next half group
     f32x4 DA[NCB], DB[NCB], O[2][4];     // expand_conv activations (the residual after the last tap) | 3-tap sums | 1x1 outputs of two block groups
@@ -148,7 +165,11 @@ __device__ __forceinline__ void first_level_chain(ProbRef P, const int4 *tile_li
     cur_mask = __builtin_amdgcn_readfirstlane(cur_mask);
     auto gather_one = [&](int tap, int i) {
         const unsigned base = (cur_mask >> i) & 1u ? b_cur : b_first + (unsigned)(tap * 3 * P.enc_jf) * 4u;
+#if R3D_CHAIN_ABL & 4
+        xv[i] = __builtin_bit_cast(float, base);
+#else
         xv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, base + (unsigned)(lq[i >> 2][i & 3] & ~3), 0, 0));
+#endif
     };
     static_assert(K0 == 64, "the gather below walks 16 columns per lane in four table quads");
     auto tap_of = [&](int ts) { return ts == 0 ? 0 : ts == 2 ? res_tap : 3 - res_tap; };   // the residual tap comes last
@@ -209,7 +230,8 @@ __device__ __forceinline__ void first_level_chain(ProbRef P, const int4 *tile_li
         rec(rec, ChainIC<0>{});
     };
     auto d_elem = [&](const f32x4 (&D)[NCB], int step) { return D[step >> 2][step & 3]; };
-    f32x4 bq, bq2;                                             // bias quads in flight
+    f32x4 bqr[3];                                              // bias quads in flight
+    f32x4 &bq = bqr[0], &bq2 = bqr[1];
 #ifdef R3D_TIMING
     const long long t_entry = wall_clock64();
 #endif
@@ -271,6 +293,7 @@ __device__ __forceinline__ void first_level_chain(ProbRef P, const int4 *tile_li
                 }
                 if (MS == SL_C - 1 && p == 40) bq = bias_quad(rb1, 0);
                 if (MS == SL_C - 1 && p == 41) bq2 = bias_quad(rb1, 1);
+                if (R3D_CHAIN_V >= 2 && MS == SL_C - 1 && p == 42) bqr[2] = bias_quad(rb1, 2);
             });
         }
 #ifdef R3D_TIMING
@@ -287,7 +310,11 @@ __device__ __forceinline__ void first_level_chain(ProbRef P, const int4 *tile_li
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = lrelu(O[G & 1][f][r] + ob[f][r], slope2) + DA[cb][r];
             // (write-through: the consumer is another workgroup, mostly on another XCD)
+#if R3D_CHAIN_ABL & 2
+            asm volatile("" :: "v"(v));
+#else
             if (row_ok) act_store4(crs, o_voff + cb * 64, v);
+#endif
         };
         auto group_rec = [&](auto self, auto g_tag) {
             constexpr int G = decltype(g_tag)::value;
@@ -300,16 +327,31 @@ __device__ __forceinline__ void first_level_chain(ProbRef P, const int4 *tile_li
                             if (G == 0) {
                                 const int hg = p >> 4, nb = 4 * MS + hg + 1;
                                 if (nb < NCB) {
+#if R3D_CHAIN_V >= 2
+                                    // block nb's quad was requested two half groups ago (slot nb % 3: 36 MFMAs = 0.5 us; one half group -
+                                    // 0.2 us, an L2 round trip on an idle chip - stalled the matrix pipe inside the forward)
+                                    if ((p & 15) == 2 && nb + 2 < NCB) bqr[(nb + 2) % 3] = bias_quad(rb1, nb + 2);
+                                    if ((p & 15) == 6) {
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r) DB[nb][r] = lrelu(DB[nb][r] + bqr[nb % 3][r], slope1);
+                                    }
+#else
                                     if ((p & 15) == 2) { bq = bq2; if (nb + 1 < NCB) bq2 = bias_quad(rb1, nb + 1); }
                                     if ((p & 15) == 6) {
 #pragma unroll
                                         for (int r = 0; r < 4; ++r) DB[nb][r] = lrelu(DB[nb][r] + bq[r], slope1);
                                     }
+#endif
                                 }
                             }
-                            // the previous group's epilogue (its bias quads were requested in that group's last slab)
+                            // the previous group's epilogue (its bias quads were requested in that group's last slab).  On gfx9 loads and
+                            // stores share vmcnt and may complete out of order with each other: a wait for a LOAD with a store pending is
+                            // compiled as a wait for the store too - a write-through store's trip to memory inside the MFMA stream, twice per
+                            // group.  So: every load this wavefront has in flight is waited for BEFORE the group's first store.
+                            if (R3D_CHAIN_V >= 1 && G > 0 && MS == 0 && p == 8) CHAIN_WAIT_VM0();
                             if (G > 0 && MS == 0 && p >= 8 && p < 40 && (p & 7) == 2) out_block(G - 1, (p - 8) >> 3);
-                            if (MS == 3 && p >= 48 && p < 52) ob[p - 48] = bias_quad(rb2, 4 * G + (p - 48));
+                            if (R3D_CHAIN_V >= 1) { if (MS == 3 && p >= 16 && p < 20) ob[p - 16] = bias_quad(rb2, 4 * G + (p - 16)); }
+                            else if (MS == 3 && p >= 48 && p < 52) ob[p - 48] = bias_quad(rb2, 4 * G + (p - 48));
                         });
                         self2(self2, ChainIC<MS + 1>{});
                     }
@@ -322,6 +364,7 @@ __device__ __forceinline__ void first_level_chain(ProbRef P, const int4 *tile_li
 #ifdef R3D_TIMING
         if (dbg && tid == 0) dbg[3] = wall_clock64();
 #endif
+        if (R3D_CHAIN_V >= 1) CHAIN_WAIT_VM0();               // (as above: the last group's quads, before its stores)
 #pragma unroll
         for (int f = 0; f < 4; ++f) out_block(NCB / 4 - 1, f);
         // ---- the tile is finished when its write-through stores have left the CU: drain, everyone, one add per 32-row unit
