@@ -204,6 +204,11 @@ int r3d_status(r3d_model *m, void *hip_stream);
                                    *  - any other stream: lanes are served round-robin; the lane's stream waits for everything the
                                    *    caller's stream holds so far, runs the forward, and the caller's stream sees the outputs
                                    *    after r3d_lanes_join(m, stream) - NOT at return as without lanes.
+                                   *    (a caller on the LEGACY DEFAULT stream: the lanes' streams are blocking streams - they are
+                                   *    behind the default stream's work without an event, and none is recorded there, because an
+                                   *    event on the default stream is behind every blocking stream's work: the lanes would take
+                                   *    turns.  For the same reason any work issued on the default stream between two lanes'
+                                   *    forwards serialises them - drive a lane loop from a stream of your own.)
                                    * One workspace per lane in flight (the caller's, as always).  Set it on both handles of a pair,
                                    * after r3d_finalize; it waits for the device, drops cached schedules and fails with
                                    * R3D_ERR_STATE while prepared (pinned) schedules exist.  r3d_prepare prepares every lane.

@@ -1471,7 +1471,7 @@ def test_bench_under_the_drivers_launcher_with_one_rank(mode):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    extra = ["--no-cpu-baseline", "--no-bf16x3", "--no-shipped-cfgs", "--no-b1024"] if mode == "windows" else ["--mode", "eval", "--clips", "6"]
+    extra = ["--no-cpu-baseline", "--no-bf16x3", "--no-shipped-cfgs", "--no-b1024", "--no-c1024"] if mode == "windows" else ["--mode", "eval", "--clips", "6"]
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"] + extra,
                          env=env, capture_output=True, text=True, timeout=900)
@@ -1480,6 +1480,11 @@ def test_bench_under_the_drivers_launcher_with_one_rank(mode):
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["world_size_observed"] == 1
     if mode == "windows":
         assert line["parity_max_abs_err"] <= 1e-4 and len(line["config"]["ms_per_step_per_rank"]) == 1
+        # the driver's multi-GPU command carries north_star's split: the 240-clip set sharded over the ranks + ONE all_gather
+        ep = line["eval_pass"]
+        assert ep["world_size_observed"] == 1 and ep["backend"] == "nccl" and ep["clips"] == 240 and ep["value"] > 0
+        assert len(ep["shard_frames"]) == 1 and len(ep["pass_ms_per_rank"]) == 1 and ep["pass_ms_imbalance"] == 1.0
+        assert ep["all_gather_ms"] >= 0 and ep["mpjpe_mm"]["checksum"] > 0 and ep["scaling"] == "strong"
     else:
         assert line["config"]["shard_imbalance"] == 1.0 and len(line["config"]["pass_ms_per_rank"]) == 1
 
