@@ -497,6 +497,8 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
         const int last2 = nk2 - 1;
         auto k_tile2 = [&](int kt2, f32x4 (&w_use)[4], f32x4 (&w_load)[4]) {
             load_w2(kt2 + 2 < last2 ? kt2 + 2 : last2, w_load);
+            // (pinned, as in first_level_taps: the scheduler would sink the request to its use)
+            __builtin_amdgcn_sched_barrier(0);
             const float *s = h_frag + kt2 * BK;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1541,6 +1543,7 @@ __device__ __forceinline__ void enc_tile(ProbRef P, const int row0, const int co
     const int last = nk - 1;
     auto k_tile = [&](int kt, f32x4 (&w_use)[4], f32x4 (&w_load)[4]) {
         load_w(kt + 1 < last ? kt + 1 : last, w_load);
+        __builtin_amdgcn_sched_barrier(0);                    // (pinned, as in first_level_taps: the scheduler would sink the request to its use)
         const float *s = a_frag + kt * BK;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1698,6 +1701,13 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
     int phase = 0;                                           // parity selects the G buffer
     auto tap_of = [&](int ts) { return ts == 0 ? 0 : ts == 2 ? res_tap : 3 - res_tap; };   // the residual tap comes last
     issue_phase(__builtin_amdgcn_readfirstlane(tile_list[0].y), 0, 0);
+#ifdef R3D_DEFER_SIGNAL
+    // Deferred hand-off: a tile that is not the run's last one does not drain its write-through stores and signal at its end (every
+    // wavefront idle for a store's trip to memory, plus a barrier) - the NEXT tile does, in front of its second barrier, by
+    // which time the stores have had its first expand_conv phase to finish.  (The next tile's first write to H comes behind its own
+    // first barrier, so H needs no barrier of its own either.)
+    int pend_base = -1, pend_add = 0;
+#endif
 #pragma unroll 1
     for (int ti = 0; ti < ntiles; ++ti) {
         const int row0 = __builtin_amdgcn_readfirstlane(tile_list[ti * tstride].y);
@@ -1780,7 +1790,16 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
                     wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = v;
                 }
             }
+#ifdef R3D_DEFER_SIGNAL
+            if (ts == 0 && pend_base >= 0) tile_drain();     // (uniform; the previous tile's stores - and this tap's weight requests, needed next)
+#endif
             __syncthreads();
+#ifdef R3D_DEFER_SIGNAL
+            if (ts == 0 && pend_base >= 0) {
+                tile_signal(cnt, pend_base, pend_add, MI);
+                pend_base = -1;
+            }
+#endif
             if (ts == R3D_TS) R3D_TSTAMP(6);
             // ---- this tap's third of the 3-tap convolution: K = C, barrier-free, weights two K tiles ahead
             {
@@ -1788,6 +1807,9 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
                 const int kbase = tap * tiles_per_tap, lastk = tiles_per_tap - 1;
                 auto k_tile1 = [&](int kin, f32x4 (&w_use)[4], f32x4 (&w_load)[4]) {
                     load_frag(w1rsrc, kbase + (kin + 2 < lastk ? kin + 2 : lastk), w_load);
+                    // (pinned: left to itself the scheduler sinks these requests to their uses - one group of 8 MFMAs ahead instead of two K tiles, and
+                    //  `s_waitcnt vmcnt(0)` four times per iteration; same registers, same results, -0.6 .. 0.9 % at 1024 windows: profiles/r06_pin_prefetch/)
+                    __builtin_amdgcn_sched_barrier(0);
                     const float *sp = h_frag + kin * BK;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -1844,6 +1866,9 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
             const int last2 = nk2 - 1;
             auto k_tile2 = [&](int kt, f32x4 (&w_use)[4], f32x4 (&w_load)[4]) {
                 load_frag(w2rsrc, kt + 2 < last2 ? kt + 2 : last2, w_load);
+                // (pinned: left to itself the scheduler sinks these requests to their uses - one group of 8 MFMAs ahead instead of two K tiles, and
+                //  `s_waitcnt vmcnt(0)` four times per iteration; same registers, same results, -0.6 .. 0.9 % at 1024 windows: profiles/r06_pin_prefetch/)
+                __builtin_amdgcn_sched_barrier(0);
                 const float *sp = h_frag + kt * BK;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -1888,6 +1913,11 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
             const int rd_row = tid >> 6, rd_c4 = (tid & 63) * 4;
             const int N = P.N, ldc = P.ldc;
             const __amdgpu_buffer_rsrc_t crs = act_rsrc(P.c + (size_t)row0 * ldc);
+#ifdef R3D_DEFER_SIGNAL
+            // every load in flight (the next tile's first raw values: requested a tap ago) is waited for BEFORE the stores: on gfx9 a
+            // wait for a load with a store pending is compiled as a wait for the store (shared vmcnt, out of order with each other)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
 #pragma unroll
             for (int j = 0; j < 4 * MI; ++j) {
                 const int lr = rd_row + 8 * j, row = row0 + lr;
@@ -1902,11 +1932,20 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
                 }
             }
         }
-        if (cnt) tile_drain();
-        __syncthreads();                                     // H is free for the next tile's activations
-        if (cnt) {
-            const int4 te = tile_list[ti * tstride + 1];     // {dependencies (none), first ready counter, granules, -}
-            tile_signal(cnt, __builtin_amdgcn_readfirstlane(te.y), __builtin_amdgcn_readfirstlane(te.z), MI);
+#ifdef R3D_DEFER_SIGNAL
+        if (cnt && ti + 1 < ntiles) {
+            const int4 te = tile_list[ti * tstride + 1];
+            pend_base = __builtin_amdgcn_readfirstlane(te.y);
+            pend_add = __builtin_amdgcn_readfirstlane(te.z);
+        } else
+#endif
+        {
+            if (cnt) tile_drain();
+            __syncthreads();                                 // H is free for the next tile's activations
+            if (cnt) {
+                const int4 te = tile_list[ti * tstride + 1];     // {dependencies (none), first ready counter, granules, -}
+                tile_signal(cnt, __builtin_amdgcn_readfirstlane(te.y), __builtin_amdgcn_readfirstlane(te.z), MI);
+            }
         }
         R3D_TSTAMP(4);
     }
@@ -2044,6 +2083,8 @@ __device__ __forceinline__ void first_level_shared(ProbRef P, const int4 *tile_l
                 const int kbase = tap * tiles_per_tap, lastk = tiles_per_tap - 1;
                 auto k_tile1 = [&](int kin, f32x4 (&w_use)[4], f32x4 (&w_load)[4]) {
                     load_frag(w1rsrc, kbase + (kin + 2 < lastk ? kin + 2 : lastk), w_load);
+                    // (pinned, as in first_level_taps)
+                    __builtin_amdgcn_sched_barrier(0);
                     const float *sp = h_frag + kin * BK;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -2092,6 +2133,8 @@ __device__ __forceinline__ void first_level_shared(ProbRef P, const int4 *tile_l
             const int last2 = nk2 - 1;
             auto k_tile2 = [&](int kt, f32x4 (&w_use)[4], f32x4 (&w_load)[4]) {
                 load_frag(w2rsrc, kt + 2 < last2 ? kt + 2 : last2, w_load);
+                // (pinned, as in first_level_taps)
+                __builtin_amdgcn_sched_barrier(0);
                 const float *sp = h_frag + kt * BK;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
