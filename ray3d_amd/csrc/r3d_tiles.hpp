@@ -1701,13 +1701,6 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
     int phase = 0;                                           // parity selects the G buffer
     auto tap_of = [&](int ts) { return ts == 0 ? 0 : ts == 2 ? res_tap : 3 - res_tap; };   // the residual tap comes last
     issue_phase(__builtin_amdgcn_readfirstlane(tile_list[0].y), 0, 0);
-#ifdef R3D_DEFER_SIGNAL
-    // Deferred hand-off: a tile that is not the run's last one does not drain its write-through stores and signal at its end (every
-    // wavefront idle for a store's trip to memory, plus a barrier) - the NEXT tile does, in front of its second barrier, by
-    // which time the stores have had its first expand_conv phase to finish.  (The next tile's first write to H comes behind its own
-    // first barrier, so H needs no barrier of its own either.)
-    int pend_base = -1, pend_add = 0;
-#endif
 #pragma unroll 1
     for (int ti = 0; ti < ntiles; ++ti) {
         const int row0 = __builtin_amdgcn_readfirstlane(tile_list[ti * tstride].y);
@@ -1790,16 +1783,7 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
                     wr[((r & 3) + 8 * (r >> 2)) * PAIR_LD] = v;
                 }
             }
-#ifdef R3D_DEFER_SIGNAL
-            if (ts == 0 && pend_base >= 0) tile_drain();     // (uniform; the previous tile's stores - and this tap's weight requests, needed next)
-#endif
             __syncthreads();
-#ifdef R3D_DEFER_SIGNAL
-            if (ts == 0 && pend_base >= 0) {
-                tile_signal(cnt, pend_base, pend_add, MI);
-                pend_base = -1;
-            }
-#endif
             if (ts == R3D_TS) R3D_TSTAMP(6);
             // ---- this tap's third of the 3-tap convolution: K = C, barrier-free, weights two K tiles ahead
             {
@@ -1913,11 +1897,6 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
             const int rd_row = tid >> 6, rd_c4 = (tid & 63) * 4;
             const int N = P.N, ldc = P.ldc;
             const __amdgpu_buffer_rsrc_t crs = act_rsrc(P.c + (size_t)row0 * ldc);
-#ifdef R3D_DEFER_SIGNAL
-            // every load in flight (the next tile's first raw values: requested a tap ago) is waited for BEFORE the stores: on gfx9 a
-            // wait for a load with a store pending is compiled as a wait for the store (shared vmcnt, out of order with each other)
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-#endif
 #pragma unroll
             for (int j = 0; j < 4 * MI; ++j) {
                 const int lr = rd_row + 8 * j, row = row0 + lr;
@@ -1932,20 +1911,11 @@ __device__ __forceinline__ void first_level_taps(ProbRef P, const int4 *tile_lis
                 }
             }
         }
-#ifdef R3D_DEFER_SIGNAL
-        if (cnt && ti + 1 < ntiles) {
-            const int4 te = tile_list[ti * tstride + 1];
-            pend_base = __builtin_amdgcn_readfirstlane(te.y);
-            pend_add = __builtin_amdgcn_readfirstlane(te.z);
-        } else
-#endif
-        {
-            if (cnt) tile_drain();
-            __syncthreads();                                 // H is free for the next tile's activations
-            if (cnt) {
-                const int4 te = tile_list[ti * tstride + 1];     // {dependencies (none), first ready counter, granules, -}
-                tile_signal(cnt, __builtin_amdgcn_readfirstlane(te.y), __builtin_amdgcn_readfirstlane(te.z), MI);
-            }
+        if (cnt) tile_drain();
+        __syncthreads();                                     // H is free for the next tile's activations
+        if (cnt) {
+            const int4 te = tile_list[ti * tstride + 1];     // {dependencies (none), first ready counter, granules, -}
+            tile_signal(cnt, __builtin_amdgcn_readfirstlane(te.y), __builtin_amdgcn_readfirstlane(te.z), MI);
         }
         R3D_TSTAMP(4);
     }
