@@ -2710,6 +2710,41 @@ __device__ __forceinline__ void lat_tile(ProbRef P, const int col0, float *smem,
 // Spins are bounded: after ~1 s without progress the wavefront raises the launch's abort flag and goes on; every later
 // wait sees the flag and returns at once, the decoder kernel turns the outputs into NaN, nothing hangs.
 typedef const FwdArgs __attribute__((address_space(4))) *FwdArgsPtr;
+// wait_deps on a descriptor a wavefront already holds (lane i = descriptor int i: ONE load for the whole descriptor in front of the tile
+// instead of dependent round trips for its header, its dependency list and then the counters)
+__device__ __forceinline__ void wait_deps_reg(const int dw, const int ndep, const gu32 cnt, const gu32 abort_flag, const long long spin_ticks) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int total = 0;
+        for (int d = 0; d < ndep; ++d) total += __builtin_amdgcn_readlane(dw, 9 + 2 * d) & 0xffff;
+        for (int off = 0; off < total; off += 64) {
+            int idx = -1, acc = 0;
+            unsigned need = 0;
+            for (int d = 0; d < ndep; ++d) {
+                const int base = __builtin_amdgcn_readlane(dw, 8 + 2 * d), nw = __builtin_amdgcn_readlane(dw, 9 + 2 * d);
+                const int n = nw & 0xffff, l = lane + off - acc;
+                if (l >= 0 && l < n) { idx = base + l; need = (unsigned)nw >> 16; }
+                acc += n;
+            }
+            long long t_first = 0;
+            for (unsigned spins = 1;; ++spins) {
+                const unsigned v = idx >= 0 ? __hip_atomic_load(cnt + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
+                if (__all(v >= need)) break;
+                __builtin_amdgcn_s_sleep(4);
+                if ((spins & 31) == 0) {
+                    if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    const long long now = wall_clock64();
+                    if (t_first == 0) t_first = now;
+                    else if (now - t_first > spin_ticks) {
+                        if (lane == 0) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
 __device__ __forceinline__ void wait_deps(const int4 *tile, const int ndep, const gu32 cnt, const gu32 abort_flag, const long long spin_ticks) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
@@ -2943,7 +2978,18 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
     int prev_pi = -1;
     int plain_seen = 0, gemv_seen = 0;       // (test hook: this workgroup's tiles so far, per kind)
     for (int t = t0; t < t1; ++t) {
-        const int4 td = tiles[t * TS];
+        // the whole descriptor (24 ints) in ONE load per wavefront, lane i = int i: header, signal fields and dependency list come out of it
+        // with v_readlane - no second and third round trip before the counters can be asked for (-0.2 .. 0.3 % of the forward, six A/B
+        // rounds: profiles/r06_desc_one_load/)
+        int dw = 0;
+        if constexpr (DEP) {
+            int dl = threadIdx.x & 63;
+            asm volatile("" : "+v"(dl));
+            dw = reinterpret_cast<const int *>(tiles + t * TS)[dl < FWD_TILE_INT4 * 4 ? dl : 0];
+        }
+        int4 td;
+        if constexpr (DEP) td = make_int4(__builtin_amdgcn_readlane(dw, 0), __builtin_amdgcn_readlane(dw, 1), __builtin_amdgcn_readlane(dw, 2), __builtin_amdgcn_readlane(dw, 3));
+        else td = tiles[t * TS];
         const int pi = __builtin_amdgcn_readfirstlane(td.x & 0xff);
         const bool new_prob = pi != prev_pi;
         prev_pi = pi;
@@ -2954,7 +3000,7 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
         int sig_base = 0, sig_add = 0, tflags = 0;
         TileDeps tdep{nullptr, 0, nullptr, nullptr, false, nullptr, 0};
         if constexpr (DEP) {
-            const int4 te = tiles[t * TS + 1];
+            const int4 te = make_int4(__builtin_amdgcn_readlane(dw, 4), __builtin_amdgcn_readlane(dw, 5), __builtin_amdgcn_readlane(dw, 6), __builtin_amdgcn_readlane(dw, 7));
             const int ndep = __builtin_amdgcn_readfirstlane(te.x);
             sig_base = __builtin_amdgcn_readfirstlane(te.y);
             sig_add = __builtin_amdgcn_readfirstlane(te.z);
@@ -2963,7 +3009,7 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
             if (dbg_arg && threadIdx.x == 0) dbg_arg[16384 + (long long)t * 4 + 0] = wall_clock64();      // tile fetched
 #endif
             // (GEMV / latency tiles wait themselves, behind their weight requests)
-            if (ndep > 0 && (!NARROW || !tile_is_narrow(ks))) wait_deps(tiles + t * TS, ndep, cnt, abort_flag, fargs->spin_ticks);
+            if (ndep > 0 && (!NARROW || !tile_is_narrow(ks))) wait_deps_reg(dw, ndep, cnt, abort_flag, fargs->spin_ticks);
 #ifdef R3D_TIMING
             if (dbg_arg && threadIdx.x == 0) dbg_arg[16384 + (long long)t * 4 + 1] = wall_clock64();      // producers ready
 #endif
