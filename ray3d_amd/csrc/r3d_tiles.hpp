@@ -70,6 +70,10 @@ __device__ __forceinline__ void gstore1(float *p, float v) { *(R3D_AS1 float *)p
 constexpr int ACT_AUX = 16;                  // aux bits of the buffer builtins: sc1
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned R3D_AS1 *gu32;
+// Single-launch form: a tile's wait for its producers, carried INTO the tile: the tile requests its first weight
+// fragments - which depend on no producer - and only then asks for the ready counters (r3d_tiles.hpp: wait_deps_reg)
+struct LateWait { int dw, ndep; gu32 cnt, abort_flag; long long spin_ticks; };
+__device__ __forceinline__ void wait_deps_reg(const int dw, const int ndep, const gu32 cnt, const gu32 abort_flag, const long long spin_ticks);
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t act_rsrc(const float *base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
 }
@@ -215,7 +219,7 @@ __device__ __forceinline__ void store_tile(ProbRef P, const f32x16 (&acc)[MI], c
 constexpr int PAIR_LD = GEMM_BN + 4;                                     // 260 floats per row of the intermediate tile
 constexpr int PAIR_MAX_MI = 4;                                           // 128 x 260 floats = 133,120 B of LDS
 template <int MI, int KS, bool PAIR = false>
-__device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int col0, float *smem, long long *dbg) {
+__device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int col0, float *smem, long long *dbg, const LateWait late = LateWait{0, 0, nullptr, nullptr, 0}) {
     static_assert(!PAIR || (KS == 1 && MI <= PAIR_MAX_MI), "fused pairs are whole tiles of at most 128 rows");
     constexpr int SF = STAGE_FLOATS;        // floats per LDS ring stage
     R3D_TSTAMP(0);
@@ -340,6 +344,7 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
     const int last = nk - 1;
     load_w(0, rb);
     if (WD2) load_w(1 < last ? 1 : last, rbn);
+    if (late.ndep > 0) wait_deps_reg(late.dw, late.ndep, late.cnt, late.abort_flag, late.spin_ticks);   // (uniform; the activations below are the producers' outputs)
     {
         Staged r0, r1;                      // all prologue tiles in flight at once: one HBM latency, not four
         issue_a(0, r0);
@@ -545,7 +550,7 @@ __device__ __forceinline__ void gemm_tile(ProbRef P, const int row0, const int c
 // before the epilogue (as the split-K tiles do).  Operand paths as in gemm_tile<1, 1>: A through the three-stage ring,
 // weights fragment-ordered straight into VGPRs two K tiles ahead (a split block's wavefront requests its own q only).
 template <int NB>
-__device__ __forceinline__ void gemm_tile_nb(ProbRef P, const int row0, const int col0, float *smem, long long *dbg) {
+__device__ __forceinline__ void gemm_tile_nb(ProbRef P, const int row0, const int col0, float *smem, long long *dbg, const LateWait late = LateWait{0, 0, nullptr, nullptr, 0}) {
     static_assert(NB >= 4 && NB <= 7, "NB = 8 is gemm_tile<1, 1>");   // (NB = 4: the narrow end of an uneven row - wavefronts 4-7 only stage)
     constexpr int SF = STAGE_FLOATS;
     constexpr int NX = NB - 4;               // quarter-blocks per extra wavefront
@@ -629,6 +634,7 @@ __device__ __forceinline__ void gemm_tile_nb(ProbRef P, const int row0, const in
         };
         load_w(0, rb);
         load_w(1 < last ? 1 : last, rbn);
+        if (late.ndep > 0) wait_deps_reg(late.dw, late.ndep, late.cnt, late.abort_flag, late.spin_ticks);
         {
             f32x4 r0, r1;
             issue_a(0, r0);
@@ -2998,6 +3004,7 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
         const int col0 = __builtin_amdgcn_readfirstlane(td.z);
         const int ks = __builtin_amdgcn_readfirstlane(td.w);      // split-K factor of this tile (1, 2 or 4)
         int sig_base = 0, sig_add = 0, tflags = 0;
+        LateWait late{0, 0, nullptr, nullptr, 0};
         TileDeps tdep{nullptr, 0, nullptr, nullptr, false, nullptr, 0};
         if constexpr (DEP) {
             const int4 te = make_int4(__builtin_amdgcn_readlane(dw, 4), __builtin_amdgcn_readlane(dw, 5), __builtin_amdgcn_readlane(dw, 6), __builtin_amdgcn_readlane(dw, 7));
@@ -3009,7 +3016,18 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
             if (dbg_arg && threadIdx.x == 0) dbg_arg[16384 + (long long)t * 4 + 0] = wall_clock64();      // tile fetched
 #endif
             // (GEMV / latency tiles wait themselves, behind their weight requests)
-            if (ndep > 0 && (!NARROW || !tile_is_narrow(ks))) wait_deps_reg(dw, ndep, cnt, abort_flag, fargs->spin_ticks);
+#ifndef R3D_TIMING
+            // plain / split-K / pair / narrow-column tiles wait inside, behind their first weight requests: a dependency hop is on the
+            // critical path of a 256-window call thirteen times, and the weights' round trip now overlaps the counters' (-1.7 % at 256
+            // windows, -0.2 % at 1024, six same-box rounds: profiles/r06_late_wait/).  First-level and gathered tiles have no producers;
+            // the bf16x3 tiles and the timing build - whose "producers ready" stamp is taken here - keep the wait in front.
+            constexpr bool LATE = !B3 && !ENC && !CHAIN;      // (the chained-tile experiment's kernel as it was measured: its register budget has no room)
+#else
+            constexpr bool LATE = false;
+#endif
+            const bool wait_here = ndep > 0 && (!NARROW || !tile_is_narrow(ks));
+            if (wait_here && !LATE) wait_deps_reg(dw, ndep, cnt, abort_flag, fargs->spin_ticks);
+            if (wait_here && LATE) late = LateWait{dw, ndep, cnt, abort_flag, fargs->spin_ticks};
 #ifdef R3D_TIMING
             if (dbg_arg && threadIdx.x == 0) dbg_arg[16384 + (long long)t * 4 + 1] = wall_clock64();      // producers ready
 #endif
@@ -3124,34 +3142,34 @@ __device__ __forceinline__ void gemm_persistent(float *smem) {
             }
             }
             if (ks > NB_CODE) {          // a single-unit tile of 4 .. 7 column blocks
-                if (ks == NB_CODE + 4) gemm_tile_nb<4>(P, row0, col0, smem, dbg);
-                else if (ks == NB_CODE + 5) gemm_tile_nb<5>(P, row0, col0, smem, dbg);
-                else if (ks == NB_CODE + 6) gemm_tile_nb<6>(P, row0, col0, smem, dbg);
-                else gemm_tile_nb<7>(P, row0, col0, smem, dbg);
+                if (ks == NB_CODE + 4) gemm_tile_nb<4>(P, row0, col0, smem, dbg, late);
+                else if (ks == NB_CODE + 5) gemm_tile_nb<5>(P, row0, col0, smem, dbg, late);
+                else if (ks == NB_CODE + 6) gemm_tile_nb<6>(P, row0, col0, smem, dbg, late);
+                else gemm_tile_nb<7>(P, row0, col0, smem, dbg, late);
                 break;
             }
             if (ks > 1) {
-                if (ks == 4) gemm_tile<1, 4>(P, row0, col0, smem, dbg);
-                else if (mi == 1) gemm_tile<1, 2>(P, row0, col0, smem, dbg);
-                else gemm_tile<2, 2>(P, row0, col0, smem, dbg);
+                if (ks == 4) gemm_tile<1, 4>(P, row0, col0, smem, dbg, late);
+                else if (mi == 1) gemm_tile<1, 2>(P, row0, col0, smem, dbg, late);
+                else gemm_tile<2, 2>(P, row0, col0, smem, dbg, late);
                 break;
             }
             if (P.w2 != nullptr) {       // fused pair (the scheduler caps these tiles at PAIR_MAX_MI units)
                 switch (mi) {
-                    case 1: gemm_tile<1, 1, true>(P, row0, col0, smem, dbg); break;
-                    case 2: gemm_tile<2, 1, true>(P, row0, col0, smem, dbg); break;
-                    case 3: gemm_tile<3, 1, true>(P, row0, col0, smem, dbg); break;
-                    default: gemm_tile<4, 1, true>(P, row0, col0, smem, dbg); break;
+                    case 1: gemm_tile<1, 1, true>(P, row0, col0, smem, dbg, late); break;
+                    case 2: gemm_tile<2, 1, true>(P, row0, col0, smem, dbg, late); break;
+                    case 3: gemm_tile<3, 1, true>(P, row0, col0, smem, dbg, late); break;
+                    default: gemm_tile<4, 1, true>(P, row0, col0, smem, dbg, late); break;
                 }
                 break;
             }
             switch (mi) {
-                case 1: gemm_tile<1, 1>(P, row0, col0, smem, dbg); break;
-                case 2: gemm_tile<2, 1>(P, row0, col0, smem, dbg); break;
-                case 3: gemm_tile<3, 1>(P, row0, col0, smem, dbg); break;
-                case 4: gemm_tile<4, 1>(P, row0, col0, smem, dbg); break;
-                case 5: gemm_tile<5, 1>(P, row0, col0, smem, dbg); break;
-                default: gemm_tile<6, 1>(P, row0, col0, smem, dbg); break;
+                case 1: gemm_tile<1, 1>(P, row0, col0, smem, dbg, late); break;
+                case 2: gemm_tile<2, 1>(P, row0, col0, smem, dbg, late); break;
+                case 3: gemm_tile<3, 1>(P, row0, col0, smem, dbg, late); break;
+                case 4: gemm_tile<4, 1>(P, row0, col0, smem, dbg, late); break;
+                case 5: gemm_tile<5, 1>(P, row0, col0, smem, dbg, late); break;
+                default: gemm_tile<6, 1>(P, row0, col0, smem, dbg, late); break;
             }
         }
         } while (false);
