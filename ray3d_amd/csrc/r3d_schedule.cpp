@@ -209,17 +209,19 @@ namespace {
 // prologue and run at 1.0 us per iteration.
 // Units of one to three iterations (the camera-embedding layers, K = 2 / 32) are all prologue and epilogue: 4 us per
 // unit by the workgroups' busy times (-DR3D_TIMING, R3D_TIMING_ALL), whatever the tile height.
-// (R3D_COST="iter,fixed,ks_iter,ks_fixed,first_extra,first_extra_wide,pair_scale": the constants, for tools/tune_cost.py)
+// (R3D_COST="iter,fixed,ks_iter,ks_fixed,first_extra,first_extra_wide,pair_scale[,nb_iter_extra,nb_fixed_extra]": the constants, for tools/tune_cost.py)
 struct CostModel {
     // (first_extra_wide 12 -> 7 and the fused pairs' second layer priced 8 % up: tools/tune_cost.py on the GPU - 1.946 against
     //  1.976 ms at 1024 windows, 0.591 against 0.589 at 256; the other constants sit on a plateau)
     double iter = 2200.0, fixed = 2500.0, ks_iter = 2600.0, ks_fixed = 6800.0, first_extra = 5.0, first_extra_wide = 7.0, pair_scale = 1.08;
+    double nb_iter_extra = 60.0, nb_fixed_extra = 1500.0;      // (gemm_tile_nb on top of the whole tile's staging / prologue: nb_cycles)
 };
 const CostModel &cost_model() {
     static const CostModel c = [] {
         CostModel m;
         if (const char *e = hook_env("R3D_COST"))
-            sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf,%lf", &m.iter, &m.fixed, &m.ks_iter, &m.ks_fixed, &m.first_extra, &m.first_extra_wide, &m.pair_scale);
+            sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf", &m.iter, &m.fixed, &m.ks_iter, &m.ks_fixed, &m.first_extra, &m.first_extra_wide, &m.pair_scale,
+                   &m.nb_iter_extra, &m.nb_fixed_extra);
         return m;
     }();
     return c;
@@ -234,7 +236,7 @@ double unit_cycles(int iters, int ks) {
 // barrier per K tile as in the whole tile (iter - 2048), prologue / epilogue plus the reduction of the split blocks
 double nb_cycles(int nk, int nb) {
     const CostModel &c = cost_model();
-    return nk * (64.0 * (16 + 4 * (nb - 4)) + (c.iter - 2048.0) + 60.0) + c.fixed + 1500.0;
+    return nk * (64.0 * (16 + 4 * (nb - 4)) + (c.iter - 2048.0) + c.nb_iter_extra) + c.fixed + c.nb_fixed_extra;
 }
 
 // a GEMV tile (r3d_kernels.hip): one memory round trip for the weights of its 32 columns, the operand copy, two barriers,
