@@ -1138,6 +1138,69 @@ def test_lanes_share_one_weight_image_and_lift_side_by_side():
         assert torch.equal(again, plain[0])
 
 
+def test_a_lanes_forward_is_captured_on_the_lanes_own_stream_and_a_relayed_capture_is_refused():
+    """R3D_OPT_LANES and hipGraphs (include/ray3d_hip.h, lanes): with the lanes' schedules pinned (r3d_prepare builds every lane's), a
+    forward issued on a lane's OWN stream can be captured there and the replay - on new input contents behind the same pointers -
+    equals the plain forward; a forward on a capturing stream that is no lane's would have to be relayed across streams inside the
+    capture, which the library refuses with R3D_ERR_STATE instead of recording half of it."""
+    import ray3d_amd
+    from ray3d_amd import synth, _capi
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
+    pos, trj, (cp, _), _ = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    dev = torch.device("cuda:0")
+    B = 207                                                     # a batch size nothing else in this process has used
+    xa = torch.from_numpy(synth.synth_rays(B, cp, seed=171)).cuda()
+    xb = torch.from_numpy(synth.synth_rays(B, cp, seed=173)).cuda()
+    p = torch.from_numpy(synth.synth_param(B, seed=172)).cuda()
+    with torch.no_grad():
+        want_a, want_b = lifter(xa, p).clone(), lifter(xb, p).clone()
+        torch.cuda.synchronize()
+        lifter.set_lanes(2)
+        lifter.prepare([B])                                     # every lane's schedule of this size, uploaded and pinned
+        with lifter.lane(1):                                    # (lane 1's workspace exists before anything is captured)
+            eager = lifter(xa, p)
+        lifter.join_lanes()
+        torch.cuda.synchronize()
+        tol = 2e-5 * max(1.0, float(want_a.abs().max()))
+        check_parity(eager, want_a.cpu().numpy(), "lane 1, eager, vs the whole-chip forward (HIP against HIP)", tol=tol)
+        x = xa.clone()
+        out = torch.empty((B, 1, 17, 3), device=dev)
+        s1 = lifter.lane_stream(1)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s1):
+            with torch.cuda.graph(g, stream=s1):
+                lifter._run(_capi.R3D_INPUT_RAYS, x, cp.receptive_field, B, p, 2, out=out)
+        for src, want in ((xa, want_a), (xb, want_b), (xa, want_a)):
+            x.copy_(src)
+            out.zero_()
+            torch.cuda.synchronize()
+            with torch.cuda.stream(s1):
+                g.replay()
+            torch.cuda.synchronize()
+            check_parity(out, want.cpu().numpy(), "lane 1, replayed capture, vs the whole-chip forward (HIP against HIP)", tol=tol)
+        lifter.check_status()
+        # a capturing stream that is no lane's: refused, nothing recorded, the handles stay usable
+        hp, ht = lifter.pos.handle(dev), lifter.trj.handle(dev)
+        ws = torch.empty(_capi.workspace_bytes(hp, ht, B), dtype=torch.uint8, device=dev)
+        inp = _capi.make_input(_capi.R3D_INPUT_RAYS, x.data_ptr(), cp.receptive_field, p.data_ptr(), 2)
+        side = torch.cuda.Stream()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g2, stream=side):
+                with pytest.raises(_capi_error(), match="cannot be captured from a caller's stream"):
+                    _capi.forward_pair(hp, ht, inp, B, out.data_ptr(), None, ws.data_ptr(), ws.numel(), side.cuda_stream)
+                out.add_(0.0)                                   # (a capture must not end empty)
+        with lifter.lane(0):
+            after = lifter(xb, p)
+        lifter.join_lanes()
+        torch.cuda.synchronize()
+        check_parity(after, want_b.cpu().numpy(), "lane 0 after the refused capture (HIP against HIP)", tol=tol)
+        lifter.release_prepared()
+        lifter.set_lanes(0)
+        assert torch.equal(lifter(xa, p), want_a)
+
+
 def test_lanes_keep_the_abort_contract(monkeypatch):
     """A lane's forward that cannot finish (hooks build: R3D_FAULT_TILE makes a tile never report) ends as without lanes: bounded
     spin, NaN outputs, r3d_status (which waits for the lanes) raises through check_status - and checked() repeats the call level
