@@ -212,6 +212,9 @@ int r3d_status(r3d_model *m, void *hip_stream);
                                    * One workspace per lane in flight (the caller's, as always).  Set it on both handles of a pair,
                                    * after r3d_finalize; it waits for the device, drops cached schedules and fails with
                                    * R3D_ERR_STATE while prepared (pinned) schedules exist.  r3d_prepare prepares every lane.
+                                   * hipGraphs: a forward issued on a lane's OWN stream can be captured there (after r3d_prepare); a
+                                   * forward on a capturing stream that is no lane's would have to be relayed inside the capture
+                                   * and is refused with R3D_ERR_STATE.
                                    * Abort contract as without lanes: a lane's forward that cannot get its workgroups resident
                                    * ends in NaN outputs and R3D_ERR_ABORTED from r3d_status (which waits for the lanes too).    */
 int r3d_set_option(r3d_model *m, int32_t option, int64_t value);
