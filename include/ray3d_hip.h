@@ -222,7 +222,8 @@ int r3d_set_option(r3d_model *m, int32_t option, int64_t value);
 /* R3D_OPT_LANES: the stream of lane `lane` (0 .. n - 1) of the handle (for a pair: the pos handle's lanes are the pair's) - a
  * hipStream_t the library owns; replaces nothing in the reference (its evaluation loop is sequential: trainer.py:295-353). */
 int r3d_lane_stream(r3d_model *m, int32_t lane, void **stream);
-/* ... and: make `stream` wait (device-side) for every forward that was relayed to a lane from another stream and not joined yet. */
+/* ... and: make `stream` wait (device-side) for every forward that was relayed to a lane and not joined yet by the stream that
+ * issued it.  Afterwards the forwards `stream` itself issued count as joined; those of other streams still wait for THEIR join. */
 int r3d_lanes_join(r3d_model *m, void *stream);
 
 /* ---- instrumentation (bench.py / tests) ---- */

@@ -739,8 +739,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
     if (rec.on()) a->nrec = (int)rec.n;
     if (relay) {                           // the caller's stream sees the outputs once it has joined this lane (r3d_lanes_join)
         if ((e = hipEventRecord(relay->done, relay->stream)) != hipSuccess) return hip_fail(e, "hipEventRecord(lane)");
-        relay->pending = true;
-        relay->for_stream = stream_v;
+        if (std::find(relay->waiters.begin(), relay->waiters.end(), stream_v) == relay->waiters.end()) relay->waiters.push_back(stream_v);
     }
     return R3D_OK;
 }
@@ -1217,10 +1216,11 @@ int r3d_lanes_join(r3d_model *m, void *stream) {
     if (!mm) { r3d::set_error("r3d_lanes_join: null model"); return R3D_ERR_ARG; }
     for (int k = 0; k < mm->lanes; ++k) {
         r3d::Model::Lane &ln = mm->lane[k];
-        if (!ln.pending) continue;
+        if (ln.waiters.empty()) continue;
+        // (every lane somebody still has to join: `stream` waits for more than its own forwards at most - never for less)
         hipError_t e = hipStreamWaitEvent((hipStream_t)stream, ln.done, 0);
         if (e != hipSuccess) return r3d::hip_fail(e, "hipStreamWaitEvent(lane)");
-        ln.pending = false;
+        ln.waiters.erase(std::remove(ln.waiters.begin(), ln.waiters.end(), stream), ln.waiters.end());
     }
     return R3D_OK;
 }

@@ -265,7 +265,14 @@ struct Model {
     // whose stream IS a lane's stream runs there; any other stream is served round-robin: the lane waits for the caller's stream,
     // and the caller's stream waits for the lanes at r3d_lanes_join (or when the same lane comes round again).
     int lanes = 0;
-    struct Lane { hipStream_t stream = nullptr; hipEvent_t done = nullptr, in = nullptr; bool pending = false; void *for_stream = nullptr; };
+    struct Lane {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr, in = nullptr;
+        // streams that had a forward relayed to this lane and have not joined it since (r3d_lanes_join): `done` is re-recorded behind
+        // every relayed forward and the lane is in order, so one wait on it covers all of them; a join by ONE stream must not
+        // make the lane look joined to the others
+        std::vector<void *> waiters;
+    };
     Lane lane[4];
     int next_lane = 0;
     const unsigned *last_clk_dev = nullptr;   // the clock stamp of the last single-launch forward (two words of its counter bank: r3d_last_clock)

@@ -334,7 +334,7 @@ class Ray3DLifter(nn.Module):
         self._lane_streams = [torch.cuda.ExternalStream(hp.lane_stream(k), device=dev) for k in range(n)]
         self._lane_ws = [_Workspace() for _ in range(n)]
         self._lane_rr = 0
-        self._lane_pending = [False] * n
+        self._lane_pending = [set() for _ in range(n)]
 
     def num_lanes(self) -> int:
         return getattr(self, "_lanes", 0)
@@ -363,20 +363,23 @@ class Ray3DLifter(nn.Module):
                 # (the legacy default stream needs no event: the lanes' streams are blocking streams and behind its work as they
                 #  are - and an event recorded on it would be behind the OTHER lanes' work in flight: the lanes would take turns)
                 st.wait_stream(cur)
-            self._lane_pending[kk] = True
+            self._lane_pending[kk].add(cur.cuda_stream)    # (the streams that still have to join this lane)
             with torch.cuda.stream(st):
                 yield kk
         return _cm()
 
     def join_lanes(self):
-        """The current stream waits for every lane that has run something since the last join (device-side)."""
+        """The current stream waits (device-side) for every lane that holds a forward its issuing stream has not joined yet; the
+        forwards issued from the current stream count as joined afterwards."""
         if not self.num_lanes():
             return
         cur = torch.cuda.current_stream(self._lane_dev)
         for kk, st in enumerate(self._lane_streams):
             if self._lane_pending[kk]:
+                # (every lane somebody still has to join: this stream waits for more than its own forwards at most; a join by one
+                #  stream does not make the lane look joined to the others)
                 cur.wait_stream(st)
-                self._lane_pending[kk] = False
+                self._lane_pending[kk].discard(cur.cuda_stream)
         self.pos.handle(self._lane_dev).lanes_join(cur.cuda_stream)      # (forwards the library itself relayed from this stream)
 
     def _lane_of_current_stream(self, dev):

@@ -1201,6 +1201,69 @@ def test_a_lanes_forward_is_captured_on_the_lanes_own_stream_and_a_relayed_captu
         assert torch.equal(lifter(xa, p), want_a)
 
 
+def test_lanes_join_is_per_issuing_stream():
+    """Two caller streams relay one forward each (lanes 0 and 1); stream A joins first.  A's join must not make lane 1 look joined
+    to stream B: B's own join still has to wait for B's forward - a copy of its output enqueued on B right behind the join holds the
+    poses, not the zeros the buffer held before.  (The first version kept one `pending` flag per lane and cleared it at ANY join.)
+    Through the C ABI (r3d_forward_pair + r3d_lanes_join) and through Ray3DLifter (forward on a side stream + join_lanes)."""
+    import ray3d_amd
+    from ray3d_amd import synth, _capi
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3,3,3")
+    pos, trj, (cp, _), _ = build_modules(mc)
+    lifter = ray3d_amd.Ray3DLifter(pos, trj).eval()
+    dev = torch.device("cuda:0")
+    B = 512                                                      # (a forward of about 2 ms on half the chip: long against a join)
+    xa = torch.from_numpy(synth.synth_rays(B, cp, seed=181)).cuda()
+    xb = torch.from_numpy(synth.synth_rays(B, cp, seed=183)).cuda()
+    p = torch.from_numpy(synth.synth_param(B, seed=182)).cuda()
+    with torch.no_grad():
+        want_a, want_b = lifter(xa, p).clone(), lifter(xb, p).clone()
+        torch.cuda.synchronize()
+        tol = 2e-5 * max(1.0, float(want_a.abs().max()), float(want_b.abs().max()))
+        lifter.set_lanes(2)
+        hp, ht = lifter.pos.handle(dev), lifter.trj.handle(dev)
+        nws = _capi.workspace_bytes(hp, ht, B)
+        ws_a, ws_b = (torch.empty(nws, dtype=torch.uint8, device=dev) for _ in range(2))
+        out_a, out_b = torch.zeros_like(want_a), torch.zeros_like(want_b)
+        snap_a, snap_b = torch.empty_like(want_a), torch.empty_like(want_b)
+        inp_a = _capi.make_input(_capi.R3D_INPUT_RAYS, xa.data_ptr(), cp.receptive_field, p.data_ptr(), 2)
+        inp_b = _capi.make_input(_capi.R3D_INPUT_RAYS, xb.data_ptr(), cp.receptive_field, p.data_ptr(), 2)
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        for rep in range(3):
+            out_a.zero_()
+            out_b.zero_()
+            torch.cuda.synchronize()
+            _capi.forward_pair(hp, ht, inp_a, B, out_a.data_ptr(), None, ws_a.data_ptr(), ws_a.numel(), sa.cuda_stream)
+            _capi.forward_pair(hp, ht, inp_b, B, out_b.data_ptr(), None, ws_b.data_ptr(), ws_b.numel(), sb.cuda_stream)
+            hp.lanes_join(sa.cuda_stream)                       # A first ...
+            hp.lanes_join(sb.cuda_stream)                       # ... B's join still waits for B's forward
+            with torch.cuda.stream(sb):
+                snap_b.copy_(out_b)
+            with torch.cuda.stream(sa):
+                snap_a.copy_(out_a)
+            torch.cuda.synchronize()
+            check_parity(snap_b, want_b.cpu().numpy(), "C ABI, stream B behind its own join (HIP against HIP)", tol=tol)
+            check_parity(snap_a, want_a.cpu().numpy(), "C ABI, stream A behind its own join (HIP against HIP)", tol=tol)
+        # the same through the module: forwards issued on two side streams are relayed by Ray3DLifter.lane()
+        for rep in range(3):
+            torch.cuda.synchronize()
+            with torch.cuda.stream(sa):
+                oa = lifter(xa, p)
+            with torch.cuda.stream(sb):
+                ob = lifter(xb, p)
+            with torch.cuda.stream(sa):
+                lifter.join_lanes()
+                ca = oa.clone()
+            with torch.cuda.stream(sb):
+                lifter.join_lanes()
+                cb = ob.clone()
+            torch.cuda.synchronize()
+            check_parity(cb, want_b.cpu().numpy(), "module, stream B behind its own join (HIP against HIP)", tol=tol)
+            check_parity(ca, want_a.cpu().numpy(), "module, stream A behind its own join (HIP against HIP)", tol=tol)
+        lifter.check_status()
+        lifter.set_lanes(0)
+
+
 def test_lanes_keep_the_abort_contract(monkeypatch):
     """A lane's forward that cannot finish (hooks build: R3D_FAULT_TILE makes a tile never report) ends as without lanes: bounded
     spin, NaN outputs, r3d_status (which waits for the lanes) raises through check_status - and checked() repeats the call level
