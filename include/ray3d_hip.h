@@ -12,7 +12,8 @@
  * was current at r3d_finalize().  Threading: a handle - and a (pos, trj) pair used together - must
  * be driven by one thread at a time (its launch plans, per-batch-size tile schedules and profiling
  * records are unguarded caches); different handles are independent and may be used concurrently
- * (the registry that maps handle pairs to plans is mutex-guarded, r3d_last_error() is thread-local).
+ * (the registry that maps handle pairs to plans is mutex-guarded, r3d_last_error() is thread-local; the ordering of whole-device
+ * forwards - two of them must never share the chip - and the launch it protects are one critical section across threads).
  * Every call enqueues on the given hipStream_t (passed as void*) and returns without syncing.
  * The first forward of a new batch size builds and uploads a tile schedule (hipMalloc + blocking
  * hipMemcpy): call r3d_prepare() for that size beforehand when the forward is to be captured into

@@ -232,6 +232,7 @@ struct FwdOrder {
     unsigned long long gen[64] = {0};
 };
 static FwdOrder g_fwd_order;
+static std::mutex g_fwd_launch_mu;      // order_single_launch(before) .. launch .. order_single_launch(after) of one forward
 
 // A stream of the library's own is about to be destroyed: nothing may record events on it any more.
 static void order_forget(hipStream_t stream) {
@@ -496,6 +497,9 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         for (int k = 0; bound && k < BIND_NBASE; ++k) bound = bd.base[k] == ba.base[k];
         const int bank = bound ? bd.bank ^ 1 : 0;
         unsigned *cnt = reinterpret_cast<unsigned *>(ctrl + (own ? bank : 0) * bank_bytes);
+        // (handles of different threads: the waits below, the launch and the note of whose forward was last are one critical section -
+        //  two threads that both passed the waits before either had launched would put two whole-device forwards on the chip together)
+        std::unique_lock<std::mutex> launch_lock(g_fwd_launch_mu);
         if ((e = order_single_launch(stream, true, cu_limit > 0)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
         // one handle on two masked streams: its counter banks and control region are one per handle - the second stream waits for the first
         if (cu_limit > 0 && lanes <= 1 && a->last_fwd_stream && a->last_fwd_stream != stream) {
@@ -559,6 +563,7 @@ static int run(Model *pos, Model *trj, const r3d_input *in, int64_t B, float *ou
         if ((e = launch_forward(fa, fw.grid, fwd_kernel, uv_launch, stream)) != hipSuccess) return hip_fail(e, "launch r3d_forward_f32");
         a->last_clk_dev = cap == hipStreamCaptureStatusNone ? cnt + fw.ncnt + 2 : nullptr;   // (a captured call runs later, maybe never)
         if ((e = order_single_launch(stream, false, cu_limit > 0)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+        launch_lock.unlock();
         if (own) {                     // the next call on these buffers needs no bind
             bd.valid = true;
             bd.bank = bank;

@@ -1264,6 +1264,51 @@ def test_lanes_join_is_per_issuing_stream():
         lifter.set_lanes(0)
 
 
+def test_two_threads_with_their_own_handles_and_streams():
+    """include/ray3d_hip.h, threading: different handles may be driven from different threads.  Two threads, each with its own pair of
+    handles and its own stream, issue single-launch forwards at the same time (ctypes releases the GIL inside the call): every result
+    equals the one-thread result bit for bit and no forward gives up waiting for its tiles - the library's ordering of whole-device
+    forwards (waits, launch, note of the last forward's stream) is one critical section, so two of them never share the chip."""
+    import threading
+    import ray3d_amd
+    from ray3d_amd import synth
+    mc = ray3d_amd.default_model_config(ARCHITECTURE="3,3,3")
+    B, reps = 256, 40
+    lifters, xs, wants = [], [], []
+    for t in range(2):
+        pos, trj, (cp, _), _ = build_modules(mc)
+        lifters.append(ray3d_amd.Ray3DLifter(pos, trj).eval())
+        xs.append(torch.from_numpy(synth.synth_rays(B, cp, seed=191 + t)).cuda())
+    p = torch.from_numpy(synth.synth_param(B, seed=190)).cuda()
+    with torch.no_grad():
+        for t in range(2):
+            wants.append(lifters[t](xs[t], p).clone())
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    errors, gate = [], threading.Barrier(2)
+
+    def work(t):
+        try:
+            with torch.no_grad(), torch.cuda.stream(streams[t]):
+                gate.wait()
+                for _ in range(reps):
+                    out = lifters[t](xs[t], p)
+                    if not torch.equal(out, wants[t]):          # (the comparison synchronises this thread's stream)
+                        errors.append("thread %d: a forward differs from the one-thread result" % t)
+                        return
+                lifters[t].check_status()
+        except Exception as e:                                   # noqa: BLE001 - reported by the assertion below
+            errors.append("thread %d: %r" % (t, e))
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    torch.cuda.synchronize()
+    assert not any(th.is_alive() for th in threads), "a thread hangs"
+    assert not errors, errors
+
+
 def test_lanes_keep_the_abort_contract(monkeypatch):
     """A lane's forward that cannot finish (hooks build: R3D_FAULT_TILE makes a tile never report) ends as without lanes: bounded
     spin, NaN outputs, r3d_status (which waits for the lanes) raises through check_status - and checked() repeats the call level
