@@ -773,10 +773,16 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == world
 
+    bar_token = torch.zeros(1, dtype=torch.float32, device=dev) if dist is not None else None
+
     def barrier():
+        # the device's work done, then a collective that every rank has to enter (a one-element all_reduce over RCCL on a
+        # preallocated tensor), then its completion: a barrier + synchronize.  (dist.barrier() does the same through a blocking
+        # wait of its own whose wake-up granularity - 0 .. 0.7 ms per call, measured under the launcher with one rank - would be
+        # charged to the K timed steps: 20 steps are 11 ms.)
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.all_reduce(bar_token)
             torch.cuda.synchronize()
 
     def max_over_ranks(v):
