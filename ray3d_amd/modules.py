@@ -505,8 +505,8 @@ class Ray3DLifter(nn.Module):
         """Batch sizes of the forwards that lift an n-window clip: ceil(n / CLIP_CHUNK) near-equal calls, each rounded up to a
         multiple of CLIP_ROUND (a short clip: to 1, 2, 4 ... 64 when it is that short), so that clips of any lengths share a
         handful of tile schedules (the library builds and uploads one per batch size) and no clip ends in a short,
-        inefficient rest call: a 5000-window clip is 2560 + 2560 (60 surplus windows), not 4096 + 1024 (120).  The sum
-        exceeds n by less than CLIP_ROUND.  CLIP_ROUND = 0 lifts exact sizes."""
+        inefficient rest call: a 5000-window clip is 2560 + 2560, not 4096 + 1024 (the same 120 surplus windows, no short call).  The
+        sum exceeds n by less than k * CLIP_ROUND.  CLIP_ROUND = 0 lifts exact sizes."""
         chunk, rnd = self.CLIP_CHUNK, self.CLIP_ROUND
         k = -(-n // chunk)
         sizes = []
