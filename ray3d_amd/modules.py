@@ -506,7 +506,7 @@ class Ray3DLifter(nn.Module):
         multiple of CLIP_ROUND (a short clip: to 1, 2, 4 ... 64 when it is that short), so that clips of any lengths share a
         handful of tile schedules (the library builds and uploads one per batch size) and no clip ends in a short,
         inefficient rest call: a 5000-window clip is 2560 + 2560, not 4096 + 1024 (the same 120 surplus windows, no short call).  The
-        sum exceeds n by less than k * CLIP_ROUND.  CLIP_ROUND = 0 lifts exact sizes."""
+        sum exceeds n by less than CLIP_ROUND (the last call takes what the rounded-up ones left).  CLIP_ROUND = 0 lifts exact sizes."""
         chunk, rnd = self.CLIP_CHUNK, self.CLIP_ROUND
         k = -(-n // chunk)
         sizes = []
