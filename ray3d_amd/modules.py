@@ -436,6 +436,9 @@ class Ray3DLifter(nn.Module):
                 caller = torch.cuda.current_stream(dev)
                 with self.lane() as k2:
                     res = self._run(mode, x, window_stride, B, param, param_stride, cam, cam_stride, return_trj, out, self._lane_ws[k2])
+                    for t in (x, param, cam, out):
+                        if t is not None:
+                            t.record_stream(self._lane_streams[k2])   # (allocated under the caller's stream, read / written on the lane's)
                 for t in (res if isinstance(res, tuple) else (res,)):
                     if t is not None:
                         t.record_stream(caller)        # (allocated under the lane's stream, consumed on the caller's after join_lanes)
