@@ -326,6 +326,9 @@ class Ray3DLifter(nn.Module):
         n = 0 if n <= 1 else n
         hp, ht = self.pos.handle(dev), self.trj.handle(dev)
         self.release_prepared()
+        if getattr(self, "_lane_keep", None):
+            torch.cuda.synchronize(dev)          # (their events live on the lanes' streams, which the option change destroys)
+            self._lane_keep = []
         with torch.cuda.device(dev):
             hp.set_option(_capi.R3D_OPT_LANES, n)
             ht.set_option(_capi.R3D_OPT_LANES, n)
@@ -335,6 +338,7 @@ class Ray3DLifter(nn.Module):
         self._lane_ws = [_Workspace() for _ in range(n)]
         self._lane_rr = 0
         self._lane_pending = [set() for _ in range(n)]
+        self._lane_keep = []                 # (event, tensors) of relayed forwards still in flight: see _run
 
     def num_lanes(self) -> int:
         return getattr(self, "_lanes", 0)
@@ -436,9 +440,17 @@ class Ray3DLifter(nn.Module):
                 caller = torch.cuda.current_stream(dev)
                 with self.lane() as k2:
                     res = self._run(mode, x, window_stride, B, param, param_stride, cam, cam_stride, return_trj, out, self._lane_ws[k2])
-                    for t in (x, param, cam, out):
-                        if t is not None:
-                            t.record_stream(self._lane_streams[k2])   # (allocated under the caller's stream, read / written on the lane's)
+                    # the caller's tensors are read / written on the lane's stream: keep them alive until the lane is past this forward
+                    # (a caller on a side stream that drops its input right after the call would otherwise get the block back from
+                    # the caching allocator and overwrite it on its own stream while the lane still reads it).  Not record_stream on
+                    # the lane's stream: the allocator would record an event there when the tensor dies - after set_lanes(0) that
+                    # stream is gone.
+                    done = torch.cuda.Event()
+                    done.record(self._lane_streams[k2])
+                    keep = self._lane_keep
+                    while keep and keep[0][0].query():
+                        keep.pop(0)
+                    keep.append((done, x, param, cam, out))
                 for t in (res if isinstance(res, tuple) else (res,)):
                     if t is not None:
                         t.record_stream(caller)        # (allocated under the lane's stream, consumed on the caller's after join_lanes)
