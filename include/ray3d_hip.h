@@ -205,6 +205,8 @@ int r3d_status(r3d_model *m, void *hip_stream);
                                    *  - any other stream: lanes are served round-robin; the lane's stream waits for everything the
                                    *    caller's stream holds so far, runs the forward, and the caller's stream sees the outputs
                                    *    after r3d_lanes_join(m, stream) - NOT at return as without lanes.
+                                   *    Until that join the forward's inputs, workspace and outputs belong to the lane: the
+                                   *    caller's stream must not overwrite or free them (it is not ordered behind the lane).
                                    *    (a caller on the LEGACY DEFAULT stream: the lanes' streams are blocking streams - they are
                                    *    behind the default stream's work without an event, and none is recorded there, because an
                                    *    event on the default stream is behind every blocking stream's work: the lanes would take
