@@ -794,7 +794,7 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin, int lane) {
         if (pin) it->second->pinned = true;
         return it->second;
     }
-    // The cache is bounded at 64 UNPINNED batch sizes: the least recently used one goes.  Sizes named in r3d_prepare are
+    // The cache is bounded at 64 UNPINNED batch sizes (per lane): the least recently used one goes.  Sizes named in r3d_prepare are
     // pinned - a captured hipGraph replays kernels whose arguments point into the schedule and never comes back here -
     // and do not count.  The victim's launches may still be in flight on any stream, hence the device-wide
     // synchronisation before its tile lists are freed; when that fails (another stream is capturing, a sticky error)
@@ -802,7 +802,10 @@ Schedule *schedule_get(Plan *pl, int64_t B, int nwg, bool pin, int lane) {
     {
         size_t unpinned = 0;
         for (int64_t b : pl->schedule_lru) unpinned += pl->schedules[b]->pinned ? 0 : 1;
-        if (unpinned >= 64) {
+        // (R3D_OPT_LANES: every lane holds its own schedule of a size - the bound is per lane, or an evaluation's 25 call sizes on four
+        //  lanes would evict, and synchronise the device, with every call)
+        const size_t cap = 64 * (size_t)std::max(1, pl->m[0] ? pl->m[0]->lanes : 1);
+        if (unpinned >= cap) {
             auto victim = std::find_if(pl->schedule_lru.begin(), pl->schedule_lru.end(), [&](int64_t b) { return !pl->schedules[b]->pinned; });
             if (victim != pl->schedule_lru.end() && hipDeviceSynchronize() == hipSuccess) {
                 const int64_t old = *victim;
